@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- M edges/s of the message-passing hot path (encoder fwd+bwd) on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one synthetic everyday-deform batch of 32
+sample pairs per GPU (BASELINE.json configs[1]): forward through the 2+2 TAGConv
+layers of the soft / rigid branches (12 hops + dense blocks), backward from a fixed
+synthetic upstream gradient (6 transposed hops + dW/dX), gradient all-reduce over
+RCCL when N > 1, and one Adam step on the encoder parameters.  Inputs are resident
+in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+SOFT = dict(n=1024, e=6132)   # per sample
+RIGID = dict(n=762, e=4560)
+
+
+def hop_bytes(n: int, e: int, f: int, addend: bool) -> int:
+    """Algorithmic bytes of one hop launch (SURVEY.md 8(d) gather model):
+    E*(4 idx + 4 w + 4F gathered row) + N*(4F written row + 4 ptr) [+ N*4F addend read]."""
+    return e * (8 + 4 * f) + n * (4 * f + 4) + (n * 4 * f if addend else 0)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="sample pairs per GPU")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-optim", action="store_true", help="leave the Adam step out of the step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--kernel-reps", type=int, default=100)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch: int, budget_s: float):
+    """Reference CPU op sequence (oracle/pyg_ref.py: index_select -> mul -> scatter_add_,
+    gcn_norm per conv call, 4 F.linear per TAGConv) on the host cores: encoder fwd+bwd on a
+    bounded number of iterations of the same B=32 workload.  Reported, not a target."""
+    from deformcontact_amd import synth
+    from deformcontact_amd.graphnet import ContactEncoder
+    from oracle import pyg_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rest, _, rig = synth.make_batch(batch)
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256, conv_module=pyg_ref)
+    g_rest = torch.randn(rest.x.shape[0], 256)
+    g_rig = torch.randn(rig.x.shape[0], 256)
+    edges = rest.edge_index.shape[1] + rig.edge_index.shape[1]
+
+    def one():
+        enc.zero_grad(set_to_none=True)
+        a, b = enc(rest, rig)
+        torch.autograd.backward([a, b], [g_rest, g_rig])
+
+    one()                                    # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(edges / med / 1e6, 4), "unit": "M edges/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{len(times)} timed iterations (1 warm-up) of the same B={batch} encoder "
+                      f"fwd+bwd, median {med * 1e3:.1f} ms, torch {torch.__version__} CPU ops, "
+                      f"{cores} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in deformcontact_amd)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from deformcontact_amd import dp, ops, synth
+    from deformcontact_amd.graph import graph_index
+    from deformcontact_amd.graphnet import ContactEncoder
+
+    # ---- workload: B sample pairs per rank, distinct geometry per rank (weak scaling) ----
+    rest, _, rig = synth.make_batch(args.batch, first_idx=rank * args.batch)
+    rest, rig = rest.to(dev), rig.to(dev)
+    n_s, e_s = rest.x.shape[0], rest.edge_index.shape[1]
+    n_r, e_r = rig.x.shape[0], rig.edge_index.shape[1]
+    edges_per_rank = e_s + e_r
+    torch.manual_seed(0)                      # identical init on every rank
+    enc = ContactEncoder([21, 25], 256).to(dev)
+    dp.broadcast_parameters(enc)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    g_rest = torch.randn(n_s, 256, device=dev, generator=gen)
+    g_rig = torch.randn(n_r, 256, device=dev, generator=gen)
+    bucket = dp.GradBucket(enc.parameters())
+    opt = None if args.no_optim else torch.optim.Adam(enc.parameters(), lr=4e-4, capturable=True)
+    # topology is built once per batch (cached on edge_index), as a data loader would
+    graph_index(rest.edge_index, n_s)
+    graph_index(rig.edge_index, n_r)
+
+    def fwd_bwd():
+        bucket.zero()
+        a, b = enc(rest, rig)
+        torch.autograd.backward([a, b], [g_rest, g_rig])
+
+    def tail():
+        bucket.all_reduce_mean()
+        if opt is not None:
+            opt.step()
+
+    # ---- capture fwd+bwd (+ Adam when single-GPU) in a hipGraph ----
+    graph = None
+    graph_has_tail = False
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fwd_bwd()
+            tail()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            graph_has_tail = world == 1
+            with torch.cuda.graph(graph):
+                fwd_bwd()
+                if graph_has_tail:
+                    tail()
+        except Exception as e:  # pragma: no cover
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager",
+                      file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            if not graph_has_tail:
+                tail()
+        else:
+            fwd_bwd()
+            tail()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = edges_per_rank * world * args.steps / elapsed / 1e6
+
+    out = {
+        "metric": "M edges/sec fwd+bwd, everyday-deform batch=32 per GPU (encoder hot path)",
+        "value": round(value, 3), "unit": "M edges/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"everyday-deform synthetic, B={args.batch} sample pairs per GPU: soft "
+                        f"{args.batch}x(1024 v, 6132 e) + rigid {args.batch}x(762 v, 4560 e); "
+                        "TAGConv encoder 2 layers/branch, hidden 256, K=3 (configs[1])",
+            "edges_per_gpu_step": edges_per_rank, "global_batch": args.batch * world,
+            "step": "fwd + bwd(synthetic upstream grad)" + (" + RCCL grad all-reduce" if world > 1 else "")
+                    + ("" if args.no_optim else " + Adam"),
+            "hipgraph": graph is not None, "parallelism": f"dp{world}",
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the F=256 hop (k_spmm_wave<4,8>) ----
+        gs, gr = graph_index(rest.edge_index, n_s), graph_index(rig.edge_index, n_r)
+        f = 256
+        cases = []
+        for g, n, e in ((gs, n_s, e_s), (gr, n_r, e_r)):
+            slab = torch.randn(n, 3 * f, device=dev)
+            x = torch.randn(n, f, device=dev)
+            cases.append((g.fwd, x, slab[:, :f], None, hop_bytes(n, e, f, False)))       # fwd hop
+            cases.append((g.bwd, slab[:, f:2 * f], slab[:, 2 * f:], slab[:, 2 * f:],
+                          hop_bytes(n, e, f, True)))                                   # bwd hop
+        tot_bytes, tot_ms, per_case = 0.0, 0.0, []
+        for adj, x, o, add, nbytes in cases:
+            for _ in range(5):
+                ops.hop(adj, x, out=o, addend=add)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(args.kernel_reps):
+                ops.hop(adj, x, out=o, addend=add)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = ev0.elapsed_time(ev1) / args.kernel_reps
+            tot_bytes += nbytes
+            tot_ms += ms
+            per_case.append({"bytes": nbytes, "us": round(ms * 1e3, 2),
+                             "GBps": round(nbytes / ms / 1e6, 1)})
+        achieved = tot_bytes / tot_ms / 1e6                      # GB/s
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_hop.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "dc::k_spmm_wave<4,8> (F=256 hop)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(tot_bytes / len(cases)),
+            "avg_launch_us": round(tot_ms / len(cases) * 1e3, 2),
+            "cases": {"soft_fwd": per_case[0], "soft_bwd": per_case[1],
+                      "rigid_fwd": per_case[2], "rigid_bwd": per_case[3]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""ctypes binding of ``libdeformcontact_hip.so`` (the C ABI in ``include/deformcontact.h``).
+
+There is deliberately NO fallback: if the library is missing or fails to load,
+every op raises.  The CPU oracle under ``oracle/`` is test infrastructure and is
+never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdeformcontact_hip.so")
+
+_lib = None
+
+_vp = c_void_p
+_SIGNATURES = {
+    "dc_version": (c_int, []),
+    "dc_last_error": (c_char_p, []),
+    "dc_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "dc_csr_build": (c_int, [_vp, c_int64, c_int64, c_int, c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _vp, c_int64, _vp]),
+    "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
+    "dc_spmm_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
+                            c_int64, _vp]),
+    "dc_compose_perm": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp]),
+    "dc_gat_edge_softmax_fwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, c_int64, _vp]),
+    "dc_gat_edge_softmax_bwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, _vp, _vp, _vp, c_int64,
+                                        _vp]),
+    "dc_sddmm_f32": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64, _vp]),
+    "dc_segment_sum_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp]),
+    "dc_gather_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp]),
+}
+
+
+class DeformContactLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise DeformContactLibraryError(
+                f"{SO_PATH} not found. Build it with `python -m deformcontact_amd.build` "
+                "(hipcc --offload-arch=gfx950). deformcontact_amd has no CPU/PyTorch fallback.")
+        try:
+            handle = ctypes.CDLL(SO_PATH)
+        except OSError as e:  # pragma: no cover
+            raise DeformContactLibraryError(f"cannot load {SO_PATH}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise DeformContactLibraryError(
+                    f"{SO_PATH} does not export {name}; rebuild the library") from e
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().dc_last_error()
+        raise DeformContactLibraryError(
+            f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def exported_names():
+    return list(_SIGNATURES)

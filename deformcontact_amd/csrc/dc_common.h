@@ -1,0 +1,46 @@
+// dc_common.h -- shared helpers for the gfx950 kernels (internal; the public
+// surface is include/deformcontact.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/deformcontact.h"
+
+namespace dc {
+
+constexpr int kWave = 64;      // CDNA4 wavefront
+constexpr int kXcds = 8;       // MI355X: 8 XCDs, each with a private 4 MiB L2
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return DC_ELAUNCH;
+    }
+    return DC_OK;
+}
+
+// XCD-aware block remap (bijective for any grid size).  Workgroups are dealt
+// round-robin over the 8 XCDs, so hardware blocks b and b+8 share an L2.  The
+// remap hands XCD k the k-th CONTIGUOUS chunk of logical blocks: rows of one
+// mesh (block-diagonal batch => its neighbours too) are then gathered through
+// one L2 instead of all eight.  Speed only; any placement is correct.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk / kXcds, r = nblk % kXcds;
+    const unsigned xcd = bid % kXcds, idx = bid / kXcds;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace dc
+
+#define DC_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            dc::set_error(__VA_ARGS__);  \
+            return DC_EINVAL;            \
+        }                                \
+    } while (0)

@@ -1,0 +1,127 @@
+"""Encoder / full-network harness with the reference's parameter names.
+
+``ContactEncoder`` is the hot path as the reference wires it
+(``/root/reference/models/model.py:39-50`` construction, ``:69-78`` forward):
+two branches (soft "resting" mesh, rigid contact sphere) of ``encoder_layers``
+conv layers, each followed by ReLU and dropout.  ``GraphNet`` adds the parts that
+are out of the hot path but needed for full-step parity (``:7-21`` unmasked
+multi-head cross attention, ``:52-64`` decoder, ``:91-95`` residual output) on
+stock PyTorch.  ``state_dict()`` keys equal the reference's, so its checkpoints
+load (``eval.py:36,89``).
+
+The reference's own ``models/model.py`` also runs unchanged on this package via
+``deformcontact_amd.install_as_torch_geometric()``; this module exists so that
+bench / tests / training on the GPU box need no file from ``/root/reference``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nn as dc_nn
+
+
+def _conv_class(backbone: str, conv_module):
+    mod = conv_module if conv_module is not None else dc_nn
+    # same fall-through as the reference: anything that is not GAT/GCN is TAG
+    name = backbone if backbone in ("GATConv", "GCNConv") else "TAGConv"
+    return getattr(mod, name)
+
+
+class ContactEncoder(nn.Module):
+    def __init__(self, input_dims: Sequence[int], hidden_dim: int, encoder_layers: int = 2,
+                 dropout_rate: float = 0.0, backbone: str = "TAGConv", conv_module=None):
+        super().__init__()
+        conv = _conv_class(backbone, conv_module)
+        self.backbone, self.dropout_rate, self.encoder_layers = backbone, dropout_rate, encoder_layers
+        widths_rest = [input_dims[0]] + [hidden_dim] * encoder_layers
+        widths_rig = [input_dims[1]] + [hidden_dim] * encoder_layers
+        self.conv_layers_resting = nn.ModuleList(
+            conv(a, b) for a, b in zip(widths_rest[:-1], widths_rest[1:]))
+        self.conv_layers_rigid = nn.ModuleList(
+            conv(a, b) for a, b in zip(widths_rig[:-1], widths_rig[1:]))
+
+    def _branch(self, layers, x, edge_index):
+        for conv in layers:
+            x = F.relu(conv(x, edge_index))
+            x = F.dropout(x, p=self.dropout_rate, training=self.training)
+        return x
+
+    def encode(self, graph_resting, graph_rigid) -> Tuple[torch.Tensor, torch.Tensor]:
+        return (self._branch(self.conv_layers_resting, graph_resting.x, graph_resting.edge_index),
+                self._branch(self.conv_layers_rigid, graph_rigid.x, graph_rigid.edge_index))
+
+    def forward(self, graph_resting, graph_rigid):
+        return self.encode(graph_resting, graph_rigid)
+
+
+class CrossAttention(nn.Module):
+    """The reference's ``MultiHeadAttention``: per head one ``Linear(d, d)`` shared by
+    queries and keys, raw rigid features as values, no 1/sqrt(d), no per-graph mask."""
+
+    def __init__(self, feature_dim: int, num_heads: int):
+        super().__init__()
+        self.attention_heads = nn.ModuleList(
+            nn.Linear(feature_dim, feature_dim) for _ in range(num_heads))
+
+    def forward(self, x_resting, x_rigid):
+        pooled = []
+        for head in self.attention_heads:
+            scores = head(x_resting) @ head(x_rigid).t()
+            pooled.append(torch.softmax(scores, dim=-1) @ x_rigid)
+        return torch.cat(pooled, dim=-1)
+
+
+class GraphNet(ContactEncoder):
+    def __init__(self, input_dims, hidden_dim, output_dim, encoder_layers, decoder_layers,
+                 dropout_rate, knn_k=None, backbone="TAGConv", use_mha=True, num_mha_heads=2,
+                 mode="res", conv_module=None):
+        super().__init__(input_dims, hidden_dim, encoder_layers, dropout_rate, backbone, conv_module)
+        self.mode, self.use_mha = mode, use_mha
+        width = hidden_dim * (num_mha_heads + 1) if use_mha else hidden_dim * 2
+        blocks = []
+        for _ in range(decoder_layers):
+            blocks += [nn.Linear(width, hidden_dim), nn.ReLU(), nn.Dropout(dropout_rate)]
+            width = hidden_dim
+        blocks.append(nn.Linear(hidden_dim, output_dim))
+        self.decoder = nn.Sequential(*blocks)
+        self.multihead_attention = CrossAttention(hidden_dim, num_mha_heads)
+
+    def forward(self, graph_resting, graph_rigid):
+        x_rest, x_rig = self.encode(graph_resting, graph_rigid)
+        pooled = self.multihead_attention(x_rest, x_rig)     # always applied (reference quirk)
+        delta = self.decoder(torch.cat([x_rest, pooled], dim=-1))
+        out = graph_resting.clone()
+        if self.mode == "res":
+            out.pos = out.pos + delta
+        elif self.mode == "rec":
+            out.pos = delta
+        return out
+
+
+def gradient_consistency_loss(pred, target) -> torch.Tensor:
+    """``models/losses.py:7-19``: mean over edges of the L2 norm of the difference of
+    edge vectors between prediction and target."""
+    ei_t, ei_p = target.edge_index, pred.edge_index
+    d_t = target.pos[ei_t[1]] - target.pos[ei_t[0]]
+    d_p = pred.pos[ei_p[1]] - pred.pos[ei_p[0]]
+    return (d_t - d_p).norm(p=2, dim=-1).sum() / ei_t.size(1)
+
+
+def load_model(network_cfg, conv_module=None) -> GraphNet:
+    """``models/model_loader.py:3-16`` for a ``config.network``-like object or dict."""
+    get = (lambda k: network_cfg[k]) if isinstance(network_cfg, dict) else \
+        (lambda k: getattr(network_cfg, k))
+    return GraphNet(input_dims=list(get("input_dims")), hidden_dim=get("hidden_dim"),
+                    output_dim=get("output_dim"), encoder_layers=get("encoder_layers"),
+                    decoder_layers=get("decoder_layers"), dropout_rate=get("dropout_rate"),
+                    knn_k=get("knn_k"), backbone=get("backbone"), use_mha=get("use_mha"),
+                    num_mha_heads=get("num_mha_heads"), mode=get("mode"), conv_module=conv_module)
+
+
+EVERYDAY_NETWORK = dict(input_dims=[21, 25], use_mha=True, num_mha_heads=2, hidden_dim=256,
+                        output_dim=3, encoder_layers=2, decoder_layers=3, dropout_rate=0.0,
+                        knn_k=7, backbone="TAGConv", mode="res")  # configs/everyday.json:36-47

@@ -1,0 +1,161 @@
+"""``TAGConv`` / ``GCNConv`` / ``GATConv`` on the HIP hop kernels.
+
+Drop-in for the PyG classes the reference instantiates at
+``/root/reference/models/model.py:39-50`` and calls at ``:71,77``.  Parameter
+names, shapes and default initialisers follow PyG 2.5.2 so reference
+checkpoints (``eval.py:36,89``: ``load_state_dict(torch.load(...))``) load
+unchanged:
+
+* ``TAGConv``: ``lins.{0..K}.weight [out,in]`` (no per-lin bias), ``bias [out]``;
+* ``GCNConv``: ``lin.weight [out,in]`` (glorot), ``bias [out]``;
+* ``GATConv``: ``lin.weight [H*out,in]`` (glorot), ``att_src/att_dst [1,H,out]``,
+  ``bias [H*out]``.
+
+No CPU path: calling a conv with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+from ..graph import GraphIndex, _require_cuda, graph_index
+
+
+class _Lin(nn.Module):
+    """Parameter holder mirroring ``torch_geometric.nn.dense.Linear(bias=False)``."""
+
+    def __init__(self, in_channels: int, out_channels: int, initializer: Optional[str] = None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.initializer = in_channels, out_channels, initializer
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.initializer == "glorot":
+            a = math.sqrt(6.0 / (self.in_channels + self.out_channels))
+        else:  # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+            a = 1.0 / math.sqrt(self.in_channels)
+        with torch.no_grad():
+            self.weight.uniform_(-a, a)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return torch.nn.functional.linear(x, self.weight)
+
+
+def _check_inputs(x: Tensor, edge_index: Tensor, in_channels: int):
+    _require_cuda(x, "x")
+    _require_cuda(edge_index, "edge_index")
+    if x.dim() != 2 or x.size(1) != in_channels:
+        raise ValueError(f"x must be [N, {in_channels}], got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise ValueError(f"x must be float32, got {x.dtype}")
+    if x.device != edge_index.device:
+        raise RuntimeError(f"x is on {x.device} but edge_index is on {edge_index.device}")
+
+
+class TAGConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, K: int = 3, bias: bool = True,
+                 normalize: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.K, self.normalize = \
+            in_channels, out_channels, K, normalize
+        self.lins = nn.ModuleList([_Lin(in_channels, out_channels) for _ in range(K + 1)])
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
+        return graph_index(edge_index, num_nodes, self_loops=False, normalize=self.normalize)
+
+    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+        _check_inputs(x, edge_index, self.in_channels)
+        g = self.graph(edge_index, x.size(0))
+        return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias)
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, K={self.K}"
+
+
+class GCNConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = _Lin(in_channels, out_channels, initializer="glorot")
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
+        return graph_index(edge_index, num_nodes, self_loops=True, normalize=True)
+
+    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+        _check_inputs(x, edge_index, self.in_channels)
+        g = self.graph(edge_index, x.size(0))
+        out = ops.propagate(g, self.lin(x), weighted=True)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+class GATConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1,
+                 negative_slope: float = 0.2, bias: bool = True):
+        super().__init__()
+        if heads != 1:
+            raise NotImplementedError("the reference only uses heads=1 (models/model.py:45,49)")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.negative_slope = negative_slope
+        self.lin = _Lin(in_channels, heads * out_channels, initializer="glorot")
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(heads * out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        a = math.sqrt(6.0 / (self.heads + self.out_channels))
+        with torch.no_grad():
+            self.att_src.uniform_(-a, a)
+            self.att_dst.uniform_(-a, a)
+            if self.bias is not None:
+                self.bias.zero_()
+
+    def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
+        return graph_index(edge_index, num_nodes, self_loops=True, normalize=False)
+
+    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+        _check_inputs(x, edge_index, self.in_channels)
+        g = self.graph(edge_index, x.size(0))
+        h = self.lin(x)
+        a_src = (h * self.att_src.view(1, -1)).sum(-1)
+        a_dst = (h * self.att_dst.view(1, -1)).sum(-1)
+        out = ops.gat_aggregate(g, h, a_src, a_dst, self.negative_slope)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+def knn(*args, **kwargs):
+    """Imported by ``models/model.py:2`` but never called by the reference."""
+    raise NotImplementedError("torch_geometric.nn.knn is dead code in the reference")

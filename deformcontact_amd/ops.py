@@ -1,0 +1,195 @@
+"""Host-side operator layer: thin launches of the C ABI + autograd wiring.
+
+Mirrors what PyG's ``TAGConv`` / ``GCNConv`` / ``GATConv`` ``forward`` do for the
+reference (``/root/reference/models/model.py:71,77``), with every gather /
+scatter step executed by ``libdeformcontact_hip.so`` on the current HIP stream.
+PyTorch is used for device memory, autograd bookkeeping and (for now) the plain
+dense GEMMs.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from .graph import GraphIndex, SortedAdjacency, _require_cuda, current_stream_ptr
+
+
+def _rowmajor(t: torch.Tensor, what: str) -> int:
+    """Return the leading dimension of a 2-D fp32 row-major (possibly column-sliced) view."""
+    if t.dim() != 2 or t.dtype != torch.float32:
+        raise ValueError(f"{what}: expected a 2-D float32 tensor, got {tuple(t.shape)} {t.dtype}")
+    if t.size(1) > 1 and t.stride(1) != 1:
+        raise ValueError(f"{what}: innermost dimension must be contiguous")
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+def hop(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = None,
+        addend: Optional[torch.Tensor] = None, weighted: bool = True) -> torch.Tensor:
+    """``out[i] = addend[i] + sum_{p in seg(i)} w[p] * x[other[p]]`` (one launch).
+
+    ``x`` / ``out`` / ``addend`` may be column slices of wider row-major buffers."""
+    _require_cuda(x, "x")
+    n, f = x.shape
+    if adj.ptr.numel() != n + 1:
+        raise ValueError(f"hop: x has {n} rows but the graph has {adj.ptr.numel() - 1} nodes")
+    if out is None:
+        out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    ldx, ldy = _rowmajor(x, "x"), _rowmajor(out, "out")
+    if out.shape != x.shape:
+        raise ValueError("hop: out shape mismatch")
+    lda = 0
+    if addend is not None:
+        if addend.shape != x.shape:
+            raise ValueError("hop: addend shape mismatch")
+        lda = _rowmajor(addend, "addend")
+    w = adj.w if weighted else None
+    rc = _lib.lib().dc_spmm_f32(
+        adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+        x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,
+        out.data_ptr(), ldy, n, f, current_stream_ptr(x.device))
+    _lib.check(rc, "dc_spmm_f32")
+    return out
+
+
+class _HopFn(torch.autograd.Function):
+    """Differentiable single hop ``y = A x`` (``A`` = weighted sorted adjacency)."""
+
+    @staticmethod
+    def forward(ctx, g: GraphIndex, x: torch.Tensor, weighted: bool):
+        ctx.g, ctx.weighted = g, weighted
+        return hop(g.fwd, x.contiguous(), weighted=weighted)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return None, hop(ctx.g.bwd, gy.contiguous(), weighted=ctx.weighted), None
+
+
+def propagate(g: GraphIndex, x: torch.Tensor, weighted: bool = True) -> torch.Tensor:
+    """Autograd-aware hop (PyG ``propagate(edge_index, x=x, edge_weight=w)``)."""
+    return _HopFn.apply(g, x, weighted)
+
+
+class _TagConvFn(torch.autograd.Function):
+    """Whole TAGConv layer: K hops into one ``[N, K*Fi]`` slab + the dense block.
+
+    ``out = x W_0^T + sum_k (A^k x) W_k^T + b`` - PyG ``tag_conv.py`` forward."""
+
+    @staticmethod
+    def forward(ctx, g: GraphIndex, x: torch.Tensor, bias: Optional[torch.Tensor], *weights):
+        x = x.contiguous()
+        n, fi = x.shape
+        k = len(weights) - 1
+        xh = torch.empty((n, max(k, 1) * fi), dtype=torch.float32, device=x.device)
+        src = x
+        for j in range(k):
+            dst = xh[:, j * fi:(j + 1) * fi]
+            hop(g.fwd, src, out=dst, weighted=g.normalize)
+            src = dst
+        w0 = weights[0]
+        out = torch.addmm(bias, x, w0.t()) if bias is not None else torch.mm(x, w0.t())
+        for j in range(k):
+            out.addmm_(xh[:, j * fi:(j + 1) * fi], weights[j + 1].t())
+        ctx.g, ctx.k, ctx.fi, ctx.has_bias = g, k, fi, bias is not None
+        ctx.save_for_backward(x, xh, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, xh, *weights = ctx.saved_tensors
+        g, k, fi = ctx.g, ctx.k, ctx.fi
+        gout = gout.contiguous()
+        need_x, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gws: List[Optional[torch.Tensor]] = []
+        gt = gout.t()
+        for j in range(k + 1):
+            if ctx.needs_input_grad[3 + j]:
+                xj = x if j == 0 else xh[:, (j - 1) * fi:j * fi]
+                gws.append(torch.mm(gt, xj))
+            else:
+                gws.append(None)
+        gb = gout.sum(0) if (ctx.has_bias and need_b) else None
+        gx = None
+        if need_x:
+            gx = torch.mm(gout, weights[0])
+            if k > 0:
+                wcat = torch.cat(list(weights[1:]), dim=1)          # [Fo, k*Fi]
+                gh = torch.mm(gout, wcat)                           # [N, k*Fi]
+                acc = gh[:, (k - 1) * fi:k * fi]
+                for j in range(k - 1, 0, -1):                       # g_j = G_j + A^T g_{j+1}
+                    dst = gh[:, (j - 1) * fi:j * fi]
+                    hop(g.bwd, acc, out=dst, addend=dst, weighted=g.normalize)
+                    acc = dst
+                hop(g.bwd, acc, out=gx, addend=gx, weighted=g.normalize)
+        return (None, gx, gb, *gws)
+
+
+def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias) -> torch.Tensor:
+    return _TagConvFn.apply(g, x, bias, *weights)
+
+
+# --------------------------------------------------------------------------- #
+# GATConv (heads = 1): edge softmax + weighted aggregation
+# --------------------------------------------------------------------------- #
+def _spmm_w(adj: SortedAdjacency, w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    n, f = x.shape
+    out = torch.empty((n, f), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dc_spmm_f32(adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr(),
+                                x.data_ptr(), _rowmajor(x, "x"), None, 0, out.data_ptr(), f, n, f,
+                                current_stream_ptr(x.device))
+    _lib.check(rc, "dc_spmm_f32")
+    return out
+
+
+class _GatAggregateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g: GraphIndex, h, a_src, a_dst, slope: float):
+        L = _lib.lib()
+        h, a_src, a_dst = h.contiguous(), a_src.contiguous(), a_dst.contiguous()
+        n = h.size(0)
+        st = current_stream_ptr(h.device)
+        alpha = torch.zeros(max(g.capacity, 1), dtype=torch.float32, device=h.device)
+        _lib.check(L.dc_gat_edge_softmax_fwd(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(),
+                                             a_src.data_ptr(), a_dst.data_ptr(), slope,
+                                             alpha.data_ptr(), n, st), "dc_gat_edge_softmax_fwd")
+        out = _spmm_w(g.fwd, alpha, h)
+        ctx.g, ctx.slope = g, slope
+        ctx.save_for_backward(h, a_src, a_dst, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        h, a_src, a_dst, alpha = ctx.saved_tensors
+        g, slope = ctx.g, ctx.slope
+        gout = gout.contiguous()
+        n, f = h.shape
+        dev = h.device
+        st = current_stream_ptr(dev)
+        cap = max(g.capacity, 1)
+        b2f = g.bwd_to_fwd()
+        cnt = g.fwd.ptr[-1:]
+        # d out / d h : transposed aggregation with alpha re-ordered by source
+        alpha_b = torch.zeros(cap, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_gather_f32(alpha.data_ptr(), b2f.data_ptr(), alpha_b.data_ptr(),
+                                   cnt.data_ptr(), g.capacity, st), "dc_gather_f32")
+        gh = _spmm_w(g.bwd, alpha_b, gout)
+        # d out / d alpha
+        galpha = torch.zeros(cap, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_sddmm_f32(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), gout.data_ptr(), f,
+                                  h.data_ptr(), f, galpha.data_ptr(), n, f, st), "dc_sddmm_f32")
+        ge = torch.zeros(cap, dtype=torch.float32, device=dev)
+        g_a_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_gat_edge_softmax_bwd(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(),
+                                             a_src.data_ptr(), a_dst.data_ptr(), slope,
+                                             alpha.data_ptr(), galpha.data_ptr(), ge.data_ptr(),
+                                             g_a_dst.data_ptr(), n, st), "dc_gat_edge_softmax_bwd")
+        g_a_src = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_segment_sum_f32(g.bwd.ptr.data_ptr(), b2f.data_ptr(), ge.data_ptr(),
+                                        g_a_src.data_ptr(), n, st), "dc_segment_sum_f32")
+        return None, gh, g_a_src, g_a_dst, None
+
+
+def gat_aggregate(g: GraphIndex, h, a_src, a_dst, slope: float) -> torch.Tensor:
+    return _GatAggregateFn.apply(g, h, a_src, a_dst, float(slope))

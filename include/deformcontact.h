@@ -1,0 +1,136 @@
+/*
+ * deformcontact.h -- C ABI of libdeformcontact_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the DeformContact message-passing hot path.  The
+ * reference has no FFI of its own: its boundary is the PyG operator surface
+ * called from /root/reference/models/model.py:45,49,71,77
+ * (`conv_layer(in, out)`, `conv(x, edge_index)`), whose arithmetic is PyG 2.5.2's
+ * gcn_norm + MessagePassing.propagate + Linear.  Each entry point below names
+ * the PyG/ATen step it replaces.  The Python host (deformcontact_amd/) binds
+ * these with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the
+ *     library allocates nothing and keeps no mutable global state except the
+ *     thread-local last-error string;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t); no call
+ *     synchronises, so all of them are legal inside hipGraph capture;
+ *   - return value 0 = enqueued, <0 = DC_E* (nothing enqueued), message in
+ *     dc_last_error();
+ *   - matrices are row-major fp32 with an explicit leading dimension (in
+ *     elements); index arrays produced by the library are int32; the only int64
+ *     input is PyG's `edge_index` [2,E].
+ */
+#ifndef DEFORMCONTACT_H
+#define DEFORMCONTACT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_OK 0
+#define DC_EINVAL (-1)   /* bad argument (null pointer, negative size, alignment) */
+#define DC_ELAUNCH (-2)  /* hipLaunch / runtime error, text in dc_last_error()   */
+#define DC_EWORKSPACE (-3)
+
+typedef void *dc_stream_t; /* hipStream_t */
+
+int dc_version(void);
+const char *dc_last_error(void);
+
+/* ---- topology: edge_index -> sorted adjacency ("CSR") ---------------------
+ * Replaces the implicit ordering of PyG's scatter_add_ (utils/_scatter.py) and,
+ * with `w != NULL`, gcn_norm (nn/conv/gcn_conv.py) which the reference
+ * recomputes in every conv call (model.py:71,77 -> TAGConv.forward).
+ *
+ * Groups the E edges by edge_index[key_row] (key_row = 1: by destination, the
+ * forward CSR; key_row = 0: by source, the transposed set used by backward),
+ * STABLY: inside a group edges keep their input order, i.e. the result equals
+ * np.argsort(edge_index[key_row], kind="stable").  Bit-exact, deterministic.
+ *
+ *   self_loops = 0 : edge set used as is (TAGConv: gcn_norm(add_self_loops=False))
+ *   self_loops = 1 : existing self loops dropped, one loop per node appended
+ *                    with edge ids E..E+N-1 (GCNConv add_remaining_self_loops,
+ *                    GATConv remove_self_loops + add_self_loops; utils/loop.py).
+ *                    Output arrays must then hold E+N entries; the actual edge
+ *                    count is ptr[N].
+ *
+ *   ptr   [N+1]  group offsets
+ *   other [E']   the other endpoint of each sorted edge (source for key_row=1)
+ *   perm  [E']   original edge id of each sorted edge
+ *   w     [E']   optional: deg^-1/2[src] * deg^-1/2[dst], deg = in-degree
+ *                counting duplicates, 0 for deg = 0.  `deg_ptr` = offsets whose
+ *                differences give that in-degree: NULL = this call's own `ptr`
+ *                (valid for key_row = 1), else the key_row=1 ptr of the same
+ *                edge set.
+ *   status[1]    device int32, OR-ed with 1 if any endpoint is outside [0,N)
+ *                (such edges are skipped).  Caller zeroes it and may read it
+ *                back after synchronising.
+ *   workspace    dc_csr_workspace_bytes(E, N) bytes, 16-byte aligned.
+ */
+int64_t dc_csr_workspace_bytes(int64_t E, int64_t N);
+int dc_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int key_row,
+                 int self_loops, int32_t *ptr, int32_t *other, int32_t *perm,
+                 const int32_t *deg_ptr, float *w, int32_t *status, void *workspace,
+                 int64_t workspace_bytes, dc_stream_t stream);
+
+/* ---- the hop: fused gather - scale - segment-sum --------------------------
+ * Replaces MessagePassing.propagate for aggr="add" with message = w_e * x_j:
+ * index_select(x, 0, row) -> mul -> zeros(N,F).scatter_add_(0, col) (three ATen
+ * ops and two [E,F] temporaries per hop in PyG).
+ *
+ *   y[i, 0:F] = (addend ? addend[i, 0:F] : 0)
+ *             + sum over p in [ptr[i], ptr[i+1]) of  w[p] * x[other[p], 0:F]
+ *
+ * summed in p order with separately rounded multiply and add, so the result is
+ * bit-identical to a serial walk over the stably sorted edges.  w == NULL means
+ * weight 1.  Forward passes the key_row=1 set, backward the key_row=0 set
+ * (y = A_hat^T g + addend).  y must not alias x; y may alias addend.
+ */
+int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
+                int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
+                int64_t N, int64_t F, dc_stream_t stream);
+
+/* pos_of[perm[p]] = p  (inverse permutation over the E' = *ptr_last sorted edges) */
+int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last /* &ptr[N] */, int32_t *pos_of,
+                   int64_t max_edges, dc_stream_t stream);
+/* out[p] = a[b[p]] for p < *count_ptr (e.g. position-in-forward-order of every
+ * backward-ordered edge: a = pos_of, b = perm of the key_row=0 set). */
+int dc_compose_perm(const int32_t *a, const int32_t *b, int32_t *out, const int32_t *count_ptr,
+                    int64_t cap, dc_stream_t stream);
+
+/* ---- GATConv edge terms (nn/conv/gat_conv.py edge_update + utils/_softmax.py) -
+ * Only reached when the reference is configured with backbone "GATConv"
+ * (models/model.py:39).  Arrays are in key_row=1 order of a self_loops=1 set;
+ * segments = incoming edges of node i.
+ *   e_p     = leaky_relu(a_src[other[p]] + a_dst[i], slope)
+ *   alpha_p = exp(e_p - max_seg e) / (sum_seg exp(e - max) + 1e-16)
+ * The aggregation out_i = sum_p alpha_p h[other[p]] is dc_spmm_f32 with w = alpha.
+ */
+int dc_gat_edge_softmax_fwd(const int32_t *ptr, const int32_t *other, const float *a_src,
+                            const float *a_dst, float slope, float *alpha, int64_t N,
+                            dc_stream_t stream);
+/* Backward: given galpha[E'] writes ge[p] = d loss / d (a_src[other[p]] + a_dst[i])
+ * (softmax and leaky-relu chained) and g_a_dst[i] = sum of ge over segment i. */
+int dc_gat_edge_softmax_bwd(const int32_t *ptr, const int32_t *other, const float *a_src,
+                            const float *a_dst, float slope, const float *alpha,
+                            const float *galpha, float *ge, float *g_a_dst, int64_t N,
+                            dc_stream_t stream);
+/* Sampled dense-dense product: d[p] = <g[i,0:F], h[other[p],0:F]> for p in segment i
+ * (gradient of the aggregation w.r.t. alpha). */
+int dc_sddmm_f32(const int32_t *ptr, const int32_t *other, const float *g, int64_t ldg,
+                 const float *h, int64_t ldh, float *d, int64_t N, int64_t F,
+                 dc_stream_t stream);
+/* out[i] = sum over p in [ptr[i],ptr[i+1]) of v[map ? map[p] : p]  (p order) */
+int dc_segment_sum_f32(const int32_t *ptr, const int32_t *map, const float *v, float *out,
+                       int64_t N, dc_stream_t stream);
+/* out[p] = v[idx[p]] for p < *count_ptr */
+int dc_gather_f32(const float *v, const int32_t *idx, float *out, const int32_t *count_ptr,
+                  int64_t cap, dc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFORMCONTACT_H */

@@ -1,0 +1,65 @@
+"""Build + ctypes binding of ``oracle/hop_ref.c`` (TEST INFRASTRUCTURE)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libhop_ref.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_DIR, "hop_ref.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC",
+                               src, "-o", _SO, "-lm"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def csr_build(edge_index: np.ndarray, n: int, key_row: int = 1):
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    e = ei.shape[1]
+    ptr = np.zeros(n + 1, np.int32)
+    other = np.zeros(e, np.int32)
+    perm = np.zeros(e, np.int32)
+    rc = lib().ref_csr_build(_p(ei, ctypes.c_int64), ctypes.c_int64(e), ctypes.c_int64(n),
+                             ctypes.c_int(key_row), _p(ptr, ctypes.c_int32),
+                             _p(other, ctypes.c_int32), _p(perm, ctypes.c_int32))
+    if rc != 0:
+        raise ValueError(f"ref_csr_build rc={rc}")
+    return ptr, other, perm
+
+
+def gcn_norm(edge_index: np.ndarray, n: int) -> np.ndarray:
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    w = np.zeros(ei.shape[1], np.float32)
+    lib().ref_gcn_norm(_p(ei, ctypes.c_int64), ctypes.c_int64(ei.shape[1]), ctypes.c_int64(n),
+                       _p(w, ctypes.c_float))
+    return w
+
+
+def hop(edge_index: np.ndarray, w: np.ndarray, x: np.ndarray) -> np.ndarray:
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    n, f = x.shape
+    y = np.empty_like(x)
+    lib().ref_hop(_p(ei, ctypes.c_int64), _p(w, ctypes.c_float), _p(x, ctypes.c_float),
+                  ctypes.c_int64(f), ctypes.c_int64(ei.shape[1]), ctypes.c_int64(n),
+                  ctypes.c_int64(f), _p(y, ctypes.c_float), ctypes.c_int64(f))
+    return y

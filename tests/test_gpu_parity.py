@@ -1,0 +1,331 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures.  Bit-exact for indices; <= 1e-5 rel (max|a-b| / max|ref|) for fp32 as
+BASELINE.json's north_star states (the hop itself is checked bit-for-bit against the
+scalar C restatement)."""
+import numpy as np
+import pytest
+import torch
+
+import deformcontact_amd as dc
+from deformcontact_amd import ops
+from deformcontact_amd.graph import GraphIndex, clear_cache
+from oracle import hop_c, pyg_ref
+from oracle.weights import fill_state_dict_, hashed_uniform
+from tests.helpers import G, golden_graphs, load_golden, random_multigraph, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# --------------------------------------------------------------------------- #
+# topology: bit-exact
+# --------------------------------------------------------------------------- #
+def _check_csr(ei, n):
+    g = GraphIndex(torch.from_numpy(ei).to(DEV), n, validate=True)
+    for key_row, adj in ((1, g.fwd), (0, g.bwd)):
+        ptr, other, perm = hop_c.csr_build(ei, n, key_row)
+        order = np.argsort(ei[key_row], kind="stable")
+        assert np.array_equal(perm, order.astype(np.int32))
+        e = ei.shape[1]
+        assert np.array_equal(_np(adj.ptr), ptr)
+        assert np.array_equal(_np(adj.perm)[:e], perm)
+        assert np.array_equal(_np(adj.other)[:e], other)
+    w_edge = hop_c.gcn_norm(ei, n)                    # edge order
+    e = ei.shape[1]
+    assert rel_err(_np(g.fwd.w)[:e], w_edge[_np(g.fwd.perm)[:e]]) < 1e-6
+    assert rel_err(_np(g.bwd.w)[:e], w_edge[_np(g.bwd.perm)[:e]]) < 1e-6
+    return g
+
+
+def test_csr_golden_fixture_bit_exact():
+    z = load_golden("mesh_graph_csr.npz")
+    ei, n = z["batch_edge_index"], z["batch_x"].shape[0]
+    g = _check_csr(ei, n)
+    assert np.array_equal(_np(g.fwd.ptr), z["rowptr"])
+    assert np.array_equal(_np(g.fwd.perm), z["perm"])
+    assert np.array_equal(_np(g.fwd.other), z["src_sorted"])
+    assert np.array_equal(_np(g.bwd.ptr), z["colptr"])
+    assert np.array_equal(_np(g.bwd.perm), z["perm_t"])
+    assert np.array_equal(_np(g.bwd.other), z["dst_sorted"])
+
+
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (5, 0, 1), (1, 7, 2), (64, 64, 3), (1000, 20000, 4),
+                                      (4099, 30011, 5), (70000, 300000, 6)])
+def test_csr_random_multigraphs_bit_exact(n, e, seed):
+    _check_csr(random_multigraph(n, e, seed), n)
+
+
+def test_csr_hub_node_long_segment():
+    n, e = 300, 40000
+    ei = random_multigraph(n, e, 11)
+    ei[1, : e // 2] = 7                                   # one destination with 20k in-edges
+    _check_csr(ei, n)
+
+
+def test_csr_self_loop_rewrite_matches_pyg_loop_utils():
+    n = 50
+    ei = random_multigraph(n, 400, 12, self_loops=True)
+    t = torch.from_numpy(ei)
+    ref = pyg_ref.add_remaining_self_loops(t, n).numpy()             # GCN
+    ref2 = pyg_ref.add_self_loops(pyg_ref.remove_self_loops(t), n).numpy()   # GAT
+    assert np.array_equal(ref, ref2)
+    g = GraphIndex(t.to(DEV), n, self_loops=True, normalize=True)
+    e2 = ref.shape[1]
+    assert g.num_edges == e2
+    order = np.argsort(ref[1], kind="stable")
+    assert np.array_equal(_np(g.fwd.other)[:e2], ref[0][order].astype(np.int32))
+    assert np.array_equal(_np(g.fwd.ptr), np.concatenate([[0], np.cumsum(np.bincount(ref[1], minlength=n))]))
+    order_t = np.argsort(ref[0], kind="stable")
+    assert np.array_equal(_np(g.bwd.other)[:e2], ref[1][order_t].astype(np.int32))
+    _, w = pyg_ref.gcn_norm(t, n, add_loops=True)
+    assert rel_err(_np(g.fwd.w)[:e2], w.numpy()[order]) < 1e-6
+
+
+def test_out_of_range_edge_is_reported():
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]], dtype=torch.long, device=DEV)
+    with pytest.raises(IndexError):
+        GraphIndex(ei, 3, validate=True)
+
+
+# --------------------------------------------------------------------------- #
+# the hop: bit-exact against the scalar C restatement
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n,e,f", [(57, 400, 21), (57, 400, 25), (300, 3000, 256), (300, 3000, 32),
+                                   (129, 900, 64), (64, 500, 128), (33, 200, 1), (33, 200, 7),
+                                   (40, 300, 260), (40, 300, 1024), (20, 90, 84), (500, 9000, 16)])
+def test_hop_bit_exact_vs_c_oracle(n, e, f):
+    ei = random_multigraph(n, e, n + f)
+    x = hashed_uniform((n, f), f, 2.0)
+    g = GraphIndex(torch.from_numpy(ei).to(DEV), n)
+    y = ops.hop(g.fwd, torch.from_numpy(x).to(DEV))
+    w = hop_c.gcn_norm(ei, n)
+    # same w on both sides so the comparison isolates the gather/scale/segment-sum
+    w_dev = np.zeros(e, np.float32)
+    w_dev[_np(g.fwd.perm)[:e]] = _np(g.fwd.w)[:e]
+    yc = hop_c.hop(ei, w_dev, x)
+    assert np.array_equal(_np(y), yc), f"hop differs: rel {rel_err(_np(y), yc):.3e}"
+    assert rel_err(w_dev, w) < 1e-6
+    # transposed operator: <A x, u> == <x, A^T u>
+    u = hashed_uniform((n, f), f + 1, 2.0)
+    yt = ops.hop(g.bwd, torch.from_numpy(u).to(DEV))
+    lhs = float((_np(y).astype(np.float64) * u).sum())
+    rhs = float((x.astype(np.float64) * _np(yt)).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+
+
+def test_hop_strided_views_and_addend():
+    n, e, f = 200, 1500, 256
+    ei = random_multigraph(n, e, 3)
+    g = GraphIndex(torch.from_numpy(ei).to(DEV), n)
+    slab = torch.from_numpy(hashed_uniform((n, 3 * f), 8, 2.0)).to(DEV)
+    x = slab[:, f:2 * f]
+    ref = ops.hop(g.fwd, x.contiguous())
+    out = slab[:, 2 * f:]
+    add = out.clone()
+    ops.hop(g.fwd, x, out=out)
+    assert torch.equal(out, ref)
+    ops.hop(g.fwd, x, out=out, addend=add)                       # y = add + A x
+    exp = _np(add).astype(np.float64) + _np(ref)
+    assert rel_err(_np(out), exp) < 1e-6
+    with pytest.raises(Exception):
+        ops.hop(g.fwd, x, out=x)
+
+
+def test_empty_graph_and_isolated_nodes():
+    n, f = 9, 256
+    ei = torch.zeros(2, 0, dtype=torch.long, device=DEV)
+    g = GraphIndex(ei, n)
+    y = ops.hop(g.fwd, torch.ones(n, f, device=DEV))
+    assert torch.count_nonzero(y) == 0
+    conv = dc.nn.TAGConv(f, 8).to(DEV)
+    x = torch.randn(n, f, device=DEV)
+    ref = torch.nn.functional.linear(x, conv.lins[0].weight) + conv.bias
+    assert rel_err(_np(conv(x, ei)), _np(ref)) < TOL
+
+
+# --------------------------------------------------------------------------- #
+# conv layers: forward + backward vs the oracle
+# --------------------------------------------------------------------------- #
+def _pair(kind, fi, fo, seed):
+    cpu = getattr(pyg_ref, kind)(fi, fo)
+    fill_state_dict_(cpu, salt0=seed)
+    gpu = getattr(dc.nn, kind)(fi, fo)
+    gpu.load_state_dict(cpu.state_dict())
+    return cpu, gpu.to(DEV)
+
+
+@pytest.mark.parametrize("kind", ["TAGConv", "GCNConv", "GATConv"])
+@pytest.mark.parametrize("n,e,fi,fo", [(120, 900, 21, 256), (120, 900, 25, 32), (90, 700, 256, 256),
+                                       (64, 300, 32, 32)])
+def test_conv_forward_backward_vs_oracle(kind, n, e, fi, fo):
+    torch.set_num_threads(1)
+    ei = random_multigraph(n, e, fi + fo)
+    x = hashed_uniform((n, fi), 31, 2.0)
+    gup = hashed_uniform((n, fo), 37, 2.0)
+    cpu, gpu = _pair(kind, fi, fo, fi)
+    xc = torch.from_numpy(x).requires_grad_(True)
+    oc = cpu(xc, torch.from_numpy(ei))
+    (oc * torch.from_numpy(gup)).sum().backward()
+    xg = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    og = gpu(xg, torch.from_numpy(ei).to(DEV))
+    (og * torch.from_numpy(gup).to(DEV)).sum().backward()
+    assert rel_err(_np(og), _np(oc)) < TOL
+    assert rel_err(_np(xg.grad), _np(xc.grad)) < TOL
+    gc = dict(cpu.named_parameters())
+    for name, p in gpu.named_parameters():
+        assert rel_err(_np(p.grad), _np(gc[name].grad)) < 2 * TOL, name
+
+
+@pytest.mark.parametrize("backbone,fname", [("TAGConv", "graphnet_tag_h32.npz"),
+                                             ("GCNConv", "graphnet_gcn_h32.npz"),
+                                             ("GATConv", "graphnet_gat_h32.npz")])
+def test_full_model_golden(backbone, fname):
+    """Fixtures produced by the reference's GraphNet + losses (oracle/make_golden.py)."""
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, gradient_consistency_loss, load_model
+    z = load_golden(fname)
+    m = load_model(dict(EVERYDAY_NETWORK, hidden_dim=int(z["hidden"]), backbone=backbone))
+    fill_state_dict_(m)
+    m = m.to(DEV).train()
+    rest, rig = golden_graphs(z, DEV)
+    acts = {}
+    for br in ("resting", "rigid"):
+        for li, conv in enumerate(getattr(m, f"conv_layers_{br}")):
+            conv.register_forward_hook(
+                lambda mod, i, o, k=f"conv_{br}_{li}": acts.__setitem__(k, o.detach()))
+    pred = m(rest, rig)
+    for k, v in acts.items():
+        assert rel_err(_np(v), z[k]) < TOL, k
+    assert rel_err(_np(pred.pos), z["pred_pos"]) < TOL
+    pred.pos = pred.pos - rest.pos
+    tgt = rest.clone()
+    tgt.pos = torch.from_numpy(z["def_pos"]).to(DEV) - rest.pos
+    l1 = torch.nn.functional.l1_loss(pred.pos, tgt.pos)
+    gcl = gradient_consistency_loss(pred, tgt)
+    assert abs(float(l1) - float(z["loss_l1"])) <= TOL * abs(float(z["loss_l1"]))
+    assert abs(float(gcl) - float(z["loss_gcl"])) <= TOL * abs(float(z["loss_gcl"]))
+    (l1 + gcl).backward()
+    for name, p in m.named_parameters():
+        assert rel_err(_np(p.grad), z["grad." + name]) < 3 * TOL, name
+
+
+def test_encoder_golden_hidden256():
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
+    z = load_golden("encoder_tag_h256.npz")
+    m = load_model(EVERYDAY_NETWORK)
+    fill_state_dict_(m)
+    m = m.to(DEV).train()
+    rest, rig = golden_graphs(z, DEV)
+    x_rest, x_rig = m.encode(rest, rig)
+    assert rel_err(_np(x_rest), z["enc_rest"]) < TOL
+    assert rel_err(_np(x_rig), z["enc_rig"]) < TOL
+    g_rest = torch.from_numpy(hashed_uniform(tuple(x_rest.shape), 991, 2.0)).to(DEV)
+    g_rig = torch.from_numpy(hashed_uniform(tuple(x_rig.shape), 997, 2.0)).to(DEV)
+    ((x_rest * g_rest).sum() + (x_rig * g_rig).sum()).backward()
+    for name, p in m.named_parameters():
+        if not name.startswith("conv_layers"):
+            continue
+        g = _np(p.grad)
+        if "grad." + name in z:
+            assert rel_err(g, z["grad." + name]) < 2 * TOL, name
+        else:
+            assert rel_err(g.reshape(-1)[::97], z["gradprobe." + name]) < 2 * TOL, name
+            ref = float(z["gradsum." + name])
+            assert abs(float(g.astype(np.float64).sum()) - ref) < 1e-4 * max(abs(ref), np.abs(g).sum() * 1e-3)
+
+
+# --------------------------------------------------------------------------- #
+# full BASELINE size (B=32): size-independent properties
+# --------------------------------------------------------------------------- #
+@pytest.fixture(scope="module")
+def everyday_b32():
+    from deformcontact_amd import synth
+    rest, deff, rig = synth.make_batch(32)
+    return rest.to(DEV), rig.to(DEV)
+
+
+def test_full_size_csr_and_hop_properties(everyday_b32):
+    rest, rig = everyday_b32
+    for b, n_exp, e_exp in ((rest, 32768, 196224), (rig, 24384, 145920)):
+        ei = _np(b.edge_index)
+        n = b.x.shape[0]
+        assert (n, ei.shape[1]) == (n_exp, e_exp)
+        g = GraphIndex(b.edge_index, n, validate=True)
+        # bit-exact indices at full size
+        order = np.argsort(ei[1], kind="stable")
+        assert np.array_equal(_np(g.fwd.perm), order.astype(np.int32))
+        assert np.array_equal(_np(g.fwd.other), ei[0][order].astype(np.int32))
+        assert np.array_equal(_np(g.fwd.ptr)[1:], np.cumsum(np.bincount(ei[1], minlength=n)))
+        order_t = np.argsort(ei[0], kind="stable")
+        assert np.array_equal(_np(g.bwd.perm), order_t.astype(np.int32))
+        # hop on ones = weighted in-degree; sortedness of groups; linearity; adjointness
+        f = 256
+        ones = torch.ones(n, f, device=DEV)
+        y1 = ops.hop(g.fwd, ones)
+        wsum = np.zeros(n, np.float64)
+        np.add.at(wsum, ei[1][order], _np(g.fwd.w).astype(np.float64))
+        assert rel_err(_np(y1)[:, 0], wsum) < 1e-6 and torch.equal(y1[:, 0], y1[:, -1])
+        a = torch.from_numpy(hashed_uniform((n, f), 1, 2.0)).to(DEV)
+        c = torch.from_numpy(hashed_uniform((n, f), 2, 2.0)).to(DEV)
+        lhs = ops.hop(g.fwd, 2.0 * a + c)
+        rhs = 2.0 * ops.hop(g.fwd, a) + ops.hop(g.fwd, c)
+        assert rel_err(_np(lhs), _np(rhs)) < 1e-6
+        yt = ops.hop(g.bwd, c)
+        l = float((ops.hop(g.fwd, a).double() * c.double()).sum())
+        r = float((a.double() * yt.double()).sum())
+        assert abs(l - r) <= 1e-6 * max(abs(l), 1.0)
+        # bit-exact vs the C oracle on the whole batch (seconds on one core)
+        w_edge = np.zeros(ei.shape[1], np.float32)
+        w_edge[_np(g.fwd.perm)] = _np(g.fwd.w)
+        assert np.array_equal(_np(ops.hop(g.fwd, a)), hop_c.hop(ei, w_edge, _np(a)))
+
+
+def test_full_size_encoder_vs_oracle(everyday_b32):
+    """B=32 encoder forward against the oracle's ATen-op sequence on the host."""
+    from deformcontact_amd.graphnet import ContactEncoder
+    rest, rig = everyday_b32
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256)
+    ref = ContactEncoder([21, 25], 256, conv_module=pyg_ref)
+    ref.load_state_dict(enc.state_dict())
+    enc = enc.to(DEV)
+    with torch.no_grad():
+        a, b = enc(rest, rig)
+        rest_c = G(rest.x.cpu(), rest.edge_index.cpu())
+        rig_c = G(rig.x.cpu(), rig.edge_index.cpu())
+        ra, rb = ref(rest_c, rig_c)
+    assert rel_err(_np(a), _np(ra)) < TOL and rel_err(_np(b), _np(rb)) < TOL
+
+
+def test_graph_cache_reuse_and_invalidation():
+    clear_cache()
+    n = 40
+    ei = torch.from_numpy(random_multigraph(n, 200, 9)).to(DEV)
+    conv = dc.nn.TAGConv(8, 8).to(DEV)
+    g1 = conv.graph(ei, n)
+    assert conv.graph(ei, n) is g1
+    ei[0, 0] = (ei[0, 0] + 1) % n                          # in-place edit bumps the version
+    assert conv.graph(ei, n) is not g1
+
+
+def test_reference_style_usage_through_alias():
+    """`from torch_geometric.nn import TAGConv` code path (models/model.py:2) on the GPU."""
+    import sys
+    dc.install_as_torch_geometric()
+    try:
+        from torch_geometric.data import Batch, Data
+        from torch_geometric.nn import TAGConv
+        d = [Data(x=torch.randn(5, 4), edge_index=torch.tensor([[0, 1, 2, 3], [1, 2, 3, 4]]),
+                  pos=torch.randn(5, 3)) for _ in range(3)]
+        b = Batch.from_data_list(d).to(DEV)
+        conv = TAGConv(4, 6).to(DEV)
+        out = torch.relu(conv(b.x, b.edge_index))
+        out.sum().backward()
+        assert out.shape == (15, 6) and conv.lins[3].weight.grad is not None
+    finally:
+        for k in ("torch_geometric", "torch_geometric.nn", "torch_geometric.data"):
+            sys.modules.pop(k, None)

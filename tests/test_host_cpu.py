@@ -1,0 +1,171 @@
+"""CPU: host logic + the C-ABI library loads and exports everything include/*.h declares."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import deformcontact_amd as dc
+from deformcontact_amd import _lib, features
+from deformcontact_amd.data import Batch, Data
+from tests.helpers import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names += re.findall(r"\b(dc_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    declared = _declared_symbols()
+    assert len(declared) >= 6
+    handle = ctypes.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/ but not exported"
+    # the Python binding covers exactly the declared surface
+    assert sorted(_lib.exported_names()) == declared
+    assert _lib.lib().dc_version() >= 100
+
+
+def test_abi_argument_errors_without_gpu():
+    L = _lib.lib()
+    assert L.dc_csr_workspace_bytes(-1, 4) < 0
+    assert L.dc_csr_workspace_bytes(10, 4) > 0
+    # bad arguments are rejected before any HIP call
+    rc = L.dc_spmm_f32(None, None, None, None, 4, None, 0, None, 4, 3, 4, None)
+    assert rc == -1 and b"null" in L.dc_last_error()
+    rc = L.dc_csr_build(None, 5, 3, 2, 0, None, None, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"key_row" in L.dc_last_error()
+
+
+def test_no_cpu_fallback():
+    conv = dc.nn.TAGConv(4, 8)
+    x = torch.zeros(5, 4)
+    ei = torch.zeros(2, 3, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        conv(x, ei)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        dc.nn.GCNConv(4, 8)(x, ei)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        dc.nn.GATConv(4, 8)(x, ei)
+
+
+def test_product_never_imports_oracle():
+    for path in glob.glob(os.path.join(ROOT, "deformcontact_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+
+
+def test_state_dict_keys_match_reference():
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
+    m = load_model(EVERYDAY_NETWORK)
+    sd = m.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 1_033_219
+    for br, fin in (("resting", 21), ("rigid", 25)):
+        for k in range(4):
+            assert sd[f"conv_layers_{br}.0.lins.{k}.weight"].shape == (256, fin)
+            assert sd[f"conv_layers_{br}.1.lins.{k}.weight"].shape == (256, 256)
+        assert sd[f"conv_layers_{br}.1.bias"].shape == (256,)
+    assert sd["multihead_attention.attention_heads.1.weight"].shape == (256, 256)
+    assert sd["decoder.0.weight"].shape == (256, 768) and sd["decoder.9.weight"].shape == (3, 256)
+    gat = dc.nn.GATConv(5, 7).state_dict()
+    assert set(gat) == {"att_src", "att_dst", "bias", "lin.weight"}
+    assert set(dc.nn.GCNConv(5, 7).state_dict()) == {"bias", "lin.weight"}
+
+
+def test_to_log_freq_golden():
+    z = load_golden("pos_encoding.npz")
+    enc = features.to_log_freq(torch.from_numpy(z["pos"]), 3, 1)
+    assert enc.shape == (37, 21)
+    assert np.allclose(enc.numpy(), z["enc"], rtol=0, atol=1e-7)
+
+
+class _M:
+    def __init__(self, v, t):
+        self.vertices, self.triangles = v, t
+
+
+def test_mesh_to_graph_and_batch_golden():
+    z = load_golden("mesh_graph_csr.npz")
+    g1 = features.mesh_to_graph(_M(z["v1"], z["t1"]))
+    g2 = features.mesh_to_graph(_M(z["v2"], z["t2"]))
+    assert g1.edge_index.dtype == torch.int64 and g1.edge_index.is_contiguous()
+    assert np.array_equal(g1.edge_index.numpy(), z["ei1"])
+    assert np.array_equal(g2.edge_index.numpy(), z["ei2"])
+    assert np.allclose(g1.x.numpy(), z["x1"], atol=1e-7)
+    b = Batch.from_data_list([g1, g2, g1])
+    assert np.array_equal(b.edge_index.numpy(), z["batch_edge_index"])     # bit-exact
+    assert np.array_equal(b.ptr.numpy(), z["batch_ptr"])
+    assert np.array_equal(b.batch.numpy(), z["batch_vec"])
+    assert np.allclose(b.x.numpy(), z["batch_x"], atol=1e-7)
+    assert b.num_graphs == 3 and len(b) == 3
+    ex = b[1]
+    assert np.array_equal(ex.edge_index.numpy(), z["ei2"]) and ex.x.shape == g2.x.shape
+    c = b.clone()
+    c.pos += 1.0
+    assert not torch.equal(c.pos, b.pos)
+    assert np.array_equal(c[2].edge_index.numpy(), z["ei1"])
+    with pytest.raises(IndexError):
+        b[3]
+
+
+def test_batch_ragged_and_extra_attributes():
+    d0 = Data(x=torch.zeros(3, 2), edge_index=torch.tensor([[0, 1], [1, 2]]), pos=torch.zeros(3, 3),
+              force=torch.ones(3), name="a")
+    d1 = Data(x=torch.ones(1, 2), edge_index=torch.zeros(2, 0, dtype=torch.long),
+              pos=torch.ones(1, 3), force=torch.zeros(3), name="b")
+    b = Batch.from_data_list([d0, d1])
+    assert b.x.shape == (4, 2) and b.edge_index.shape == (2, 2)
+    assert b.force.shape == (2, 3) and b.name == ["a", "b"]
+    assert b[1].edge_index.shape == (2, 0) and b[1].name == "b"
+    with pytest.raises(ValueError):
+        Batch.from_data_list([])
+
+
+def test_feature_rigid_layout():
+    enc = torch.arange(42, dtype=torch.float32).reshape(2, 21)
+    f = features.feature_rigid(torch.tensor([1.0, 2.0, 3.0]), 0.5, enc)
+    assert f.shape == (2, 25)
+    assert torch.equal(f[:, :3], torch.tensor([[1.0, 2.0, 3.0]] * 2))
+    assert torch.equal(f[:, 3], torch.tensor([0.5, 0.5])) and torch.equal(f[:, 4:], enc)
+
+
+def test_gcl_loss_golden():
+    from deformcontact_amd.graphnet import gradient_consistency_loss
+    from tests.helpers import G
+    z = load_golden("gcl_loss.npz")
+    ei = torch.from_numpy(z["edge_index"])
+    p = G(None, ei, torch.from_numpy(z["pred_pos"]).requires_grad_(True))
+    t = G(None, ei, torch.from_numpy(z["tgt_pos"]))
+    loss = gradient_consistency_loss(p, t)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-6 * abs(float(z["loss"]))
+    assert np.allclose(p.pos.grad.numpy(), z["grad_pred"], rtol=1e-5, atol=1e-8)
+
+
+def test_pyg_alias_installs_modules():
+    import sys
+    dc.install_as_torch_geometric()
+    from torch_geometric.nn import GATConv, GCNConv, TAGConv, knn  # noqa: F401
+    from torch_geometric.data import Batch as B2, Data as D2
+    assert TAGConv is dc.nn.TAGConv and B2 is Batch and D2 is Data
+    for k in ("torch_geometric", "torch_geometric.nn", "torch_geometric.data"):
+        sys.modules.pop(k, None)
+
+
+def test_synth_everyday_shape():
+    from deformcontact_amd import synth
+    rest, deff, rig = synth.make_batch(2)
+    assert rest.x.shape == (2048, 21) and rest.edge_index.shape == (2, 12264)
+    assert rig.x.shape == (1524, 25) and rig.edge_index.shape == (2, 9120)
+    deg = np.bincount(rig.edge_index.numpy()[1][:4560], minlength=762)
+    assert sorted(np.unique(deg).tolist()) == [5, 6, 40]
+    assert deff.pos.shape == rest.pos.shape
