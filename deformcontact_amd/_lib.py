@@ -25,6 +25,15 @@ _SIGNATURES = {
     "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
     "dc_spmm_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                             c_int64, _vp]),
+    "dc_tag_linear_fwd": (c_int, [POINTER(_vp), POINTER(c_int64), POINTER(_vp), c_int, _vp, c_int,
+                                  _vp, c_int64, c_int64, c_int64, c_int64, _vp]),
+    "dc_tag_linear_bwd_dx": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp), c_int,
+                                     POINTER(_vp), POINTER(c_int64), c_int64, c_int64, c_int64,
+                                     _vp]),
+    "dc_tag_linear_bwd_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int]),
+    "dc_tag_linear_bwd_dw": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp), POINTER(c_int64),
+                                     c_int, POINTER(_vp), _vp, _vp, c_int64, c_int64, c_int64,
+                                     c_int64, _vp]),
     "dc_compose_perm": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp]),
     "dc_gat_edge_softmax_fwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, c_int64, _vp]),
     "dc_gat_edge_softmax_bwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, _vp, _vp, _vp, c_int64,

@@ -46,7 +46,10 @@ class ContactEncoder(nn.Module):
 
     def _branch(self, layers, x, edge_index):
         for conv in layers:
-            x = F.relu(conv(x, edge_index))
+            if getattr(conv, "supports_fused_relu", False):
+                x = conv(x, edge_index, relu=True)        # ReLU in the MFMA epilogue
+            else:
+                x = F.relu(conv(x, edge_index))
             x = F.dropout(x, p=self.dropout_rate, training=self.training)
         return x
 

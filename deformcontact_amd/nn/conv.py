@@ -79,10 +79,14 @@ class TAGConv(nn.Module):
     def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
         return graph_index(edge_index, num_nodes, self_loops=False, normalize=self.normalize)
 
-    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+    supports_fused_relu = True
+
+    def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False) -> Tensor:
+        """``conv(x, edge_index)`` as PyG; ``relu=True`` (extension) fuses the ReLU the
+        reference applies right after (``models/model.py:71,77``) into the MFMA epilogue."""
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
-        return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias)
+        return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu)
 
     def extra_repr(self) -> str:
         return f"{self.in_channels}, {self.out_channels}, K={self.K}"

@@ -8,6 +8,7 @@ dense GEMMs.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import List, Optional
 
 import torch
@@ -71,62 +72,100 @@ def propagate(g: GraphIndex, x: torch.Tensor, weighted: bool = True) -> torch.Te
     return _HopFn.apply(g, x, weighted)
 
 
-class _TagConvFn(torch.autograd.Function):
-    """Whole TAGConv layer: K hops into one ``[N, K*Fi]`` slab + the dense block.
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
-    ``out = x W_0^T + sum_k (A^k x) W_k^T + b`` - PyG ``tag_conv.py`` forward."""
+
+def _i64_array(vals):
+    return (ctypes.c_int64 * len(vals))(*vals)
+
+
+MAX_SEG = 4   # DC_MAX_SEG in include/deformcontact.h
+
+
+class _TagConvFn(torch.autograd.Function):
+    """Whole TAGConv layer (+ optional fused ReLU): K hops into one ``[N, K*Fi]`` slab, then
+    ONE fp32-MFMA kernel for ``act(x W_0^T + sum_k (A^k x) W_k^T + b)`` - PyG ``tag_conv.py``
+    forward followed by ``F.relu`` (``models/model.py:71,77``).  Backward: one dW kernel
+    (+ bias grad), one dX kernel writing the per-hop gradient slab, K transposed hops."""
 
     @staticmethod
-    def forward(ctx, g: GraphIndex, x: torch.Tensor, bias: Optional[torch.Tensor], *weights):
+    def forward(ctx, g: GraphIndex, x: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
+                *weights):
         x = x.contiguous()
         n, fi = x.shape
         k = len(weights) - 1
+        fo = weights[0].size(0)
+        if k + 1 > MAX_SEG:
+            raise NotImplementedError(f"TAGConv K={k} > {MAX_SEG - 1} is not supported by the fused dense block")
+        ws = [w.contiguous() for w in weights]
         xh = torch.empty((n, max(k, 1) * fi), dtype=torch.float32, device=x.device)
-        src = x
+        xs, src = [x], x
         for j in range(k):
             dst = xh[:, j * fi:(j + 1) * fi]
             hop(g.fwd, src, out=dst, weighted=g.normalize)
+            xs.append(dst)
             src = dst
-        w0 = weights[0]
-        out = torch.addmm(bias, x, w0.t()) if bias is not None else torch.mm(x, w0.t())
-        for j in range(k):
-            out.addmm_(xh[:, j * fi:(j + 1) * fi], weights[j + 1].t())
-        ctx.g, ctx.k, ctx.fi, ctx.has_bias = g, k, fi, bias is not None
-        ctx.save_for_backward(x, xh, *weights)
+        ldxs = [fi] + [k * fi] * k
+        out = torch.empty((n, fo), dtype=torch.float32, device=x.device)
+        b = bias.contiguous() if bias is not None else None
+        rc = _lib.lib().dc_tag_linear_fwd(
+            _ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), k + 1,
+            b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), fo, n, fi, fo,
+            current_stream_ptr(x.device))
+        _lib.check(rc, "dc_tag_linear_fwd")
+        ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu = g, k, fi, fo, bias is not None, relu
+        ctx.save_for_backward(x, xh, out if relu else None, *ws)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, xh, *weights = ctx.saved_tensors
-        g, k, fi = ctx.g, ctx.k, ctx.fi
+        x, xh, out, *ws = ctx.saved_tensors
+        g, k, fi, fo = ctx.g, ctx.k, ctx.fi, ctx.fo
+        L = _lib.lib()
         gout = gout.contiguous()
-        need_x, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        gws: List[Optional[torch.Tensor]] = []
-        gt = gout.t()
-        for j in range(k + 1):
-            if ctx.needs_input_grad[3 + j]:
-                xj = x if j == 0 else xh[:, (j - 1) * fi:j * fi]
-                gws.append(torch.mm(gt, xj))
-            else:
-                gws.append(None)
-        gb = gout.sum(0) if (ctx.has_bias and need_b) else None
+        n = x.size(0)
+        dev = x.device
+        st = current_stream_ptr(dev)
+        need_x, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        need_w = any(ctx.needs_input_grad[4:])
+        mask_ptr = out.data_ptr() if out is not None else None
+        xs = [x] + [xh[:, j * fi:(j + 1) * fi] for j in range(k)]
+        ldxs = [fi] + [k * fi] * k
+
+        gws: List[Optional[torch.Tensor]] = [None] * (k + 1)
+        gb = None
+        if need_w or need_b:
+            gw_all = torch.empty((k + 1, fo, fi), dtype=torch.float32, device=dev)
+            gb = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
+            nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, k + 1)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = L.dc_tag_linear_bwd_dw(
+                gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(xs), _i64_array(ldxs), k + 1,
+                _ptr_array([gw_all[j] for j in range(k + 1)]),
+                gb.data_ptr() if gb is not None else None, scratch.data_ptr(), nbytes, n, fi, fo, st)
+            _lib.check(rc, "dc_tag_linear_bwd_dw")
+            gws = [gw_all[j] if ctx.needs_input_grad[4 + j] else None for j in range(k + 1)]
+
         gx = None
         if need_x:
-            gx = torch.mm(gout, weights[0])
+            gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
+            gh = torch.empty((n, max(k, 1) * fi), dtype=torch.float32, device=dev)
+            gxs = [gx] + [gh[:, j * fi:(j + 1) * fi] for j in range(k)]
+            rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws), k + 1,
+                                        _ptr_array(gxs), _i64_array(ldxs), n, fi, fo, st)
+            _lib.check(rc, "dc_tag_linear_bwd_dx")
             if k > 0:
-                wcat = torch.cat(list(weights[1:]), dim=1)          # [Fo, k*Fi]
-                gh = torch.mm(gout, wcat)                           # [N, k*Fi]
-                acc = gh[:, (k - 1) * fi:k * fi]
+                acc = gxs[k]
                 for j in range(k - 1, 0, -1):                       # g_j = G_j + A^T g_{j+1}
-                    dst = gh[:, (j - 1) * fi:j * fi]
-                    hop(g.bwd, acc, out=dst, addend=dst, weighted=g.normalize)
-                    acc = dst
+                    hop(g.bwd, acc, out=gxs[j], addend=gxs[j], weighted=g.normalize)
+                    acc = gxs[j]
                 hop(g.bwd, acc, out=gx, addend=gx, weighted=g.normalize)
-        return (None, gx, gb, *gws)
+        return (None, gx, gb, None, *gws)
 
 
-def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias) -> torch.Tensor:
-    return _TagConvFn.apply(g, x, bias, *weights)
+def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False) -> torch.Tensor:
+    return _TagConvFn.apply(g, x, bias, bool(relu), *weights)
 
 
 # --------------------------------------------------------------------------- #

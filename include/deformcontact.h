@@ -93,6 +93,41 @@ int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w, const 
                 int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
                 int64_t N, int64_t F, dc_stream_t stream);
 
+/* ---- dense block of TAGConv ------------------------------------------------
+ * Replaces `out = lins[0](x); out = out + lins[k](x_k) ...; out = out + bias`
+ * (nn/conv/tag_conv.py forward) = up to DC_MAX_SEG bias-free F.linear calls,
+ * adds, and the optional ReLU of model.py:71,77, as ONE fp32-MFMA kernel:
+ *
+ *   out[N,Fo] = act( sum_s  xs[s][N,Fi] . ws[s][Fo,Fi]^T  + bias )
+ *
+ * xs[s] has leading dimension ldxs[s]; ws[s] is PyG's Linear.weight layout
+ * [Fo,Fi] (ld = Fi).  Exact fp32 (v_mfma_f32_32x32x2_f32 is an fmaf chain).
+ */
+#define DC_MAX_SEG 4
+int dc_tag_linear_fwd(const float *const *xs, const int64_t *ldxs, const float *const *ws,
+                      int nseg, const float *bias, int relu, float *out, int64_t ldo,
+                      int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream);
+
+/* dX-side of the backward:  gxs[s][N,Fi] = g[N,Fo] . ws[s][Fo,Fi]   (s = 0..nseg-1),
+ * with g optionally masked by the ReLU of the forward output (`out_for_mask`:
+ * g is taken as 0 where out <= 0; NULL = no mask). */
+int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
+                         const float *const *ws, int nseg, float *const *gxs,
+                         const int64_t *ldgxs, int64_t N, int64_t Fi, int64_t Fo,
+                         dc_stream_t stream);
+
+/* dW-side: gws[s][Fo,Fi] = g^T[Fo,N] . xs[s][N,Fi] (same optional ReLU mask),
+ * gbias[Fo] = column sums of g (NULL to skip).  `partials` is a caller-owned
+ * scratch of dc_tag_linear_bwd_dw_workspace_bytes() bytes (split-N partial
+ * slabs, summed in chunk order by a second kernel: deterministic, no float
+ * atomics). */
+int64_t dc_tag_linear_bwd_dw_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo, int nseg);
+int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
+                         const float *const *xs, const int64_t *ldxs, int nseg,
+                         float *const *gws, float *gbias, void *partials,
+                         int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                         dc_stream_t stream);
+
 /* pos_of[perm[p]] = p  (inverse permutation over the E' = *ptr_last sorted edges) */
 int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last /* &ptr[N] */, int32_t *pos_of,
                    int64_t max_edges, dc_stream_t stream);

@@ -16,6 +16,9 @@ def rel_err(a, b):
     """max |a-b| / max |b|  -- the tolerance north_star states is 1e-5 on this."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 

@@ -149,6 +149,57 @@ def test_empty_graph_and_isolated_nodes():
 
 
 # --------------------------------------------------------------------------- #
+# dense block (fp32 MFMA) through the C ABI vs float64
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n,fi,fo,nseg,relu", [
+    (1, 21, 256, 4, True), (63, 25, 256, 4, False), (65, 32, 32, 4, True), (200, 256, 256, 4, True),
+    (130, 256, 130, 2, False), (64, 16, 3, 1, True), (257, 84, 260, 3, True), (1000, 256, 256, 1, False)])
+def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu):
+    import ctypes
+    from deformcontact_amd import _lib
+    from deformcontact_amd.graph import current_stream_ptr
+    from deformcontact_amd.ops import _i64_array, _ptr_array
+    L = _lib.lib()
+    slab = torch.from_numpy(hashed_uniform((n, nseg * fi), 5, 2.0)).to(DEV)
+    xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+    ld = [nseg * fi] * nseg
+    ws = [torch.from_numpy(hashed_uniform((fo, fi), 40 + s, 2.0 / np.sqrt(fi))).to(DEV) for s in range(nseg)]
+    bias = torch.from_numpy(hashed_uniform((fo,), 77, 0.5)).to(DEV)
+    out = torch.empty(n, fo, device=DEV)
+    st = current_stream_ptr(torch.device(DEV))
+    _lib.check(L.dc_tag_linear_fwd(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
+                                   int(relu), out.data_ptr(), fo, n, fi, fo, st), "fwd")
+    ref = sum(xs[s].double().cpu() @ ws[s].double().cpu().t() for s in range(nseg)) + bias.double().cpu()
+    pre = ref.clone()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert rel_err(_np(out), ref.numpy()) < 2e-6
+    # backward
+    g = torch.from_numpy(hashed_uniform((n, fo), 91, 2.0)).to(DEV)
+    gm = g.double().cpu() * ((pre > 0).double() if relu else 1.0)
+    # ReLU mask is taken from the forward output (> 0), as torch's threshold_backward does
+    if relu:
+        gm = g.double().cpu() * (out.double().cpu() > 0).double()
+    gws = [torch.empty(fo, fi, device=DEV) for _ in range(nseg)]
+    gb = torch.empty(fo, device=DEV)
+    nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    mask = out.data_ptr() if relu else None
+    _lib.check(L.dc_tag_linear_bwd_dw(g.data_ptr(), fo, mask, fo, _ptr_array(xs), _i64_array(ld), nseg,
+                                      _ptr_array(gws), gb.data_ptr(), scratch.data_ptr(), nbytes, n, fi,
+                                      fo, st), "dw")
+    for s in range(nseg):
+        assert rel_err(_np(gws[s]), (gm.t() @ xs[s].double().cpu()).numpy()) < 2e-6, s
+    assert rel_err(_np(gb), gm.sum(0).numpy()) < 2e-6
+    gslab = torch.zeros(n, nseg * fi, device=DEV)
+    gxs = [gslab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+    _lib.check(L.dc_tag_linear_bwd_dx(g.data_ptr(), fo, mask, fo, _ptr_array(ws), nseg, _ptr_array(gxs),
+                                      _i64_array(ld), n, fi, fo, st), "dx")
+    for s in range(nseg):
+        assert rel_err(_np(gxs[s]), (gm @ ws[s].double().cpu()).numpy()) < 2e-6, s
+
+
+# --------------------------------------------------------------------------- #
 # conv layers: forward + backward vs the oracle
 # --------------------------------------------------------------------------- #
 def _pair(kind, fi, fo, seed):
@@ -199,7 +250,9 @@ def test_full_model_golden(backbone, fname):
                 lambda mod, i, o, k=f"conv_{br}_{li}": acts.__setitem__(k, o.detach()))
     pred = m(rest, rig)
     for k, v in acts.items():
-        assert rel_err(_np(v), z[k]) < TOL, k
+        # TAGConv runs with the ReLU fused into the MFMA epilogue inside the encoder
+        ref = z[k].clip(min=0) if backbone == "TAGConv" else z[k]
+        assert rel_err(_np(v), ref) < TOL, k
     assert rel_err(_np(pred.pos), z["pred_pos"]) < TOL
     pred.pos = pred.pos - rest.pos
     tgt = rest.clone()
@@ -210,7 +263,15 @@ def test_full_model_golden(backbone, fname):
     assert abs(float(gcl) - float(z["loss_gcl"])) <= TOL * abs(float(z["loss_gcl"]))
     (l1 + gcl).backward()
     for name, p in m.named_parameters():
-        assert rel_err(_np(p.grad), z["grad." + name]) < 3 * TOL, name
+        ref = z["grad." + name]
+        if name.endswith("att_dst"):
+            # softmax is invariant to a per-destination shift: d loss / d att_dst only flows
+            # through the leaky-relu kink and is ~1e-12 (rounding noise of the softmax
+            # backward); compare it on the scale of its sibling att_src gradient instead.
+            scale = np.abs(z["grad." + name.replace("att_dst", "att_src")]).max()
+            assert np.abs(_np(p.grad) - ref).max() < 3 * TOL * scale, name
+            continue
+        assert rel_err(_np(p.grad), ref) < 3 * TOL, name
 
 
 def test_encoder_golden_hidden256():
