@@ -84,83 +84,96 @@ MAX_SEG = 4   # DC_MAX_SEG in include/deformcontact.h
 
 
 class _TagConvFn(torch.autograd.Function):
-    """Whole TAGConv layer (+ optional fused ReLU): K hops into one ``[N, K*Fi]`` slab, then
+    """Whole TAGConv layer (+ optional fused ReLU): K hops into one ``[N, (K+1)*Fi]`` slab, then
     ONE fp32-MFMA kernel for ``act(x W_0^T + sum_k (A^k x) W_k^T + b)`` - PyG ``tag_conv.py``
     forward followed by ``F.relu`` (``models/model.py:71,77``).  Backward: one dW kernel
-    (+ bias grad), one dX kernel writing the per-hop gradient slab, K transposed hops."""
+    (+ bias grad), one dX kernel writing the per-hop gradient slab, K transposed hops.
+
+    Narrow layers (Fi = 21 / 25 of the input encodings) run the dense block as ONE segment
+    over the concatenated slab (K-dim (K+1)*Fi = 84 / 100: aligned float4 loads, one
+    128-wide dW tile); wide layers pass the K+1 column blocks as separate segments."""
 
     @staticmethod
     def forward(ctx, g: GraphIndex, x: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
                 *weights):
-        x = x.contiguous()
         n, fi = x.shape
         k = len(weights) - 1
         fo = weights[0].size(0)
         if k + 1 > MAX_SEG:
             raise NotImplementedError(f"TAGConv K={k} > {MAX_SEG - 1} is not supported by the fused dense block")
-        ws = [w.contiguous() for w in weights]
-        xh = torch.empty((n, max(k, 1) * fi), dtype=torch.float32, device=x.device)
-        xs, src = [x], x
+        dev = x.device
+        concat = (fi * (k + 1) <= 128) or (fi % 4 != 0)
+        slab = torch.empty((n, (k + 1) * fi), dtype=torch.float32, device=dev)
+        blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
+        blocks[0].copy_(x)
         for j in range(k):
-            dst = xh[:, j * fi:(j + 1) * fi]
-            hop(g.fwd, src, out=dst, weighted=g.normalize)
-            xs.append(dst)
-            src = dst
-        ldxs = [fi] + [k * fi] * k
-        out = torch.empty((n, fo), dtype=torch.float32, device=x.device)
+            hop(g.fwd, blocks[j], out=blocks[j + 1], weighted=g.normalize)
+        if concat:
+            ws = [torch.cat([w for w in weights], dim=1)]            # [Fo, (K+1)*Fi]
+            xs, ldxs, fi_eff = [slab], [(k + 1) * fi], (k + 1) * fi
+        else:
+            ws = [w.contiguous() for w in weights]
+            xs, ldxs, fi_eff = blocks, [(k + 1) * fi] * (k + 1), fi
+        out = torch.empty((n, fo), dtype=torch.float32, device=dev)
         b = bias.contiguous() if bias is not None else None
         rc = _lib.lib().dc_tag_linear_fwd(
-            _ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), k + 1,
-            b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), fo, n, fi, fo,
-            current_stream_ptr(x.device))
+            _ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
+            b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), fo, n, fi_eff, fo,
+            current_stream_ptr(dev))
         _lib.check(rc, "dc_tag_linear_fwd")
-        ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu = g, k, fi, fo, bias is not None, relu
-        ctx.save_for_backward(x, xh, out if relu else None, *ws)
+        ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu, ctx.concat = \
+            g, k, fi, fo, bias is not None, relu, concat
+        ctx.save_for_backward(slab, out if relu else None, *ws)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, xh, out, *ws = ctx.saved_tensors
-        g, k, fi, fo = ctx.g, ctx.k, ctx.fi, ctx.fo
+        slab, out, *ws = ctx.saved_tensors
+        g, k, fi, fo, concat = ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.concat
         L = _lib.lib()
         gout = gout.contiguous()
-        n = x.size(0)
-        dev = x.device
+        n = slab.size(0)
+        dev = slab.device
         st = current_stream_ptr(dev)
         need_x, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         need_w = any(ctx.needs_input_grad[4:])
         mask_ptr = out.data_ptr() if out is not None else None
-        xs = [x] + [xh[:, j * fi:(j + 1) * fi] for j in range(k)]
-        ldxs = [fi] + [k * fi] * k
+        width = (k + 1) * fi
+        if concat:
+            xs, ldxs, fi_eff, nseg = [slab], [width], width, 1
+        else:
+            xs = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
+            ldxs, fi_eff, nseg = [width] * (k + 1), fi, k + 1
 
         gws: List[Optional[torch.Tensor]] = [None] * (k + 1)
         gb = None
         if need_w or need_b:
-            gw_all = torch.empty((k + 1, fo, fi), dtype=torch.float32, device=dev)
+            gw_all = torch.empty((nseg, fo, fi_eff), dtype=torch.float32, device=dev)
             gb = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
-            nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, k + 1)
+            nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi_eff, fo, nseg)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             rc = L.dc_tag_linear_bwd_dw(
-                gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(xs), _i64_array(ldxs), k + 1,
-                _ptr_array([gw_all[j] for j in range(k + 1)]),
-                gb.data_ptr() if gb is not None else None, scratch.data_ptr(), nbytes, n, fi, fo, st)
+                gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(xs), _i64_array(ldxs), nseg,
+                _ptr_array([gw_all[j] for j in range(nseg)]),
+                gb.data_ptr() if gb is not None else None, scratch.data_ptr(), nbytes, n, fi_eff,
+                fo, st)
             _lib.check(rc, "dc_tag_linear_bwd_dw")
-            gws = [gw_all[j] if ctx.needs_input_grad[4 + j] else None for j in range(k + 1)]
+            for j in range(k + 1):
+                if ctx.needs_input_grad[4 + j]:
+                    gws[j] = gw_all[0][:, j * fi:(j + 1) * fi] if concat else gw_all[j]
 
         gx = None
         if need_x:
-            gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
-            gh = torch.empty((n, max(k, 1) * fi), dtype=torch.float32, device=dev)
-            gxs = [gx] + [gh[:, j * fi:(j + 1) * fi] for j in range(k)]
-            rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws), k + 1,
-                                        _ptr_array(gxs), _i64_array(ldxs), n, fi, fo, st)
+            gslab = torch.empty((n, width), dtype=torch.float32, device=dev)
+            gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
+            gxs = [gslab] if concat else gblocks
+            rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws), nseg,
+                                        _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
             _lib.check(rc, "dc_tag_linear_bwd_dx")
-            if k > 0:
-                acc = gxs[k]
-                for j in range(k - 1, 0, -1):                       # g_j = G_j + A^T g_{j+1}
-                    hop(g.bwd, acc, out=gxs[j], addend=gxs[j], weighted=g.normalize)
-                    acc = gxs[j]
-                hop(g.bwd, acc, out=gx, addend=gx, weighted=g.normalize)
+            for j in range(k, 0, -1):                   # g_{j-1} = G_{j-1} + A^T g_j
+                hop(g.bwd, gblocks[j], out=gblocks[j - 1], addend=gblocks[j - 1],
+                    weighted=g.normalize)
+            gx = gblocks[0]
         return (None, gx, gb, None, *gws)
 
 
