@@ -1,0 +1,135 @@
+// dc_dense.h -- shared pieces of the dense-block kernels (internal).
+#pragma once
+#include "dc_common.h"
+
+namespace dc {
+
+constexpr int BK = 16;
+constexpr int LDK = BK + 4;
+constexpr int BN = 128;           // block tile = (64*MB) x 128, 2x2 waves of (32*MB) x 64
+constexpr int kMaxSeg = DC_MAX_SEG;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct Mat {
+    const float *p;
+    int64_t ld;
+};
+
+// ---- LDS -> register fragments (one 8-wide k chunk) and the 8 MFMAs that consume them ----
+// The fragments of the NEXT chunk are read while the MFMAs of the current chunk issue (the
+// next chunk may belong to the next stage: 3-deep LDS ring), so the matrix pipe never waits
+// on LDS latency, also right after a barrier.
+template <int MB>
+struct Frag {
+    float a[MB][4];
+    float b[2][4];
+};
+
+template <int MB, bool A_KC, bool B_KC>
+__device__ __forceinline__ void load_frag(Frag<MB> &f, const float *As, const float *Bs, int c,
+                                          int wm, int wn) {
+    constexpr int BM = 64 * MB;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int kb = 8 * c + 4 * h;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int row = wm * 32 * MB + mb * 32 + r;
+        if (A_KC) {
+            const float4 t = *reinterpret_cast<const float4 *>(As + row * LDK + kb);
+            f.a[mb][0] = t.x, f.a[mb][1] = t.y, f.a[mb][2] = t.z, f.a[mb][3] = t.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.a[mb][t] = As[(kb + t) * BM + row];
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        if (B_KC) {
+            const float4 t =
+                *reinterpret_cast<const float4 *>(Bs + (wn * 64 + nb * 32 + r) * LDK + kb);
+            f.b[nb][0] = t.x, f.b[nb][1] = t.y, f.b[nb][2] = t.z, f.b[nb][3] = t.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.b[nb][t] = Bs[(kb + t) * BN + wn * 64 + nb * 32 + r];
+        }
+    }
+}
+
+template <int MB>
+__device__ __forceinline__ void mma_frag(const Frag<MB> &f, f32x16 (&acc)[MB][2]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mb][t], f.b[0][t], acc[mb][0], 0, 0, 0);
+            acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mb][t], f.b[1][t], acc[mb][1], 0, 0, 0);
+        }
+}
+
+template <int MB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MB][2]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][0][i] = 0.f, acc[mb][1][i] = 0.f;
+}
+
+template <int MB> struct Tile {
+    static constexpr int BM = 64 * MB;
+    static constexpr int A_KC = BM * LDK, B_KC = BN * LDK, A_RC = BK * BM, B_RC = BK * BN;
+};
+
+// C/D fragment -> (row, col) of the wave's 32x32 blocks: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+template <int MB, typename F>
+__device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[MB][2], int wm, int wn, F &&f) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = wm * 32 * MB + mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int col = wn * 64 + nb * 32 + c;
+                f(row, col, acc[mb][nb][reg]);
+            }
+}
+
+struct FwdParams {
+    Mat x[kMaxSeg];
+    Mat w[kMaxSeg];
+    const float *bias;
+    float *out;
+    int64_t ldo, N, Fi, Fo;
+    int nseg, relu;
+};
+
+struct DxParams {
+    Mat g, mask;
+    int has_mask;
+    Mat w[kMaxSeg];
+    float *gx[kMaxSeg];
+    int64_t ldgx[kMaxSeg];
+    int64_t N, Fi, Fo;
+    int nseg;
+};
+
+struct DwParams {
+    Mat g, mask;
+    int has_mask;
+    Mat x[kMaxSeg];
+    float *partial;        // [nchunks][nseg][Fo][Fi]
+    float *bias_partial;   // [nchunks][Fo] or null
+    int64_t N, Fi, Fo, chunk_rows;
+    int nseg, nchunks;
+};
+
+
+// lean fast-path launchers (dc_dense_fast.hip); return false when the shape is not eligible
+bool fwd_fast_launch(const FwdParams &p, int mb, hipStream_t hs);
+bool dx_fast_launch(const DxParams &p, int mb, hipStream_t hs);
+bool dw_fast_launch(const DwParams &p, int mb, hipStream_t hs);
+
+}  // namespace dc

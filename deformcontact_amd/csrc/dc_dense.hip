@@ -19,41 +19,33 @@
 // contiguous is kept "RC" ([k][row]: conflict-free ds_read_b32) - no transposes while
 // staging.  Inside each 8-wide k chunk the k order is permuted identically for A and B
 // (lane half h takes k = 4h+t for MFMA t) so a KC operand needs ONE b128 per 4 MFMAs.
-#include "dc_common.h"
+#include <stdlib.h>
+
+#include "dc_dense.h"
 
 namespace dc {
 
-constexpr int BK = 16;
-constexpr int LDK = BK + 4;
-constexpr int BM = 64, BN = 128;
-constexpr int kMaxSeg = DC_MAX_SEG;
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-struct Mat {
-    const float *p;
-    int64_t ld;
-};
-
+// Loads are UNCONDITIONAL with clamped (always in-bounds) addresses and the out-of-range /
+// ReLU-masked lanes are zeroed when the registers are written to LDS: no branches around
+// loads, so the prefetch stays in flight behind the MFMAs.
 // VEC kernels are only launched when every operand is 16-byte aligned with ld % 4 == 0 and
-// extents % 4 == 0, so a float4 is either wholly inside or wholly outside: one predicated
-// global_load_dwordx4, no tail code in the hot loop.  The scalar variant handles F = 21 / 25.
+// extents % 4 == 0, so a float4 is either wholly inside or wholly outside.  The scalar
+// variant handles F = 21 / 25 (four dword loads, per-element validity).
 template <bool VEC>
-__device__ __forceinline__ float4 ld4(const float *p, int nvalid) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ float4 ld4(const float *row_ptr, int64_t k, int64_t kmax) {
     if (VEC) {
-        if (nvalid >= 4) r = *reinterpret_cast<const float4 *>(p);
+        const int64_t kc = (k + 4 <= kmax) ? k : 0;
+        return *reinterpret_cast<const float4 *>(row_ptr + kc);
     } else {
-        if (nvalid > 0) r.x = p[0];
-        if (nvalid > 1) r.y = p[1];
-        if (nvalid > 2) r.z = p[2];
-        if (nvalid > 3) r.w = p[3];
+        const int64_t last = kmax - 1;
+        return make_float4(row_ptr[k + 0 <= last ? k + 0 : last], row_ptr[k + 1 <= last ? k + 1 : last],
+                           row_ptr[k + 2 <= last ? k + 2 : last], row_ptr[k + 3 <= last ? k + 3 : last]);
     }
-    return r;
 }
 
-__device__ __forceinline__ int nvalid4(int64_t remaining) {
-    return remaining >= 4 ? 4 : (remaining > 0 ? (int)remaining : 0);
+__device__ __forceinline__ float4 zero_invalid(float4 v, bool row_ok, int64_t k, int64_t kmax) {
+    return make_float4((row_ok && k + 0 < kmax) ? v.x : 0.f, (row_ok && k + 1 < kmax) ? v.y : 0.f,
+                       (row_ok && k + 2 < kmax) ? v.z : 0.f, (row_ok && k + 3 < kmax) ? v.w : 0.f);
 }
 
 __device__ __forceinline__ float4 relu_mask(float4 v, float4 m) {
@@ -62,155 +54,183 @@ __device__ __forceinline__ float4 relu_mask(float4 v, float4 m) {
 }
 
 // ---- global -> registers for one BK-deep stage --------------------------------
-// KC source: element (row, k) at p[row*ld + k]; tile = ROWS x BK
-template <int ROWS, bool VEC>
+// The register sets hold ONLY the loaded float4s; tile coordinates are recomputed from the
+// (wave-uniform) stage arguments when the set is written to LDS, so a second set in flight
+// costs 4 VGPRs per float4 and nothing else.
+struct TileArgs {          // what load() and store() both need; all wave-uniform
+    int64_t r0, rmax;      // first row / row bound of the tile's slow index
+    int64_t c0, cmax;      // first element / bound of the tile's contiguous index
+};
+
+// KC source: element (row, k) at p[row*ld + k]; tile = ROWS x BK (requires rmax, cmax >= 1)
+template <int ROWS, bool VEC, bool MASK>
 struct StageKC {
     float4 v[ROWS / 64];
-    __device__ __forceinline__ void load(const Mat &m, const Mat *mask, int64_t row0,
-                                         int64_t nrows, int64_t k0, int64_t kmax) {
+    float4 m[MASK ? ROWS / 64 : 1];
+    __device__ __forceinline__ void load(const Mat &mat, const Mat &mask, const TileArgs &t) {
         const int k4 = threadIdx.x & 3, r = threadIdx.x >> 2;
+        const int64_t k = t.c0 + 4 * k4;
 #pragma unroll
         for (int j = 0; j < ROWS / 64; ++j) {
-            const int64_t row = row0 + r + 64 * j, k = k0 + 4 * k4;
-            const int nv = row < nrows ? nvalid4(kmax - k) : 0;
-            v[j] = ld4<VEC>(m.p + row * m.ld + k, nv);
-            if (mask) v[j] = relu_mask(v[j], ld4<VEC>(mask->p + row * mask->ld + k, nv));
+            const int64_t row = t.r0 + r + 64 * j;
+            const int64_t rc = row < t.rmax ? row : t.rmax - 1;
+            v[j] = ld4<VEC>(mat.p + rc * mat.ld, k, t.cmax);
+            if (MASK) m[j] = ld4<VEC>(mask.p + rc * mask.ld, k, t.cmax);
         }
     }
-    __device__ __forceinline__ void store(float *lds) const {
+    __device__ __forceinline__ float4 value(int j, const TileArgs &t) const {
+        const int k4 = threadIdx.x & 3, r = threadIdx.x >> 2;
+        float4 x = zero_invalid(v[j], t.r0 + r + 64 * j < t.rmax, t.c0 + 4 * k4, t.cmax);
+        if (MASK) x = relu_mask(x, m[j]);
+        return x;
+    }
+    __device__ __forceinline__ void store(float *lds, const TileArgs &t) const {
         const int k4 = threadIdx.x & 3, r = threadIdx.x >> 2;
 #pragma unroll
         for (int j = 0; j < ROWS / 64; ++j)
-            *reinterpret_cast<float4 *>(lds + (r + 64 * j) * LDK + 4 * k4) = v[j];
+            *reinterpret_cast<float4 *>(lds + (r + 64 * j) * LDK + 4 * k4) = value(j, t);
     }
 };
 
-// RC source: element (k, col) at p[k*ld + col]; tile = BK x COLS
-template <int COLS, bool VEC>
+// RC source: element (k, col) at p[k*ld + col]; tile = BK x COLS: r0/rmax index k, c0/cmax
+// index the contiguous column
+template <int COLS, bool VEC, bool MASK>
 struct StageRC {
     static constexpr int PER = COLS / 4;        // float4 per k row
     static constexpr int KPER = 256 / PER;      // k rows covered per pass
     static constexpr int NLD = BK / KPER;
     float4 v[NLD];
-    __device__ __forceinline__ void load(const Mat &m, const Mat *mask, int64_t k0, int64_t kmax,
-                                         int64_t col0, int64_t ncols) {
-        const int c4 = threadIdx.x % PER, kk = threadIdx.x / PER;
+    float4 m[MASK ? NLD : 1];
+    __device__ __forceinline__ void load(const Mat &mat, const Mat &mask, const TileArgs &t) {
+        const int c4 = threadIdx.x % PER, kr = threadIdx.x / PER;
+        const int64_t col = t.c0 + 4 * c4;
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int64_t k = k0 + kk + KPER * j, col = col0 + 4 * c4;
-            const int nv = k < kmax ? nvalid4(ncols - col) : 0;
-            v[j] = ld4<VEC>(m.p + k * m.ld + col, nv);
-            if (mask) v[j] = relu_mask(v[j], ld4<VEC>(mask->p + k * mask->ld + col, nv));
+            const int64_t k = t.r0 + kr + KPER * j;
+            const int64_t kc = k < t.rmax ? k : t.rmax - 1;
+            v[j] = ld4<VEC>(mat.p + kc * mat.ld, col, t.cmax);
+            if (MASK) m[j] = ld4<VEC>(mask.p + kc * mask.ld, col, t.cmax);
         }
     }
-    __device__ __forceinline__ void store(float *lds) const {
-        const int c4 = threadIdx.x % PER, kk = threadIdx.x / PER;
+    __device__ __forceinline__ float4 value(int j, const TileArgs &t) const {
+        const int c4 = threadIdx.x % PER, kr = threadIdx.x / PER;
+        float4 x = zero_invalid(v[j], t.r0 + kr + KPER * j < t.rmax, t.c0 + 4 * c4, t.cmax);
+        if (MASK) x = relu_mask(x, m[j]);
+        return x;
+    }
+    __device__ __forceinline__ void store(float *lds, const TileArgs &t) const {
+        const int c4 = threadIdx.x % PER, kr = threadIdx.x / PER;
 #pragma unroll
         for (int j = 0; j < NLD; ++j)
-            *reinterpret_cast<float4 *>(lds + (kk + KPER * j) * COLS + 4 * c4) = v[j];
+            *reinterpret_cast<float4 *>(lds + (kr + KPER * j) * COLS + 4 * c4) = value(j, t);
     }
 };
 
-// ---- one BK stage of MFMAs for this wave's 32 x 64 sub-tile --------------------
-template <bool A_KC, bool B_KC>
-__device__ __forceinline__ void mma_stage(const float *As, const float *Bs, f32x16 (&acc)[2],
-                                          int wm, int wn) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-        float a[4], b[2][4];
-        const int kb = 8 * c + 4 * h;
-        if (A_KC) {
-            const float4 t = *reinterpret_cast<const float4 *>(As + (wm * 32 + r) * LDK + kb);
-            a[0] = t.x, a[1] = t.y, a[2] = t.z, a[3] = t.w;
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = As[(kb + t) * BM + wm * 32 + r];
+constexpr int kRing = 3;   // LDS stages
+static_assert(BK == 16, "the pipeline below is written for two 8-wide chunks per stage");
+
+// Software pipeline shared by the three kernels.  Per stage: [read chunk 1 | MFMA chunk 0]
+// [read chunk 0 of stage it+1 | MFMA chunk 1], then refill the ring: registers (global data
+// of stage it+2, loaded one step ago) -> LDS, issue the global loads of stage it+3, barrier.
+// Software pipeline shared by the three kernels.
+//   global -> registers : issued FOUR stages ahead into one of two named register sets, so a
+//                         load has two full MFMA phases to land (L2/HBM latency under load is
+//                         longer than one phase: with a one-stage prefetch the kernel ran at
+//                         ~60 % of the MFMA rate, serialising memory and matrix time);
+//   registers -> LDS    : two stages ahead, into a 3-deep ring;
+//   LDS -> fragments    : one 8-wide chunk ahead of the MFMAs that consume it.
+struct NoHook {
+    template <typename S>
+    __device__ __forceinline__ void operator()(const S &, const TileArgs &) const {}
+};
+
+// Software pipeline shared by the three kernels.
+//   global -> registers : issued FOUR stages ahead into one of two named register sets, so a
+//                         load has two full MFMA phases to land (L2/HBM latency under load is
+//                         longer than one phase: with a one-stage prefetch the kernel ran at
+//                         ~60 % of the MFMA rate, serialising memory and matrix time);
+//   registers -> LDS    : two stages ahead, into a 3-deep ring;
+//   LDS -> fragments    : one 8-wide chunk ahead of the MFMAs that consume it.
+// `tile(st, ta, tb)` fills the wave-uniform tile coordinates of stage st; `ldA/ldB(set, t)`
+// issue the loads.
+template <int MB, bool A_KC, bool B_KC, int STAGE, int OFFB, typename SA, typename SB,
+          typename TileFn, typename LdA, typename LdB, typename Hook = NoHook>
+__device__ __forceinline__ void gemm_pipeline(float *lds, int nst, TileFn &&tile, LdA &&ldA,
+                                              LdB &&ldB, f32x16 (&acc)[MB][2], int wm, int wn,
+                                              Hook &&on_store_a = NoHook{}) {
+    SA a0, a1;
+    SB b0, b1;
+    auto gload = [&](int st, SA &ra, SB &rb) {
+        TileArgs ta, tb;
+        tile(st, ta, tb);
+        ldA(ra, ta);
+        ldB(rb, tb);
+    };
+    auto lstore = [&](int st, const SA &ra, const SB &rb) {
+        TileArgs ta, tb;
+        tile(st, ta, tb);
+        ra.store(lds + (st % kRing) * STAGE, ta);
+        rb.store(lds + (st % kRing) * STAGE + OFFB, tb);
+        on_store_a(ra, ta);             // every stage passes here exactly once
+    };
+    if (nst > 0) gload(0, a0, b0);
+    if (nst > 1) gload(1, a1, b1);
+    if (nst > 0) lstore(0, a0, b0);
+    if (nst > 2) gload(2, a0, b0);
+    if (nst > 1) lstore(1, a1, b1);
+    if (nst > 3) gload(3, a1, b1);
+    __syncthreads();
+    Frag<MB> f0, f1;
+    if (nst > 0) load_frag<MB, A_KC, B_KC>(f0, lds, lds + OFFB, 0, wm, wn);
+    auto step = [&](int it, SA &ra, SB &rb) {
+        if (it + 2 < nst) lstore(it + 2, ra, rb);      // loaded two steps ago
+        if (it + 4 < nst) gload(it + 4, ra, rb);
+        const float *cur = lds + (it % kRing) * STAGE;
+        load_frag<MB, A_KC, B_KC>(f1, cur, cur + OFFB, 1, wm, wn);
+        mma_frag<MB>(f0, acc);
+        if (it + 1 < nst) {
+            const float *nxt = lds + ((it + 1) % kRing) * STAGE;
+            load_frag<MB, A_KC, B_KC>(f0, nxt, nxt + OFFB, 0, wm, wn);
         }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            if (B_KC) {
-                const float4 t =
-                    *reinterpret_cast<const float4 *>(Bs + (wn * 64 + nb * 32 + r) * LDK + kb);
-                b[nb][0] = t.x, b[nb][1] = t.y, b[nb][2] = t.z, b[nb][3] = t.w;
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) b[nb][t] = Bs[(kb + t) * BN + wn * 64 + nb * 32 + r];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[0][t], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[1][t], acc[1], 0, 0, 0);
-        }
+        mma_frag<MB>(f1, acc);
+        __syncthreads();
+    };
+    for (int it = 0; it < nst; it += 2) {     // two named register sets: nothing runtime-indexed
+        step(it, a0, b0);
+        if (it + 1 >= nst) break;
+        step(it + 1, a1, b1);
     }
-}
-
-constexpr int kLdsA_KC = BM * LDK, kLdsB_KC = BN * LDK;
-constexpr int kLdsA_RC = BK * BM, kLdsB_RC = BK * BN;
-
-// C/D fragment -> (row, col) of the wave's 32x32 block: col = lane&31,
-// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-template <typename F>
-__device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[2], int wm, int wn, F &&f) {
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const int col = wn * 64 + nb * 32 + c;
-            f(row, col, acc[nb][reg]);
-        }
 }
 
 // =============================== forward ========================================
-struct FwdParams {
-    Mat x[kMaxSeg];
-    Mat w[kMaxSeg];
-    const float *bias;
-    float *out;
-    int64_t ldo, N, Fi, Fo;
-    int nseg, relu;
-};
 
-template <bool VEC>
+template <int MB, bool VEC>
 __global__ void __launch_bounds__(256)
 k_tag_linear_fwd(FwdParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (kLdsA_KC + kLdsB_KC)];
+    using T = Tile<MB>;
+    constexpr int BM = T::BM, kStage = T::A_KC + T::B_KC, kOffB = T::A_KC;
+    __shared__ __attribute__((aligned(16))) float lds[kRing * kStage];
     const unsigned ntn = (unsigned)((p.Fo + BN - 1) / BN);
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row0 = (int64_t)(lb / ntn) * BM, col0 = (int64_t)(lb % ntn) * BN;
     const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
-    constexpr int kStage = kLdsA_KC + kLdsB_KC, kOffB = kLdsA_KC;
 
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = 0.f, acc[1][i] = 0.f;
+    f32x16 acc[MB][2];
+    zero_acc<MB>(acc);
 
     const int kst = (int)((p.Fi + BK - 1) / BK), nst = kst * p.nseg;
-    StageKC<BM, VEC> ra;
-    StageKC<BN, VEC> rb;
-    ra.load(p.x[0], nullptr, row0, p.N, 0, p.Fi);
-    rb.load(p.w[0], nullptr, col0, p.Fo, 0, p.Fi);
-    ra.store(lds);
-    rb.store(lds + kOffB);
-    __syncthreads();
-    for (int it = 0; it < nst; ++it) {
-        const int nx = it + 1;
-        if (nx < nst) {
-            const int s = nx / kst;
-            const int64_t k0 = (int64_t)(nx % kst) * BK;
-            ra.load(p.x[s], nullptr, row0, p.N, k0, p.Fi);
-            rb.load(p.w[s], nullptr, col0, p.Fo, k0, p.Fi);
-        }
-        mma_stage<true, true>(lds + (it & 1) * kStage, lds + (it & 1) * kStage + kOffB, acc, wm, wn);
-        if (nx < nst) {
-            ra.store(lds + (nx & 1) * kStage);
-            rb.store(lds + (nx & 1) * kStage + kOffB);
-        }
-        __syncthreads();
-    }
+    using SA = StageKC<BM, VEC, false>;
+    using SB = StageKC<BN, VEC, false>;
+    int seg = 0;   // segment of the stage most recently described by tile()
+    auto tile = [&](int st, TileArgs &ta, TileArgs &tb) {
+        seg = st / kst;
+        const int64_t k0 = (int64_t)(st % kst) * BK;
+        ta = TileArgs{row0, p.N, k0, p.Fi};
+        tb = TileArgs{col0, p.Fo, k0, p.Fi};
+    };
+    auto ldA = [&](SA &ra, const TileArgs &t) { ra.load(p.x[seg], p.x[seg], t); };
+    auto ldB = [&](SB &rb, const TileArgs &t) { rb.load(p.w[seg], p.w[seg], t); };
+    gemm_pipeline<MB, true, true, kStage, kOffB, SA, SB>(lds, nst, tile, ldA, ldB, acc, wm, wn);
     // each lane owns two output columns (one per 32-wide block): fetch their bias once
     float bcol[2];
 #pragma unroll
@@ -219,7 +239,7 @@ k_tag_linear_fwd(FwdParams p) {
         bcol[nb] = (p.bias && col < p.Fo) ? p.bias[col] : 0.f;
     }
     const bool relu = p.relu != 0;
-    for_each_acc(acc, wm, wn, [&](int r, int c, float v) {
+    for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
         const int64_t row = row0 + r, col = col0 + c;
         if (row < p.N && col < p.Fo) {
             v += bcol[(c >> 5) & 1];
@@ -230,77 +250,49 @@ k_tag_linear_fwd(FwdParams p) {
 }
 
 // =============================== backward: dX ===================================
-struct DxParams {
-    Mat g, mask;
-    int has_mask;
-    Mat w[kMaxSeg];
-    float *gx[kMaxSeg];
-    int64_t ldgx[kMaxSeg];
-    int64_t N, Fi, Fo;
-    int nseg;
-};
 
-template <bool VEC>
+template <int MB, bool VEC, bool MASK>
 __global__ void __launch_bounds__(256)
 k_tag_linear_bwd_dx(DxParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (kLdsA_KC + kLdsB_RC)];
+    using T = Tile<MB>;
+    constexpr int BM = T::BM, kStage = T::A_KC + T::B_RC, kOffB = T::A_KC;
+    __shared__ __attribute__((aligned(16))) float lds[kRing * kStage];
     const unsigned ntn = (unsigned)((p.Fi + BN - 1) / BN), per_row = ntn * p.nseg;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row0 = (int64_t)(lb / per_row) * BM;
     const int s = (int)((lb % per_row) / ntn);
     const int64_t col0 = (int64_t)(lb % ntn) * BN;
     const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
-    constexpr int kStage = kLdsA_KC + kLdsB_RC, kOffB = kLdsA_KC;
-    const Mat *mk = p.has_mask ? &p.mask : nullptr;
 
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = 0.f, acc[1][i] = 0.f;
+    f32x16 acc[MB][2];
+    zero_acc<MB>(acc);
 
     const int nst = (int)((p.Fo + BK - 1) / BK);
-    StageKC<BM, VEC> ra;
-    StageRC<BN, VEC> rb;
-    ra.load(p.g, mk, row0, p.N, 0, p.Fo);
-    rb.load(p.w[s], nullptr, 0, p.Fo, col0, p.Fi);
-    ra.store(lds);
-    rb.store(lds + kOffB);
-    __syncthreads();
-    for (int it = 0; it < nst; ++it) {
-        const int nx = it + 1;
-        if (nx < nst) {
-            ra.load(p.g, mk, row0, p.N, (int64_t)nx * BK, p.Fo);
-            rb.load(p.w[s], nullptr, (int64_t)nx * BK, p.Fo, col0, p.Fi);
-        }
-        mma_stage<true, false>(lds + (it & 1) * kStage, lds + (it & 1) * kStage + kOffB, acc, wm, wn);
-        if (nx < nst) {
-            ra.store(lds + (nx & 1) * kStage);
-            rb.store(lds + (nx & 1) * kStage + kOffB);
-        }
-        __syncthreads();
-    }
+    using SA = StageKC<BM, VEC, MASK>;
+    using SB = StageRC<BN, VEC, false>;
+    auto tile = [&](int st, TileArgs &ta, TileArgs &tb) {
+        ta = TileArgs{row0, p.N, (int64_t)st * BK, p.Fo};
+        tb = TileArgs{(int64_t)st * BK, p.Fo, col0, p.Fi};
+    };
+    auto ldA = [&](SA &ra, const TileArgs &t) { ra.load(p.g, p.mask, t); };
+    auto ldB = [&](SB &rb, const TileArgs &t) { rb.load(p.w[s], p.w[s], t); };
+    gemm_pipeline<MB, true, false, kStage, kOffB, SA, SB>(lds, nst, tile, ldA, ldB, acc, wm, wn);
     float *out = p.gx[s];
     const int64_t ldo = p.ldgx[s];
-    for_each_acc(acc, wm, wn, [&](int r, int c, float v) {
+    for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
         const int64_t row = row0 + r, col = col0 + c;
         if (row < p.N && col < p.Fi) out[row * ldo + col] = v;
     });
 }
 
 // =============================== backward: dW ===================================
-struct DwParams {
-    Mat g, mask;
-    int has_mask;
-    Mat x[kMaxSeg];
-    float *partial;        // [nchunks][nseg][Fo][Fi]
-    float *bias_partial;   // [nchunks][Fo] or null
-    int64_t N, Fi, Fo, chunk_rows;
-    int nseg, nchunks;
-};
 
-template <bool VEC>
+template <int MB, bool VEC, bool MASK>
 __global__ void __launch_bounds__(256)
 k_tag_linear_bwd_dw(DwParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (kLdsA_RC + kLdsB_RC)];
+    using T = Tile<MB>;
+    constexpr int BM = T::BM, kStage = T::A_RC + T::B_RC, kOffB = T::A_RC;
+    __shared__ __attribute__((aligned(16))) float lds[kRing * kStage];
     const unsigned ntm = (unsigned)((p.Fo + BM - 1) / BM), ntn = (unsigned)((p.Fi + BN - 1) / BN);
     const unsigned tiles = ntm * ntn, per_chunk = tiles * p.nseg;
     const unsigned lb = blockIdx.x;
@@ -310,50 +302,60 @@ k_tag_linear_bwd_dw(DwParams p) {
     const int64_t n_beg = (int64_t)chunk * p.chunk_rows;
     const int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
     const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
-    constexpr int kStage = kLdsA_RC + kLdsB_RC, kOffB = kLdsA_RC;
-    const Mat *mk = p.has_mask ? &p.mask : nullptr;
     const bool do_bias = p.bias_partial && s == 0 && f0 == 0;
 
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] = 0.f, acc[1][i] = 0.f;
-    float bsum = 0.f;
+    f32x16 acc[MB][2];
+    zero_acc<MB>(acc);
+    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int nst = (int)((n_end - n_beg + BK - 1) / BK);
-    StageRC<BM, VEC> ra;
-    StageRC<BN, VEC> rb;
-    if (nst > 0) {
-        ra.load(p.g, mk, n_beg, n_end, o0, p.Fo);
-        rb.load(p.x[s], nullptr, n_beg, n_end, f0, p.Fi);
-        ra.store(lds);
-        rb.store(lds + kOffB);
-    }
-    __syncthreads();
-    for (int it = 0; it < nst; ++it) {
-        const int nx = it + 1;
-        if (nx < nst) {
-            ra.load(p.g, mk, n_beg + (int64_t)nx * BK, n_end, o0, p.Fo);
-            rb.load(p.x[s], nullptr, n_beg + (int64_t)nx * BK, n_end, f0, p.Fi);
-        }
-        mma_stage<false, false>(lds + (it & 1) * kStage, lds + (it & 1) * kStage + kOffB, acc, wm, wn);
-        if (do_bias && threadIdx.x < BM) {
-            const float *a = lds + (it & 1) * kStage;
+    using SA = StageRC<BM, VEC, MASK>;
+    using SB = StageRC<BN, VEC, false>;
+    auto tile = [&](int st, TileArgs &ta, TileArgs &tb) {
+        ta = TileArgs{n_beg + (int64_t)st * BK, n_end, o0, p.Fo};
+        tb = TileArgs{n_beg + (int64_t)st * BK, n_end, f0, p.Fi};
+    };
+    auto ldA = [&](SA &ra, const TileArgs &t) { ra.load(p.g, p.mask, t); };
+    auto ldB = [&](SB &rb, const TileArgs &t) { rb.load(p.x[s], p.x[s], t); };
+    // bias gradient = column sums of the (masked) g tile: each thread adds up the float4s it
+    // stages (4 columns x NLD node rows per stage); reduced across threads after the loop
+    auto bias_hook = [&](const SA &ra, const TileArgs &t) {
+        if (do_bias) {
 #pragma unroll
-            for (int k = 0; k < BK; ++k) bsum += a[k * BM + threadIdx.x];
+            for (int j = 0; j < SA::NLD; ++j) {
+                const float4 x = ra.value(j, t);
+                bsum4.x += x.x, bsum4.y += x.y, bsum4.z += x.z, bsum4.w += x.w;
+            }
         }
-        if (nx < nst) {
-            ra.store(lds + (nx & 1) * kStage);
-            rb.store(lds + (nx & 1) * kStage + kOffB);
-        }
-        __syncthreads();
-    }
+    };
+    gemm_pipeline<MB, false, false, kStage, kOffB, SA, SB>(lds, nst, tile, ldA, ldB, acc, wm, wn,
+                                                          bias_hook);
     float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
-    for_each_acc(acc, wm, wn, [&](int r, int c, float v) {
+    for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
         const int64_t o = o0 + r, f = f0 + c;
         if (o < p.Fo && f < p.Fi) out[o * p.Fi + f] = v;
     });
-    if (do_bias && threadIdx.x < BM && o0 + threadIdx.x < p.Fo)
-        p.bias_partial[(int64_t)chunk * p.Fo + o0 + threadIdx.x] = bsum;
+    if (do_bias) {
+        // thread t holds columns 4*(t % PER)..+3 of k-rows t / PER: reduce the 256/PER row
+        // groups through LDS (all stages are consumed; the ring is free)
+        __syncthreads();
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[threadIdx.x] = bsum4;
+        __syncthreads();
+        if (threadIdx.x < SA::PER) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < 256 / SA::PER; ++g) {
+                const float4 v = red[g * SA::PER + threadIdx.x];
+                t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+            }
+            float *bp = p.bias_partial + (int64_t)chunk * p.Fo;
+            const int64_t o = o0 + 4 * threadIdx.x;
+            if (o + 0 < p.Fo) bp[o + 0] = t.x;
+            if (o + 1 < p.Fo) bp[o + 1] = t.y;
+            if (o + 2 < p.Fo) bp[o + 2] = t.z;
+            if (o + 3 < p.Fo) bp[o + 3] = t.w;
+        }
+    }
 }
 
 // sum the per-chunk slabs in chunk order (deterministic), scatter into the per-segment outputs
@@ -386,8 +388,33 @@ static inline Mat make_mat(const float *p, int64_t ld, bool *vec) {
     return Mat{p, ld};
 }
 
+// tile height: 128-row tiles halve the L2->LDS traffic per FLOP (the kernel is only MFMA-bound
+// with that slack); 64-row tiles for small problems keep enough blocks in flight.
+static inline int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+static inline int pick_mb(int64_t rows, int64_t col_tiles) {
+    static const int forced = env_int("DC_DENSE_MB", 0);
+    if (forced == 1 || forced == 2) return forced;
+    return (((rows + 127) / 128) * col_tiles >= 512) ? 2 : 1;
+}
+
+static inline bool use_fast() {
+    static const int v = env_int("DC_DENSE_FAST", 1);
+    return v != 0;
+}
+
+static inline int dw_mb(int64_t Fo) {
+    static const int forced = env_int("DC_DENSE_MB_DW", 0);
+    if (forced == 1 || forced == 2) return forced;
+    return Fo >= 128 ? 2 : 1;
+}
+
 static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_rows,
                     int *nchunks) {
+    const int64_t BM = 64 * dw_mb(Fo);
     const int64_t tiles = ((Fo + BM - 1) / BM) * ((Fi + BN - 1) / BN) * nseg;
     int64_t want = 1024 / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
@@ -420,14 +447,21 @@ extern "C" int dc_tag_linear_fwd(const float *const *xs, const int64_t *ldxs,
     }
     p.bias = bias, p.out = out, p.ldo = ldo, p.N = N, p.Fi = Fi, p.Fo = Fo;
     p.nseg = nseg, p.relu = relu;
-    const int64_t grid = ((N + BM - 1) / BM) * ((Fo + BN - 1) / BN);
+    const int64_t ntn = (Fo + BN - 1) / BN;
+    const int mb = pick_mb(N, ntn);
+    const int64_t grid = ((N + 64 * mb - 1) / (64 * mb)) * ntn;
     DC_REQUIRE(grid < (int64_t)INT32_MAX, "dc_tag_linear_fwd: grid too large");
-    if (vec)
-        hipLaunchKernelGGL(k_tag_linear_fwd<true>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, p);
+    const dim3 gd((unsigned)grid), bd(256);
+    hipStream_t hs = (hipStream_t)stream;
+    if (use_fast() && vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
+    if (mb == 2 && vec)
+        hipLaunchKernelGGL((k_tag_linear_fwd<2, true>), gd, bd, 0, hs, p);
+    else if (mb == 2)
+        hipLaunchKernelGGL((k_tag_linear_fwd<2, false>), gd, bd, 0, hs, p);
+    else if (vec)
+        hipLaunchKernelGGL((k_tag_linear_fwd<1, true>), gd, bd, 0, hs, p);
     else
-        hipLaunchKernelGGL(k_tag_linear_fwd<false>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, p);
+        hipLaunchKernelGGL((k_tag_linear_fwd<1, false>), gd, bd, 0, hs, p);
     return check_launch("dc_tag_linear_fwd");
 }
 
@@ -452,14 +486,27 @@ extern "C" int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *ou
         p.ldgx[s] = ldgxs[s];
     }
     p.N = N, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg;
-    const int64_t grid = ((N + BM - 1) / BM) * ((Fi + BN - 1) / BN) * nseg;
+    const int64_t ntn = ((Fi + BN - 1) / BN) * nseg;
+    const int mb = pick_mb(N, ntn);
+    const int64_t grid = ((N + 64 * mb - 1) / (64 * mb)) * ntn;
     DC_REQUIRE(grid < (int64_t)INT32_MAX, "dc_tag_linear_bwd_dx: grid too large");
-    if (vec)
-        hipLaunchKernelGGL(k_tag_linear_bwd_dx<true>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(k_tag_linear_bwd_dx<false>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, p);
+    if (!p.has_mask) p.mask = p.g;
+    const dim3 gd((unsigned)grid), bd(256);
+    hipStream_t hs = (hipStream_t)stream;
+    if (use_fast() && vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
+#define DC_DX(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
+    if (mb == 2) {
+        if (vec && p.has_mask) DC_DX(2, true, true);
+        else if (vec) DC_DX(2, true, false);
+        else if (p.has_mask) DC_DX(2, false, true);
+        else DC_DX(2, false, false);
+    } else {
+        if (vec && p.has_mask) DC_DX(1, true, true);
+        else if (vec) DC_DX(1, true, false);
+        else if (p.has_mask) DC_DX(1, false, true);
+        else DC_DX(1, false, false);
+    }
+#undef DC_DX
     return check_launch("dc_tag_linear_bwd_dx");
 }
 
@@ -500,14 +547,28 @@ extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *ou
     p.N = N, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg;
     p.partial = (float *)partials;
     p.bias_partial = gbias ? p.partial + (int64_t)p.nchunks * nseg * Fo * Fi : nullptr;
-    const int64_t tiles = ((Fo + BM - 1) / BM) * ((Fi + BN - 1) / BN);
+    const int mb = dw_mb(Fo);
+    const int64_t tiles = ((Fo + 64 * mb - 1) / (64 * mb)) * ((Fi + BN - 1) / BN);
     const int64_t grid = tiles * nseg * p.nchunks;
-    if (vec)
-        hipLaunchKernelGGL(k_tag_linear_bwd_dw<true>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(k_tag_linear_bwd_dw<false>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, p);
+    if (!p.has_mask) p.mask = p.g;
+    const dim3 gd((unsigned)grid), bd(256);
+    hipStream_t hs = (hipStream_t)stream;
+    bool fast_done = use_fast() && vec && dw_fast_launch(p, mb, hs);
+#define DC_DW(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
+    if (fast_done) {
+    } else
+    if (mb == 2) {
+        if (vec && p.has_mask) DC_DW(2, true, true);
+        else if (vec) DC_DW(2, true, false);
+        else if (p.has_mask) DC_DW(2, false, true);
+        else DC_DW(2, false, false);
+    } else {
+        if (vec && p.has_mask) DC_DW(1, true, true);
+        else if (vec) DC_DW(1, true, false);
+        else if (p.has_mask) DC_DW(1, false, true);
+        else DC_DW(1, false, false);
+    }
+#undef DC_DW
     r.partial = p.partial, r.bias_partial = p.bias_partial, r.gbias = gbias;
     r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = p.nchunks;
     const int64_t total = (int64_t)nseg * Fo * Fi + (gbias ? Fo : 0);
