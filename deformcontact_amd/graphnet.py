@@ -53,9 +53,40 @@ class ContactEncoder(nn.Module):
             x = F.dropout(x, p=self.dropout_rate, training=self.training)
         return x
 
+    #: run the soft and the rigid branch on two HIP streams (they are independent until the
+    #: cross-attention): each branch's kernels fill the tail of the other's, and the short hop
+    #: kernels of one branch hide under the dense blocks of the other.  Autograd replays the
+    #: same two-stream structure in backward; inside hipGraph capture it becomes two parallel
+    #: graph branches.
+    overlap_branches = True
+    _side_streams = {}
+
+    @classmethod
+    def _side_stream(cls, device) -> "torch.cuda.Stream":
+        key = (device.type, device.index)
+        if key not in cls._side_streams:
+            cls._side_streams[key] = torch.cuda.Stream(device=device)
+        return cls._side_streams[key]
+
     def encode(self, graph_resting, graph_rigid) -> Tuple[torch.Tensor, torch.Tensor]:
-        return (self._branch(self.conv_layers_resting, graph_resting.x, graph_resting.edge_index),
-                self._branch(self.conv_layers_rigid, graph_rigid.x, graph_rigid.edge_index))
+        x_s, e_s = graph_resting.x, graph_resting.edge_index
+        x_r, e_r = graph_rigid.x, graph_rigid.edge_index
+        if not (self.overlap_branches and x_s.is_cuda and x_r.is_cuda):
+            return (self._branch(self.conv_layers_resting, x_s, e_s),
+                    self._branch(self.conv_layers_rigid, x_r, e_r))
+        # topology is built (and cached) on the caller's stream before the fork
+        for convs, x, e in ((self.conv_layers_resting, x_s, e_s), (self.conv_layers_rigid, x_r, e_r)):
+            if len(convs) and hasattr(convs[0], "graph"):
+                convs[0].graph(e, x.size(0))
+        main = torch.cuda.current_stream(x_s.device)
+        side = self._side_stream(x_s.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out_r = self._branch(self.conv_layers_rigid, x_r, e_r)
+        out_s = self._branch(self.conv_layers_resting, x_s, e_s)
+        main.wait_stream(side)
+        out_r.record_stream(main)
+        return out_s, out_r
 
     def forward(self, graph_resting, graph_rigid):
         return self.encode(graph_resting, graph_rigid)

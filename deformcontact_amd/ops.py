@@ -102,18 +102,27 @@ class _TagConvFn(torch.autograd.Function):
         if k + 1 > MAX_SEG:
             raise NotImplementedError(f"TAGConv K={k} > {MAX_SEG - 1} is not supported by the fused dense block")
         dev = x.device
-        concat = (fi * (k + 1) <= 128) or (fi % 4 != 0)
-        slab = torch.empty((n, (k + 1) * fi), dtype=torch.float32, device=dev)
+        concat = (fi * (k + 1) <= 128) or (fi % 16 != 0)
+        width = (k + 1) * fi
+        # narrow layers: one K segment over the whole slab, zero-padded to a multiple of 16 so
+        # the lean MFMA path (aligned float4 loads, no K tail) applies (84 -> 96, 100 -> 112)
+        wpad = (width + 15) // 16 * 16 if concat else width
+        slab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
+        if wpad > width:
+            slab[:, width:].zero_()
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
         blocks[0].copy_(x)
         for j in range(k):
             hop(g.fwd, blocks[j], out=blocks[j + 1], weighted=g.normalize)
         if concat:
-            ws = [torch.cat([w for w in weights], dim=1)]            # [Fo, (K+1)*Fi]
-            xs, ldxs, fi_eff = [slab], [(k + 1) * fi], (k + 1) * fi
+            parts = [w for w in weights]
+            if wpad > width:
+                parts.append(torch.zeros((fo, wpad - width), dtype=torch.float32, device=dev))
+            ws = [torch.cat(parts, dim=1)]                           # [Fo, wpad]
+            xs, ldxs, fi_eff = [slab], [wpad], wpad
         else:
             ws = [w.contiguous() for w in weights]
-            xs, ldxs, fi_eff = blocks, [(k + 1) * fi] * (k + 1), fi
+            xs, ldxs, fi_eff = blocks, [wpad] * (k + 1), fi
         out = torch.empty((n, fo), dtype=torch.float32, device=dev)
         b = bias.contiguous() if bias is not None else None
         rc = _lib.lib().dc_tag_linear_fwd(
@@ -138,12 +147,12 @@ class _TagConvFn(torch.autograd.Function):
         need_x, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         need_w = any(ctx.needs_input_grad[4:])
         mask_ptr = out.data_ptr() if out is not None else None
-        width = (k + 1) * fi
+        wpad = slab.size(1)
         if concat:
-            xs, ldxs, fi_eff, nseg = [slab], [width], width, 1
+            xs, ldxs, fi_eff, nseg = [slab], [wpad], wpad, 1
         else:
             xs = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-            ldxs, fi_eff, nseg = [width] * (k + 1), fi, k + 1
+            ldxs, fi_eff, nseg = [wpad] * (k + 1), fi, k + 1
 
         gws: List[Optional[torch.Tensor]] = [None] * (k + 1)
         gb = None
@@ -164,7 +173,7 @@ class _TagConvFn(torch.autograd.Function):
 
         gx = None
         if need_x:
-            gslab = torch.empty((n, width), dtype=torch.float32, device=dev)
+            gslab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
             gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
             gxs = [gslab] if concat else gblocks
             rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws), nseg,
