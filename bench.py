@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="sample pairs per GPU")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-optim", action="store_true", help="leave the Adam step out of the step")
+    ap.add_argument("--serial-branches", action="store_true",
+                    help="soft and rigid branch on ONE stream (default: two overlapped HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--kernel-reps", type=int, default=100)
@@ -59,7 +61,10 @@ def cpu_baseline(batch: int, budget_s: float):
     from deformcontact_amd import synth
     from deformcontact_amd.graphnet import ContactEncoder
     from oracle import pyg_ref
-    cores = os.cpu_count() or 1
+    # torch's CPU gather/scatter stop scaling (and then regress badly) past ~32 threads: measured
+    # on the 2 x EPYC 9575F GPU box 1 thr 2.24 s, 16 thr 1.19 s, 32 thr 1.15 s, 64 thr 1.81 s,
+    # 128 thr 3.41 s per step (tools/cpu_threads.py), so the baseline runs at its best setting.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     rest, _, rig = synth.make_batch(batch)
     torch.manual_seed(0)
@@ -86,7 +91,7 @@ def cpu_baseline(batch: int, budget_s: float):
             "kind": "port",
             "sample": f"{len(times)} timed iterations (1 warm-up) of the same B={batch} encoder "
                       f"fwd+bwd, median {med * 1e3:.1f} ms, torch {torch.__version__} CPU ops, "
-                      f"{cores} threads"}
+                      f"{cores} threads (of {os.cpu_count()} logical CPUs; best-scaling setting)"}
 
 
 def main():
@@ -118,6 +123,7 @@ def main():
     edges_per_rank = e_s + e_r
     torch.manual_seed(0)                      # identical init on every rank
     enc = ContactEncoder([21, 25], 256).to(dev)
+    enc.overlap_branches = not args.serial_branches
     dp.broadcast_parameters(enc)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     g_rest = torch.randn(n_s, 256, device=dev, generator=gen)
@@ -206,7 +212,8 @@ def main():
             "edges_per_gpu_step": edges_per_rank, "global_batch": args.batch * world,
             "step": "fwd + bwd(synthetic upstream grad)" + (" + RCCL grad all-reduce" if world > 1 else "")
                     + ("" if args.no_optim else " + Adam"),
-            "hipgraph": graph is not None, "parallelism": f"dp{world}",
+            "hipgraph": graph is not None, "two_stream_branches": not args.serial_branches,
+            "parallelism": f"dp{world}",
         },
     }
 
