@@ -358,29 +358,50 @@ k_tag_linear_bwd_dw(DwParams p) {
     }
 }
 
-// sum the per-chunk slabs in chunk order (deterministic), scatter into the per-segment outputs
+// Sum the per-chunk slabs in chunk order (deterministic) and write each output block:
+// block j = columns [(j % bps)*cols, +cols) of segment j / bps, as a contiguous [Fo, cols]
+// matrix; `accumulate` adds into the destination (gradient accumulation fused here instead of
+// one elementwise add per parameter afterwards).
 struct ReduceParams {
     const float *partial, *bias_partial;
-    float *gw[kMaxSeg];
+    float *gw[2 * kMaxSeg];
     float *gbias;
-    int64_t Fi, Fo;
-    int nseg, nchunks;
+    int64_t Fi, Fo, cols;
+    int nseg, nchunks, ngw, bps, accumulate;
 };
 
 __global__ void __launch_bounds__(256)
 k_dw_reduce(ReduceParams p) {
-    const int64_t per_seg = p.Fo * p.Fi, total = per_seg * p.nseg;
+    const int64_t per_out = p.Fo * p.cols, total = per_out * p.ngw;
+    const int64_t seg_elems = p.Fo * p.Fi, slab = seg_elems * p.nseg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float *src;
+    float *dst;
+    int64_t stride;
     if (i < total) {
-        float s = 0.f;
-        for (int c = 0; c < p.nchunks; ++c) s += p.partial[(int64_t)c * total + i];
-        p.gw[i / per_seg][i % per_seg] = s;
+        const int j = (int)(i / per_out);
+        const int64_t rem = i % per_out, o = rem / p.cols, c = rem % p.cols;
+        src = p.partial + (int64_t)(j / p.bps) * seg_elems + o * p.Fi + (int64_t)(j % p.bps) * p.cols + c;
+        dst = p.gw[j] + rem;
+        stride = slab;
     } else if (p.gbias && i < total + p.Fo) {
-        const int64_t o = i - total;
-        float s = 0.f;
-        for (int c = 0; c < p.nchunks; ++c) s += p.bias_partial[(int64_t)c * p.Fo + o];
-        p.gbias[o] = s;
+        src = p.bias_partial + (i - total);
+        dst = p.gbias + (i - total);
+        stride = p.Fo;
+    } else {
+        return;
     }
+    float s = 0.f;
+    int c = 0;
+    for (; c + 8 <= p.nchunks; c += 8) {          // 8 independent loads in flight, fixed add order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(c + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < p.nchunks; ++c) s += src[(int64_t)c * stride];
+    *dst = p.accumulate ? *dst + s : s;
 }
 
 static inline Mat make_mat(const float *p, int64_t ld, bool *vec) {
@@ -418,6 +439,7 @@ static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_
     const int64_t tiles = ((Fo + BM - 1) / BM) * ((Fi + BN - 1) / BN) * nseg;
     int64_t want = 1024 / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
+    if (want > 64) want = 64;                 // keeps the slab-reduce pass short
     int64_t rows = (N + want - 1) / want;
     if (rows < 256) rows = 256;
     rows = (rows + BK - 1) / BK * BK;
@@ -521,7 +543,8 @@ extern "C" int64_t dc_tag_linear_bwd_dw_workspace_bytes(int64_t N, int64_t Fi, i
 
 extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask,
                                     int64_t ldo, const float *const *xs, const int64_t *ldxs,
-                                    int nseg, float *const *gws, float *gbias, void *partials,
+                                    int nseg, float *const *gws, int ngw, int64_t gw_cols,
+                                    float *gbias, int accumulate, void *partials,
                                     int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
                                     dc_stream_t stream) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dw: nseg must be 1..%d", kMaxSeg);
@@ -539,9 +562,16 @@ extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *ou
     if (out_for_mask) p.mask = make_mat(out_for_mask, ldo, &vec);
     ReduceParams r{};
     for (int s = 0; s < nseg; ++s) {
-        DC_REQUIRE(xs[s] && gws[s] && ldxs[s] >= Fi, "dc_tag_linear_bwd_dw: bad segment %d", s);
+        DC_REQUIRE(xs[s] && ldxs[s] >= Fi, "dc_tag_linear_bwd_dw: bad segment %d", s);
         p.x[s] = make_mat(xs[s], ldxs[s], &vec);
-        r.gw[s] = gws[s];
+    }
+    DC_REQUIRE(ngw >= nseg && ngw <= 2 * kMaxSeg && ngw % nseg == 0 && gw_cols >= 1 &&
+                   (ngw / nseg) * gw_cols <= Fi,
+               "dc_tag_linear_bwd_dw: %d output blocks of %lld columns do not tile %d segments of %lld",
+               ngw, (long long)gw_cols, nseg, (long long)Fi);
+    for (int j = 0; j < ngw; ++j) {
+        DC_REQUIRE(gws[j], "dc_tag_linear_bwd_dw: null output block %d", j);
+        r.gw[j] = gws[j];
     }
     dw_plan(N, Fi, Fo, nseg, &p.chunk_rows, &p.nchunks);
     p.N = N, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg;
@@ -571,7 +601,8 @@ extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *ou
 #undef DC_DW
     r.partial = p.partial, r.bias_partial = p.bias_partial, r.gbias = gbias;
     r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = p.nchunks;
-    const int64_t total = (int64_t)nseg * Fo * Fi + (gbias ? Fo : 0);
+    r.cols = gw_cols, r.ngw = ngw, r.bps = ngw / nseg, r.accumulate = accumulate;
+    const int64_t total = (int64_t)ngw * Fo * gw_cols + (gbias ? Fo : 0);
     hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, r);
     return check_launch("dc_tag_linear_bwd_dw");

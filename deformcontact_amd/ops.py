@@ -82,6 +82,19 @@ def _i64_array(vals):
 
 MAX_SEG = 4   # DC_MAX_SEG in include/deformcontact.h
 
+#: Accumulate weight / bias gradients straight into ``param.grad`` inside the dW slab-reduce
+#: kernel when every parameter of the layer already has a dense fp32 ``.grad`` (e.g. the views of
+#: ``dp.GradBucket``), instead of returning them to autograd (which would run one elementwise
+#: ``add`` kernel per parameter).  Tensor hooks on those parameters do not fire in that mode;
+#: set to False to get stock autograd behaviour.
+DIRECT_PARAM_GRAD = True
+
+
+def _grad_sink(p) -> bool:
+    g = getattr(p, "grad", None)
+    return (g is not None and g.dtype == torch.float32 and g.is_contiguous()
+            and g.device == p.device and g.shape == p.shape)
+
 
 class _TagConvFn(torch.autograd.Function):
     """Whole TAGConv layer (+ optional fused ReLU): K hops into one ``[N, (K+1)*Fi]`` slab, then
@@ -132,6 +145,7 @@ class _TagConvFn(torch.autograd.Function):
         _lib.check(rc, "dc_tag_linear_fwd")
         ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu, ctx.concat = \
             g, k, fi, fo, bias is not None, relu, concat
+        ctx.params, ctx.bias_param = weights, bias       # the Parameter objects themselves
         ctx.save_for_backward(slab, out if relu else None, *ws)
         return out
 
@@ -157,19 +171,26 @@ class _TagConvFn(torch.autograd.Function):
         gws: List[Optional[torch.Tensor]] = [None] * (k + 1)
         gb = None
         if need_w or need_b:
-            gw_all = torch.empty((nseg, fo, fi_eff), dtype=torch.float32, device=dev)
-            gb = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
+            # one output block per lins[k].weight, in either layout of the dense block
+            direct = (DIRECT_PARAM_GRAD and not torch.is_grad_enabled()
+                      and all(_grad_sink(p) for p in ctx.params)
+                      and (not ctx.has_bias or _grad_sink(ctx.bias_param)))
+            if direct:
+                outs = [p.grad for p in ctx.params]
+                gb_out = ctx.bias_param.grad if ctx.has_bias else None
+            else:
+                outs = [torch.empty((fo, fi), dtype=torch.float32, device=dev) for _ in range(k + 1)]
+                gb_out = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
             nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi_eff, fo, nseg)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             rc = L.dc_tag_linear_bwd_dw(
                 gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(xs), _i64_array(ldxs), nseg,
-                _ptr_array([gw_all[j] for j in range(nseg)]),
-                gb.data_ptr() if gb is not None else None, scratch.data_ptr(), nbytes, n, fi_eff,
-                fo, st)
+                _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
+                int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo, st)
             _lib.check(rc, "dc_tag_linear_bwd_dw")
-            for j in range(k + 1):
-                if ctx.needs_input_grad[4 + j]:
-                    gws[j] = gw_all[0][:, j * fi:(j + 1) * fi] if concat else gw_all[j]
+            if not direct:
+                gws = [outs[j] if ctx.needs_input_grad[4 + j] else None for j in range(k + 1)]
+                gb = gb_out
 
         gx = None
         if need_x:

@@ -116,17 +116,22 @@ int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *out_for_mask,
                          const int64_t *ldgxs, int64_t N, int64_t Fi, int64_t Fo,
                          dc_stream_t stream);
 
-/* dW-side: gws[s][Fo,Fi] = g^T[Fo,N] . xs[s][N,Fi] (same optional ReLU mask),
- * gbias[Fo] = column sums of g (NULL to skip).  `partials` is a caller-owned
- * scratch of dc_tag_linear_bwd_dw_workspace_bytes() bytes (split-N partial
- * slabs, summed in chunk order by a second kernel: deterministic, no float
+/* dW-side: (g*relu')^T[Fo,N] . xs[s][N,Fi] (same optional ReLU mask), gbias[Fo] = column
+ * sums of g*relu' (NULL to skip).  The result is delivered as `ngw` output blocks (ngw a
+ * multiple of nseg): block j = columns [(j % bps)*gw_cols, +gw_cols) of segment j / bps,
+ * bps = ngw / nseg, written to gws[j] as a contiguous [Fo, gw_cols] matrix - i.e. one block
+ * per PyG `lins[k].weight` whether the layer ran as K+1 segments (ngw = nseg, gw_cols = Fi)
+ * or as one concatenated segment (nseg = 1, ngw = K+1, gw_cols = F_in).  accumulate != 0 adds
+ * into gws / gbias (fused gradient accumulation) instead of overwriting.
+ * `partials` is a caller-owned scratch of dc_tag_linear_bwd_dw_workspace_bytes() bytes
+ * (split-N partial slabs, summed in chunk order by a second kernel: deterministic, no float
  * atomics). */
 int64_t dc_tag_linear_bwd_dw_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo, int nseg);
 int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
                          const float *const *xs, const int64_t *ldxs, int nseg,
-                         float *const *gws, float *gbias, void *partials,
-                         int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
-                         dc_stream_t stream);
+                         float *const *gws, int ngw, int64_t gw_cols, float *gbias,
+                         int accumulate, void *partials, int64_t partials_bytes, int64_t N,
+                         int64_t Fi, int64_t Fo, dc_stream_t stream);
 
 /* pos_of[perm[p]] = p  (inverse permutation over the E' = *ptr_last sorted edges) */
 int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last /* &ptr[N] */, int32_t *pos_of,

@@ -186,8 +186,8 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu):
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     mask = out.data_ptr() if relu else None
     _lib.check(L.dc_tag_linear_bwd_dw(g.data_ptr(), fo, mask, fo, _ptr_array(xs), _i64_array(ld), nseg,
-                                      _ptr_array(gws), gb.data_ptr(), scratch.data_ptr(), nbytes, n, fi,
-                                      fo, st), "dw")
+                                      _ptr_array(gws), nseg, fi, gb.data_ptr(), 0, scratch.data_ptr(), nbytes,
+                                      n, fi, fo, st), "dw")
     for s in range(nseg):
         assert rel_err(_np(gws[s]), (gm.t() @ xs[s].double().cpu()).numpy()) < 2e-6, s
     assert rel_err(_np(gb), gm.sum(0).numpy()) < 2e-6
@@ -390,3 +390,46 @@ def test_reference_style_usage_through_alias():
     finally:
         for k in ("torch_geometric", "torch_geometric.nn", "torch_geometric.data"):
             sys.modules.pop(k, None)
+
+
+@pytest.mark.parametrize("fi,fo", [(21, 256), (256, 256)])
+def test_direct_param_grad_accumulation_equals_autograd(fi, fo):
+    """ops.DIRECT_PARAM_GRAD: dW / bias gradients accumulated into existing .grad buffers by the
+    slab-reduce kernel must equal what autograd's AccumulateGrad produces."""
+    n, e = 150, 1100
+    ei = torch.from_numpy(random_multigraph(n, e, 17)).to(DEV)
+    x = torch.from_numpy(hashed_uniform((n, fi), 3, 2.0)).to(DEV).requires_grad_(True)
+    gup = torch.from_numpy(hashed_uniform((n, fo), 4, 2.0)).to(DEV)
+    conv = dc.nn.TAGConv(fi, fo).to(DEV)
+    with torch.no_grad():
+        conv.bias.copy_(torch.from_numpy(hashed_uniform((fo,), 5, 0.3)))
+
+    def run():
+        out = conv(x, ei, relu=True)
+        (out * gup).sum().backward()
+
+    run()                                                   # .grad is None -> autograd path
+    ref = {k: p.grad.clone() for k, p in conv.named_parameters()}
+    gx_ref = x.grad.clone()
+    for p in conv.parameters():
+        p.grad = torch.zeros_like(p)                        # dense buffers -> direct path
+    ptrs = {k: p.grad.data_ptr() for k, p in conv.named_parameters()}
+    x.grad = None
+    run()
+    for k, p in conv.named_parameters():
+        assert p.grad.data_ptr() == ptrs[k], "direct mode must write in place"
+        assert rel_err(_np(p.grad), _np(ref[k])) < 1e-6, k
+    assert torch.equal(x.grad, gx_ref)
+    x.grad = None
+    run()                                                   # accumulates: 2x
+    for k, p in conv.named_parameters():
+        assert rel_err(_np(p.grad), 2 * _np(ref[k])) < 1e-6, k
+    old = ops.DIRECT_PARAM_GRAD
+    try:
+        ops.DIRECT_PARAM_GRAD = False
+        x.grad = None
+        run()                                               # stock autograd accumulate: 3x
+        for k, p in conv.named_parameters():
+            assert rel_err(_np(p.grad), 3 * _np(ref[k])) < 1e-6, k
+    finally:
+        ops.DIRECT_PARAM_GRAD = old

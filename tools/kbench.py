@@ -66,7 +66,7 @@ def main():
             L.dc_tag_linear_bwd_dx(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld, n, fi, fo, st)
 
         def dw():
-            L.dc_tag_linear_bwd_dw(g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, gb.data_ptr(),
+            L.dc_tag_linear_bwd_dw(g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi, gb.data_ptr(), 0,
                                    scratch.data_ptr(), nbytes, n, fi, fo, st)
 
         for kn, fn in (("fwd", fwd), ("dX", dx), ("dW", dw)):
