@@ -422,6 +422,12 @@ static inline int pick_mb(int64_t rows, int64_t col_tiles) {
     return (((rows + 127) / 128) * col_tiles >= 512) ? 2 : 1;
 }
 
+static inline int split_mb(int64_t rows, int64_t col_tiles) {
+    static const int forced = env_int("DC_SPLIT_MB", 0);
+    if (forced == 1 || forced == 2) return forced;
+    return (((rows + 127) / 128) * col_tiles >= 256) ? 2 : 1;
+}
+
 static inline bool use_fast() {
     static const int v = env_int("DC_DENSE_FAST", 1);
     return v != 0;
@@ -452,10 +458,9 @@ static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_
 
 using namespace dc;
 
-extern "C" int dc_tag_linear_fwd(const float *const *xs, const int64_t *ldxs,
-                                 const float *const *ws, int nseg, const float *bias, int relu,
-                                 float *out, int64_t ldo, int64_t N, int64_t Fi, int64_t Fo,
-                                 dc_stream_t stream) {
+static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *const *ws, int nseg,
+                    const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t Fi,
+                    int64_t Fo, dc_stream_t stream, bool split) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_fwd: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_fwd: bad sizes");
     if (N == 0) return DC_OK;
@@ -475,6 +480,8 @@ extern "C" int dc_tag_linear_fwd(const float *const *xs, const int64_t *ldxs,
     DC_REQUIRE(grid < (int64_t)INT32_MAX, "dc_tag_linear_fwd: grid too large");
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
+    if (split && vec && fwd_split_launch(p, split_mb(N, ntn), hs))
+        return check_launch("dc_tag_linear_fwd_split");
     if (use_fast() && vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
     if (mb == 2 && vec)
         hipLaunchKernelGGL((k_tag_linear_fwd<2, true>), gd, bd, 0, hs, p);
@@ -487,10 +494,9 @@ extern "C" int dc_tag_linear_fwd(const float *const *xs, const int64_t *ldxs,
     return check_launch("dc_tag_linear_fwd");
 }
 
-extern "C" int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *out_for_mask,
-                                    int64_t ldo, const float *const *ws, int nseg,
-                                    float *const *gxs, const int64_t *ldgxs, int64_t N, int64_t Fi,
-                                    int64_t Fo, dc_stream_t stream) {
+static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
+                   const float *const *ws, int nseg, float *const *gxs, const int64_t *ldgxs,
+                   int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream, float *split_ws) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dx: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dx: bad sizes");
     if (N == 0) return DC_OK;
@@ -515,6 +521,8 @@ extern "C" int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *ou
     if (!p.has_mask) p.mask = p.g;
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
+    if (split_ws && vec && dx_split_launch(p, split_ws, split_mb(N, ntn), hs))
+        return check_launch("dc_tag_linear_bwd_dx_split");
     if (use_fast() && vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
 #define DC_DX(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) {
@@ -530,6 +538,44 @@ extern "C" int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *ou
     }
 #undef DC_DX
     return check_launch("dc_tag_linear_bwd_dx");
+}
+
+extern "C" int dc_tag_linear_fwd(const float *const *xs, const int64_t *ldxs,
+                                 const float *const *ws, int nseg, const float *bias, int relu,
+                                 float *out, int64_t ldo, int64_t N, int64_t Fi, int64_t Fo,
+                                 dc_stream_t stream) {
+    return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, false);
+}
+
+extern "C" int dc_tag_linear_fwd_split(const float *const *xs, const int64_t *ldxs,
+                                       const float *const *ws, int nseg, const float *bias,
+                                       int relu, float *out, int64_t ldo, int64_t N, int64_t Fi,
+                                       int64_t Fo, dc_stream_t stream) {
+    return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, true);
+}
+
+extern "C" int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *out_for_mask,
+                                    int64_t ldo, const float *const *ws, int nseg,
+                                    float *const *gxs, const int64_t *ldgxs, int64_t N, int64_t Fi,
+                                    int64_t Fo, dc_stream_t stream) {
+    return dx_impl(g, ldg, out_for_mask, ldo, ws, nseg, gxs, ldgxs, N, Fi, Fo, stream, nullptr);
+}
+
+extern "C" int64_t dc_tag_linear_bwd_dx_split_workspace_bytes(int64_t Fi, int64_t Fo, int nseg) {
+    if (Fi < 1 || Fo < 1 || nseg < 1 || nseg > kMaxSeg) return DC_EINVAL;
+    return (int64_t)sizeof(float) * nseg * Fi * Fo + 16;
+}
+
+extern "C" int dc_tag_linear_bwd_dx_split(const float *g, int64_t ldg, const float *out_for_mask,
+                                          int64_t ldo, const float *const *ws, int nseg,
+                                          float *const *gxs, const int64_t *ldgxs, void *workspace,
+                                          int64_t workspace_bytes, int64_t N, int64_t Fi,
+                                          int64_t Fo, dc_stream_t stream) {
+    DC_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 &&
+                   workspace_bytes >= dc_tag_linear_bwd_dx_split_workspace_bytes(Fi, Fo, nseg),
+               "dc_tag_linear_bwd_dx_split: workspace missing, misaligned or too small");
+    return dx_impl(g, ldg, out_for_mask, ldo, ws, nseg, gxs, ldgxs, N, Fi, Fo, stream,
+                   (float *)workspace);
 }
 
 extern "C" int64_t dc_tag_linear_bwd_dw_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo,

@@ -1,0 +1,317 @@
+// dc_dense_split.hip -- fp32-accurate dense block on the bf16 matrix cores (gfx950).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  An fp32 operand is the exact sum
+// of three bf16 numbers, x = hi + mid + lo (8 + 8 + 8 significant bits, each remainder exactly
+// representable), and a bf16 x bf16 product is exact in the fp32 accumulator, so
+//
+//   a*b = hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid) + O(2^-24 |a*b|)
+//
+// i.e. SIX v_mfma_f32_32x32x16_bf16 reproduce the fp32 product to fp32 rounding level (simulated
+// error of the split: 6e-9 relative, below the 5e-7 of the fp32 accumulation itself) at
+// 16/6 = 2.7x the fp32 MFMA peak.  Range is not an issue (bf16 has the fp32 exponent).
+//
+// This file: the two dense kernels whose operands are both reduction-contiguous ("KC/KC"):
+//   fwd : out[N,Fo]    = act(sum_s xs[s][N,Fi] . ws[s][Fo,Fi]^T + b)
+//   dX  : gxs[s][N,Fi] = (g*relu')[N,Fo] . wt[s][Fi,Fo]^T      with wt[s] = ws[s]^T (tiny
+//                                                               transposes done per call)
+// fp32 stays the storage format everywhere: tiles are split into the three planes on their way
+// from registers into LDS (v_cvt_pk_bf16_f32 + exact subtractions), 112-byte LDS rows
+// (3 x 32 B planes + 16 B pad) keep both the b64 plane stores and the b128 fragment reads
+// conflict-free.  dW (both operands node-major) stays on the fp32 kernel.
+#include "dc_dense.h"
+
+namespace dc {
+
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int SROW = 112;                 // LDS bytes per operand row per stage
+constexpr int kPlane = 32;                // bytes per plane inside a row (16 bf16)
+
+__device__ __forceinline__ void split1(float x, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+    hi = (__bf16)x;
+    const float r = x - (float)hi;        // exact
+    mid = (__bf16)r;
+    const float r2 = r - (float)mid;      // exact
+    lo = (__bf16)r2;
+}
+
+__device__ __forceinline__ void split4(const float4 &v, bf16x4 &hi, bf16x4 &mid, bf16x4 &lo) {
+    __bf16 h, m, l;
+    split1(v.x, h, m, l); hi[0] = h, mid[0] = m, lo[0] = l;
+    split1(v.y, h, m, l); hi[1] = h, mid[1] = m, lo[1] = l;
+    split1(v.z, h, m, l); hi[2] = h, mid[2] = m, lo[2] = l;
+    split1(v.w, h, m, l); hi[3] = h, mid[3] = m, lo[3] = l;
+}
+
+// fp32 [rows][K] (k contiguous) operand: per-thread float4 pointers, split at LDS-store time
+template <int ROWS, bool MASK>
+struct SplitOp {
+    static constexpr int NV = ROWS / 64;
+    const float *p[NV];
+    const float *pm[MASK ? NV : 1];
+    float4 v[NV];
+    float4 m[MASK ? NV : 1];
+    int off[NV];                                     // LDS byte offsets of the hi plane
+
+    __device__ __forceinline__ void init(const float *base, const float *mbase, int64_t ld,
+                                         int64_t row0, int64_t nrows) {
+        const int k4 = threadIdx.x & 3, r = threadIdx.x >> 2;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            int64_t row = row0 + r + 64 * j;
+            row = row < nrows ? row : nrows - 1;
+            p[j] = base + row * ld + 4 * k4;
+            if (MASK) pm[j] = mbase + row * ld + 4 * k4;
+            off[j] = (r + 64 * j) * SROW + 8 * k4;
+        }
+    }
+    __device__ __forceinline__ void rebase(int64_t delta) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) p[j] += delta;
+    }
+    __device__ __forceinline__ void load() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = *reinterpret_cast<const float4 *>(p[j]);
+            p[j] += BK;
+            if (MASK) {
+                m[j] = *reinterpret_cast<const float4 *>(pm[j]);
+                pm[j] += BK;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char *lds) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 x = v[j];
+            if (MASK)
+                x = make_float4(m[j].x > 0.f ? x.x : 0.f, m[j].y > 0.f ? x.y : 0.f,
+                                m[j].z > 0.f ? x.z : 0.f, m[j].w > 0.f ? x.w : 0.f);
+            bf16x4 hi, mid, lo;
+            split4(x, hi, mid, lo);
+            *reinterpret_cast<bf16x4 *>(lds + off[j]) = hi;
+            *reinterpret_cast<bf16x4 *>(lds + off[j] + kPlane) = mid;
+            *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * kPlane) = lo;
+        }
+    }
+};
+
+template <int MB>
+struct SplitFrag {
+    bf16x8 a[MB][3];
+    bf16x8 b[2][3];
+};
+
+template <int MB>
+__device__ __forceinline__ void load_split_frag(SplitFrag<MB> &f, const char *As, const char *Bs,
+                                                int wm, int wn) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            f.a[mb][pl] = *reinterpret_cast<const bf16x8 *>(
+                As + (wm * 32 * MB + mb * 32 + r) * SROW + pl * kPlane + 16 * h);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            f.b[nb][pl] = *reinterpret_cast<const bf16x8 *>(
+                Bs + (wn * 64 + nb * 32 + r) * SROW + pl * kPlane + 16 * h);
+}
+
+// six products, smallest terms first
+template <int MB>
+__device__ __forceinline__ void mma_split(const SplitFrag<MB> &f, f32x16 (&acc)[MB][2]) {
+    constexpr int HI = 0, MID = 1, LO = 2;
+    constexpr int pa[6] = {LO, HI, MID, MID, HI, HI};
+    constexpr int pb[6] = {HI, LO, MID, HI, MID, HI};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mb][pa[t]], f.b[nb][pb[t]],
+                                                                      acc[mb][nb], 0, 0, 0);
+}
+
+template <int MB, typename OA, typename OB, typename Next>
+__device__ __forceinline__ void split_loop(char *lds, int nst, OA &A, OB &B, Next &&next_stage,
+                                           f32x16 (&acc)[MB][2], int wm, int wn) {
+    constexpr int BM = 64 * MB, kOffB = BM * SROW, kStage = (BM + BN) * SROW;
+    if (nst <= 0) return;
+    A.load();
+    B.load();
+    next_stage();
+    A.store(lds);
+    B.store(lds + kOffB);
+    if (nst > 1) {
+        A.load();
+        B.load();
+        next_stage();
+    }
+    __syncthreads();
+    for (int it = 0; it < nst; ++it) {
+        char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
+        SplitFrag<MB> f;
+        load_split_frag<MB>(f, cur, cur + kOffB, wm, wn);
+        if (it + 1 < nst) {
+            A.store(nxt);
+            B.store(nxt + kOffB);
+        }
+        if (it + 2 < nst) {
+            A.load();
+            B.load();
+            next_stage();
+        }
+        mma_split<MB>(f, acc);
+        __syncthreads();
+    }
+}
+
+// ------------------------------- forward -------------------------------------------
+template <int MB>
+__global__ void __launch_bounds__(256)
+k_fwd_split(FwdParams p) {
+    constexpr int BM = 64 * MB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * SROW];
+    const unsigned ntn = (unsigned)((p.Fo + BN - 1) / BN);
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = (int64_t)(lb / ntn) * BM, col0 = (int64_t)(lb % ntn) * BN;
+    const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
+
+    f32x16 acc[MB][2];
+    zero_acc<MB>(acc);
+    SplitOp<BM, false> A;
+    SplitOp<BN, false> B;
+    A.init(p.x[0].p, nullptr, p.x[0].ld, row0, p.N);
+    B.init(p.w[0].p, nullptr, p.Fi, col0, p.Fo);
+    const int kst = (int)(p.Fi / BK), nst = kst * p.nseg;
+    int kk = 0, seg = 0;
+    auto next_stage = [&]() {
+        if (++kk == kst && seg + 1 < p.nseg) {
+            kk = 0;
+            A.rebase((p.x[seg + 1].p - p.x[seg].p) - p.Fi);
+            B.rebase((p.w[seg + 1].p - p.w[seg].p) - p.Fi);
+            ++seg;
+        }
+    };
+    split_loop<MB>(lds, nst, A, B, next_stage, acc, wm, wn);
+
+    float bcol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int64_t col = col0 + wn * 64 + nb * 32 + (threadIdx.x & 31);
+        bcol[nb] = (p.bias && col < p.Fo) ? p.bias[col] : 0.f;
+    }
+    const bool relu = p.relu != 0;
+    for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
+        const int64_t row = row0 + r, col = col0 + c;
+        if (row < p.N && col < p.Fo) {
+            v += bcol[(c >> 5) & 1];
+            if (relu) v = fmaxf(v, 0.f);
+            p.out[row * p.ldo + col] = v;
+        }
+    });
+}
+
+// ------------------------------- backward: dX --------------------------------------
+// p.w[s] here are the TRANSPOSED weights wt[s] [Fi, Fo] (ld = Fo)
+template <int MB, bool MASK>
+__global__ void __launch_bounds__(256)
+k_dx_split(DxParams p) {
+    constexpr int BM = 64 * MB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * SROW];
+    const unsigned ntn = (unsigned)((p.Fi + BN - 1) / BN), per_row = ntn * p.nseg;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = (int64_t)(lb / per_row) * BM;
+    const int s = (int)((lb % per_row) / ntn);
+    const int64_t col0 = (int64_t)(lb % ntn) * BN;
+    const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
+
+    f32x16 acc[MB][2];
+    zero_acc<MB>(acc);
+    SplitOp<BM, MASK> A;
+    SplitOp<BN, false> B;
+    A.init(p.g.p, p.mask.p, p.g.ld, row0, p.N);
+    B.init(p.w[s].p, nullptr, p.Fo, col0, p.Fi);
+    split_loop<MB>(lds, (int)(p.Fo / BK), A, B, []() {}, acc, wm, wn);
+    float *out = p.gx[s];
+    const int64_t ldo = p.ldgx[s];
+    for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
+        const int64_t row = row0 + r, col = col0 + c;
+        if (row < p.N && col < p.Fi) out[row * ldo + col] = v;
+    });
+}
+
+// wt[s][f][o] = w[s][o][f] for up to kMaxSeg segments in one launch (32x32 LDS tiles)
+struct TransposeParams {
+    const float *w[kMaxSeg];
+    float *wt;
+    int64_t Fi, Fo;
+    int nseg;
+};
+
+__global__ void __launch_bounds__(256)
+k_transpose_w(TransposeParams p) {
+    __shared__ float tile[32][33];
+    const int64_t tf = (p.Fi + 31) / 32, to = (p.Fo + 31) / 32;
+    const int64_t b = blockIdx.x;
+    const int s = (int)(b / (tf * to));
+    const int64_t o0 = ((b % (tf * to)) / tf) * 32, f0 = (b % tf) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t o = o0 + i, f = f0 + tx;
+        tile[i][tx] = (o < p.Fo && f < p.Fi) ? p.w[s][o * p.Fi + f] : 0.f;
+    }
+    __syncthreads();
+    float *dst = p.wt + (int64_t)s * p.Fi * p.Fo;
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t f = f0 + i, o = o0 + tx;
+        if (f < p.Fi && o < p.Fo) dst[f * p.Fo + o] = tile[tx][i];
+    }
+}
+
+static inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
+
+bool fwd_split_launch(const FwdParams &p, int mb, hipStream_t hs) {
+    if (p.Fi % BK != 0 || p.Fi < BK) return false;
+    for (int s = 0; s < p.nseg; ++s)
+        if (!al16(p.x[s].p) || !al16(p.w[s].p) || p.x[s].ld % 4 != 0 || p.x[s].ld != p.x[0].ld)
+            return false;
+    const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
+    const dim3 gd((unsigned)grid), bd(256);
+    if (mb == 2)
+        hipLaunchKernelGGL((k_fwd_split<2>), gd, bd, 0, hs, p);
+    else
+        hipLaunchKernelGGL((k_fwd_split<1>), gd, bd, 0, hs, p);
+    return true;
+}
+
+bool dx_split_eligible(const DxParams &p) {
+    if (p.Fo % BK != 0 || p.Fo < BK || p.Fi % 4 != 0 || !al16(p.g.p) || p.g.ld % 4 != 0) return false;
+    if (p.has_mask && (!al16(p.mask.p) || p.mask.ld != p.g.ld)) return false;
+    return true;
+}
+
+// `p.w[s]` = original weights [Fo,Fi]; `wt` = workspace of nseg*Fi*Fo floats (16-B aligned)
+bool dx_split_launch(DxParams p, float *wt, int mb, hipStream_t hs) {
+    if (!dx_split_eligible(p) || !al16(wt)) return false;
+    TransposeParams t{};
+    for (int s = 0; s < p.nseg; ++s) t.w[s] = p.w[s].p;
+    t.wt = wt, t.Fi = p.Fi, t.Fo = p.Fo, t.nseg = p.nseg;
+    const int64_t tiles = ((p.Fi + 31) / 32) * ((p.Fo + 31) / 32) * p.nseg;
+    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)tiles), dim3(256), 0, hs, t);
+    for (int s = 0; s < p.nseg; ++s) p.w[s] = Mat{wt + (int64_t)s * p.Fi * p.Fo, p.Fo};
+    const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN) * p.nseg;
+    const dim3 gd((unsigned)grid), bd(256);
+#define DC_L(MB_, M_) hipLaunchKernelGGL((k_dx_split<MB_, M_>), gd, bd, 0, hs, p)
+    if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
+    else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
+#undef DC_L
+    return true;
+}
+
+}  // namespace dc

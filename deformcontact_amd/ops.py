@@ -9,6 +9,7 @@ dense GEMMs.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -90,6 +91,14 @@ MAX_SEG = 4   # DC_MAX_SEG in include/deformcontact.h
 DIRECT_PARAM_GRAD = True
 
 
+#: Run the forward and dX dense blocks on the bf16 matrix cores with every fp32 operand split
+#: exactly into hi + mid + lo bf16 terms and six MFMA products (``dc_tag_linear_*_split``):
+#: fp32-accurate (measured error vs float64 equal to the fp32-MFMA / rocBLAS kernels,
+#: profiles/r01/d_split_accuracy.txt) at up to 2.7x the fp32 MFMA peak.  ``DC_DENSE_SPLIT=0``
+#: (or setting this to False) keeps everything on ``v_mfma_f32_32x32x2_f32``.
+DENSE_SPLIT_BF16 = os.environ.get("DC_DENSE_SPLIT", "1") != "0"
+
+
 def _grad_sink(p) -> bool:
     g = getattr(p, "grad", None)
     return (g is not None and g.dtype == torch.float32 and g.is_contiguous()
@@ -138,7 +147,9 @@ class _TagConvFn(torch.autograd.Function):
             xs, ldxs, fi_eff = blocks, [wpad] * (k + 1), fi
         out = torch.empty((n, fo), dtype=torch.float32, device=dev)
         b = bias.contiguous() if bias is not None else None
-        rc = _lib.lib().dc_tag_linear_fwd(
+        L = _lib.lib()
+        fwd = L.dc_tag_linear_fwd_split if DENSE_SPLIT_BF16 else L.dc_tag_linear_fwd
+        rc = fwd(
             _ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
             b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), fo, n, fi_eff, fo,
             current_stream_ptr(dev))
@@ -197,8 +208,15 @@ class _TagConvFn(torch.autograd.Function):
             gslab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
             gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
             gxs = [gslab] if concat else gblocks
-            rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws), nseg,
-                                        _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
+            if DENSE_SPLIT_BF16:
+                wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi_eff, fo, nseg)
+                wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                rc = L.dc_tag_linear_bwd_dx_split(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws),
+                                                  nseg, _ptr_array(gxs), _i64_array(ldxs),
+                                                  wsx.data_ptr(), wsb, n, fi_eff, fo, st)
+            else:
+                rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws), nseg,
+                                            _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
             _lib.check(rc, "dc_tag_linear_bwd_dx")
             for j in range(k, 0, -1):                   # g_{j-1} = G_{j-1} + A^T g_j
                 hop(g.bwd, gblocks[j], out=gblocks[j - 1], addend=gblocks[j - 1],

@@ -154,7 +154,8 @@ def test_empty_graph_and_isolated_nodes():
 @pytest.mark.parametrize("n,fi,fo,nseg,relu", [
     (1, 21, 256, 4, True), (63, 25, 256, 4, False), (65, 32, 32, 4, True), (200, 256, 256, 4, True),
     (130, 256, 130, 2, False), (64, 16, 3, 1, True), (257, 84, 260, 3, True), (1000, 256, 256, 1, False)])
-def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu):
+@pytest.mark.parametrize("split", [False, True])
+def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu, split):
     import ctypes
     from deformcontact_amd import _lib
     from deformcontact_amd.graph import current_stream_ptr
@@ -167,8 +168,9 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu):
     bias = torch.from_numpy(hashed_uniform((fo,), 77, 0.5)).to(DEV)
     out = torch.empty(n, fo, device=DEV)
     st = current_stream_ptr(torch.device(DEV))
-    _lib.check(L.dc_tag_linear_fwd(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
-                                   int(relu), out.data_ptr(), fo, n, fi, fo, st), "fwd")
+    fwd = L.dc_tag_linear_fwd_split if split else L.dc_tag_linear_fwd
+    _lib.check(fwd(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
+                   int(relu), out.data_ptr(), fo, n, fi, fo, st), "fwd")
     ref = sum(xs[s].double().cpu() @ ws[s].double().cpu().t() for s in range(nseg)) + bias.double().cpu()
     pre = ref.clone()
     if relu:
@@ -193,8 +195,15 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu):
     assert rel_err(_np(gb), gm.sum(0).numpy()) < 2e-6
     gslab = torch.zeros(n, nseg * fi, device=DEV)
     gxs = [gslab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
-    _lib.check(L.dc_tag_linear_bwd_dx(g.data_ptr(), fo, mask, fo, _ptr_array(ws), nseg, _ptr_array(gxs),
-                                      _i64_array(ld), n, fi, fo, st), "dx")
+    if split:
+        wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi, fo, nseg)
+        wsx = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        _lib.check(L.dc_tag_linear_bwd_dx_split(g.data_ptr(), fo, mask, fo, _ptr_array(ws), nseg,
+                                                _ptr_array(gxs), _i64_array(ld), wsx.data_ptr(), wsb,
+                                                n, fi, fo, st), "dx_split")
+    else:
+        _lib.check(L.dc_tag_linear_bwd_dx(g.data_ptr(), fo, mask, fo, _ptr_array(ws), nseg, _ptr_array(gxs),
+                                          _i64_array(ld), n, fi, fo, st), "dx")
     for s in range(nseg):
         assert rel_err(_np(gxs[s]), (gm @ ws[s].double().cpu()).numpy()) < 2e-6, s
 
