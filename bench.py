@@ -205,8 +205,8 @@ def main():
         "value": round(value, 3), "unit": "M edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dense_arithmetic": ("fp32 storage and accumulate; fwd/dX products as exact 3-way bf16 splits "
-                             "(6 bf16 MFMAs, fp32-accurate), dW on fp32 MFMA") if ops.DENSE_SPLIT_BF16
+        "dense_arithmetic": ("fp32 storage and accumulate; dense products as exact 3-way bf16 splits "
+                             "(6 bf16 MFMAs per product tile, fp32-accurate)") if ops.DENSE_SPLIT_BF16
         else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
         "config": {
             "workload": f"everyday-deform synthetic, B={args.batch} sample pairs per GPU: soft "

@@ -40,6 +40,10 @@ _SIGNATURES = {
     "dc_tag_linear_bwd_dw": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp), POINTER(c_int64),
                                      c_int, POINTER(_vp), c_int, c_int64, _vp, c_int, _vp, c_int64,
                                      c_int64, c_int64, c_int64, _vp]),
+    "dc_tag_linear_bwd_dw_split": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp),
+                                           POINTER(c_int64), c_int, POINTER(_vp), c_int, c_int64,
+                                           _vp, c_int, _vp, c_int64, c_int64, c_int64, c_int64,
+                                           _vp]),
     "dc_compose_perm": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp]),
     "dc_gat_edge_softmax_fwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, c_int64, _vp]),
     "dc_gat_edge_softmax_bwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, _vp, _vp, _vp, c_int64,

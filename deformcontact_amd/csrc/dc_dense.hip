@@ -561,6 +561,19 @@ extern "C" int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *ou
     return dx_impl(g, ldg, out_for_mask, ldo, ws, nseg, gxs, ldgxs, N, Fi, Fo, stream, nullptr);
 }
 
+extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask,
+                                    int64_t ldo, const float *const *xs, const int64_t *ldxs,
+                                    int nseg, float *const *gws, int ngw, int64_t gw_cols,
+                                    float *gbias, int accumulate, void *partials,
+                                    int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                                    dc_stream_t stream);
+extern "C" int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const float *out_for_mask,
+                                          int64_t ldo, const float *const *xs, const int64_t *ldxs,
+                                          int nseg, float *const *gws, int ngw, int64_t gw_cols,
+                                          float *gbias, int accumulate, void *partials,
+                                          int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                                          dc_stream_t stream);
+
 extern "C" int64_t dc_tag_linear_bwd_dx_split_workspace_bytes(int64_t Fi, int64_t Fo, int nseg) {
     if (Fi < 1 || Fo < 1 || nseg < 1 || nseg > kMaxSeg) return DC_EINVAL;
     return (int64_t)sizeof(float) * nseg * Fi * Fo + 16;
@@ -587,12 +600,11 @@ extern "C" int64_t dc_tag_linear_bwd_dw_workspace_bytes(int64_t N, int64_t Fi, i
     return (int64_t)sizeof(float) * nchunks * (nseg * Fo * Fi + Fo) + 16;
 }
 
-extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask,
-                                    int64_t ldo, const float *const *xs, const int64_t *ldxs,
-                                    int nseg, float *const *gws, int ngw, int64_t gw_cols,
-                                    float *gbias, int accumulate, void *partials,
-                                    int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
-                                    dc_stream_t stream) {
+static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
+                   const float *const *xs, const int64_t *ldxs, int nseg, float *const *gws, int ngw,
+                   int64_t gw_cols, float *gbias, int accumulate, void *partials,
+                   int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream,
+                   bool split) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dw: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dw: bad sizes");
     DC_REQUIRE(g && xs && ldxs && gws && partials && ldg >= Fo,
@@ -629,7 +641,8 @@ extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *ou
     if (!p.has_mask) p.mask = p.g;
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
-    bool fast_done = use_fast() && vec && dw_fast_launch(p, mb, hs);
+    bool fast_done = (split && vec && dw_split_launch(p, mb, hs)) ||
+                     (use_fast() && vec && dw_fast_launch(p, mb, hs));
 #define DC_DW(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (fast_done) {
     } else
@@ -652,4 +665,24 @@ extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *ou
     hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, r);
     return check_launch("dc_tag_linear_bwd_dw");
+}
+
+extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask,
+                                    int64_t ldo, const float *const *xs, const int64_t *ldxs,
+                                    int nseg, float *const *gws, int ngw, int64_t gw_cols,
+                                    float *gbias, int accumulate, void *partials,
+                                    int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                                    dc_stream_t stream) {
+    return dw_impl(g, ldg, out_for_mask, ldo, xs, ldxs, nseg, gws, ngw, gw_cols, gbias, accumulate,
+                   partials, partials_bytes, N, Fi, Fo, stream, false);
+}
+
+extern "C" int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const float *out_for_mask,
+                                          int64_t ldo, const float *const *xs, const int64_t *ldxs,
+                                          int nseg, float *const *gws, int ngw, int64_t gw_cols,
+                                          float *gbias, int accumulate, void *partials,
+                                          int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                                          dc_stream_t stream) {
+    return dw_impl(g, ldg, out_for_mask, ldo, xs, ldxs, nseg, gws, ngw, gw_cols, gbias, accumulate,
+                   partials, partials_bytes, N, Fi, Fo, stream, true);
 }

@@ -246,6 +246,188 @@ k_dx_split(DxParams p) {
     });
 }
 
+// ------------------------------- backward: dW --------------------------------------
+// Both operands are node-major ([n][o] and [n][f], the reduction index n is the SLOW one), so
+// the split planes are kept as [k][m] images (k = node within the stage) and the MFMA operands
+// (8 consecutive k for one m per lane) come out of gfx950's transposing LDS read
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of (row q, columns
+// 4p..4p+3) of a 4 x 16 block and lane i receives column i of the 4 rows.  Rows are padded by
+// 64 B so the four rows of a block land on disjoint bank quarters.
+template <int COLS> struct TrImage {
+    static constexpr int ROWB = COLS * 2 + 64;          // bytes per k row of one plane
+    static constexpr int PLANE = BK * ROWB;             // bytes per plane
+    static constexpr int BYTES = 3 * PLANE;
+};
+
+// fp32 [K][cols] (col contiguous) operand tile BK x COLS: split at LDS-store time into 3 images
+template <int COLS, bool MASK>
+struct SplitOpRC {
+    static constexpr int NV = COLS / 64;
+    static constexpr int PER = COLS / 4, KPER = 256 / PER;
+    using Img = TrImage<COLS>;
+    const float *p[NV];
+    const float *pm[MASK ? NV : 1];
+    float4 v[NV];
+    float4 m[MASK ? NV : 1];
+    int off[NV];
+    int64_t step;
+
+    __device__ __forceinline__ void init(const float *base, const float *mbase, int64_t ld,
+                                         int64_t k0, int64_t col0, int64_t ncols) {
+        const int c4 = threadIdx.x % PER, kr = threadIdx.x / PER;
+        int64_t col = col0 + 4 * c4;
+        col = col + 4 <= ncols ? col : ncols - 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int64_t k = k0 + kr + KPER * j;
+            p[j] = base + k * ld + col;
+            if (MASK) pm[j] = mbase + k * ld + col;
+            off[j] = (kr + KPER * j) * Img::ROWB + 8 * c4;
+        }
+        step = BK * ld;
+    }
+    __device__ __forceinline__ void load() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = *reinterpret_cast<const float4 *>(p[j]);
+            p[j] += step;
+            if (MASK) {
+                m[j] = *reinterpret_cast<const float4 *>(pm[j]);
+                pm[j] += step;
+            }
+        }
+    }
+    __device__ __forceinline__ float4 value(int j) const {
+        if (!MASK) return v[j];
+        return make_float4(m[j].x > 0.f ? v[j].x : 0.f, m[j].y > 0.f ? v[j].y : 0.f,
+                           m[j].z > 0.f ? v[j].z : 0.f, m[j].w > 0.f ? v[j].w : 0.f);
+    }
+    __device__ __forceinline__ void store(char *lds) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            bf16x4 hi, mid, lo;
+            split4(value(j), hi, mid, lo);
+            *reinterpret_cast<bf16x4 *>(lds + off[j]) = hi;
+            *reinterpret_cast<bf16x4 *>(lds + off[j] + Img::PLANE) = mid;
+            *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * Img::PLANE) = lo;
+        }
+    }
+};
+
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// one MFMA operand (8 consecutive k for column m0 + (lane & 31)) from a [k][m] plane image
+template <int COLS>
+__device__ __forceinline__ bf16x8 tr_operand(const char *plane, int m0) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int h = g >> 1;
+    const char *a = plane + (8 * h + q) * TrImage<COLS>::ROWB + (m0 + 16 * (g & 1) + 4 * pp) * 2;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(a));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s16x4 *)(uintptr_t)(a + 4 * TrImage<COLS>::ROWB));
+    union { s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo4, u.s[1] = hi4;
+    return u.b;
+}
+
+template <int MB, bool MASK>
+__global__ void __launch_bounds__(256)
+k_dw_split(DwParams p) {
+    constexpr int BM = 64 * MB;
+    using IA = TrImage<BM>;
+    using IB = TrImage<BN>;
+    constexpr int kStage = IA::BYTES + IB::BYTES, kOffB = IA::BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
+    const unsigned ntm = (unsigned)((p.Fo + BM - 1) / BM), ntn = (unsigned)((p.Fi + BN - 1) / BN);
+    const unsigned tiles = ntm * ntn, per_chunk = tiles * p.nseg;
+    const unsigned lb = blockIdx.x;
+    const unsigned chunk = lb / per_chunk, rem = lb % per_chunk;
+    const int s = (int)(rem / tiles);
+    const int64_t o0 = (int64_t)((rem % tiles) / ntn) * BM, f0 = (int64_t)((rem % tiles) % ntn) * BN;
+    const int64_t n_beg = (int64_t)chunk * p.chunk_rows;
+    const int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
+    const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
+    const bool do_bias = p.bias_partial && s == 0 && f0 == 0;
+
+    f32x16 acc[MB][2];
+    zero_acc<MB>(acc);
+    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    using OA = SplitOpRC<BM, MASK>;
+    OA A;
+    SplitOpRC<BN, false> B;
+    A.init(p.g.p, p.mask.p, p.g.ld, n_beg, o0, p.Fo);
+    B.init(p.x[s].p, nullptr, p.x[s].ld, n_beg, f0, p.Fi);
+    auto bias_acc = [&]() {
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < OA::NV; ++j) {
+                const float4 x = A.value(j);
+                bsum4.x += x.x, bsum4.y += x.y, bsum4.z += x.z, bsum4.w += x.w;
+            }
+        }
+    };
+    const int nst = (int)((n_end - n_beg) / BK);
+    if (nst > 0) {
+        A.load();
+        B.load();
+        A.store(lds);
+        B.store(lds + kOffB);
+        bias_acc();
+        if (nst > 1) {
+            A.load();
+            B.load();
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < nst; ++it) {
+        const char *cur = lds + (it & 1) * kStage;
+        char *nxt = lds + ((it + 1) & 1) * kStage;
+        SplitFrag<MB> f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                f.a[mb][pl] = tr_operand<BM>(cur + pl * IA::PLANE, wm * 32 * MB + mb * 32);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                f.b[nb][pl] = tr_operand<BN>(cur + kOffB + pl * IB::PLANE, wn * 64 + nb * 32);
+        }
+        if (it + 1 < nst) {
+            A.store(nxt);
+            B.store(nxt + kOffB);
+            bias_acc();
+        }
+        if (it + 2 < nst) {
+            A.load();
+            B.load();
+        }
+        mma_split<MB>(f, acc);
+        __syncthreads();
+    }
+    float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
+    for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
+        const int64_t o = o0 + r, ff = f0 + c;
+        if (o < p.Fo && ff < p.Fi) out[o * p.Fi + ff] = v;
+    });
+    if (do_bias) {
+        __syncthreads();
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[threadIdx.x] = bsum4;
+        __syncthreads();
+        if (threadIdx.x < OA::PER) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < 256 / OA::PER; ++g) {
+                const float4 v = red[g * OA::PER + threadIdx.x];
+                t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+            }
+            float *bp = p.bias_partial + (int64_t)chunk * p.Fo;
+            const int64_t o = o0 + 4 * threadIdx.x;
+            if (o + 4 <= p.Fo) bp[o + 0] = t.x, bp[o + 1] = t.y, bp[o + 2] = t.z, bp[o + 3] = t.w;
+        }
+    }
+}
+
 // wt[s][f][o] = w[s][o][f] for up to kMaxSeg segments in one launch (32x32 LDS tiles)
 struct TransposeParams {
     const float *w[kMaxSeg];
@@ -308,6 +490,22 @@ bool dx_split_launch(DxParams p, float *wt, int mb, hipStream_t hs) {
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN) * p.nseg;
     const dim3 gd((unsigned)grid), bd(256);
 #define DC_L(MB_, M_) hipLaunchKernelGGL((k_dx_split<MB_, M_>), gd, bd, 0, hs, p)
+    if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
+    else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
+#undef DC_L
+    return true;
+}
+
+bool dw_split_launch(const DwParams &p, int mb, hipStream_t hs) {
+    if (p.N % BK != 0 || p.chunk_rows % BK != 0 || p.Fi % 4 != 0 || p.Fo % 4 != 0 || p.Fi < 4 ||
+        p.Fo < 4 || !al16(p.g.p) || p.g.ld % 4 != 0)
+        return false;
+    if (p.has_mask && (!al16(p.mask.p) || p.mask.ld != p.g.ld)) return false;
+    for (int s = 0; s < p.nseg; ++s)
+        if (!al16(p.x[s].p) || p.x[s].ld % 4 != 0) return false;
+    const int64_t tiles = ((p.Fo + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN);
+    const dim3 gd((unsigned)(tiles * p.nseg * p.nchunks)), bd(256);
+#define DC_L(MB_, M_) hipLaunchKernelGGL((k_dw_split<MB_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
     else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
 #undef DC_L

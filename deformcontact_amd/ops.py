@@ -91,7 +91,7 @@ MAX_SEG = 4   # DC_MAX_SEG in include/deformcontact.h
 DIRECT_PARAM_GRAD = True
 
 
-#: Run the forward and dX dense blocks on the bf16 matrix cores with every fp32 operand split
+#: Run the dense blocks (forward, dX, dW) on the bf16 matrix cores with every fp32 operand split
 #: exactly into hi + mid + lo bf16 terms and six MFMA products (``dc_tag_linear_*_split``):
 #: fp32-accurate (measured error vs float64 equal to the fp32-MFMA / rocBLAS kernels,
 #: profiles/r01/d_split_accuracy.txt) at up to 2.7x the fp32 MFMA peak.  ``DC_DENSE_SPLIT=0``
@@ -194,7 +194,8 @@ class _TagConvFn(torch.autograd.Function):
                 gb_out = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
             nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi_eff, fo, nseg)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            rc = L.dc_tag_linear_bwd_dw(
+            dw = L.dc_tag_linear_bwd_dw_split if DENSE_SPLIT_BF16 else L.dc_tag_linear_bwd_dw
+            rc = dw(
                 gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(xs), _i64_array(ldxs), nseg,
                 _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
                 int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo, st)

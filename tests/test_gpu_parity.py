@@ -187,7 +187,8 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu, split):
     nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     mask = out.data_ptr() if relu else None
-    _lib.check(L.dc_tag_linear_bwd_dw(g.data_ptr(), fo, mask, fo, _ptr_array(xs), _i64_array(ld), nseg,
+    dw = L.dc_tag_linear_bwd_dw_split if split else L.dc_tag_linear_bwd_dw
+    _lib.check(dw(g.data_ptr(), fo, mask, fo, _ptr_array(xs), _i64_array(ld), nseg,
                                       _ptr_array(gws), nseg, fi, gb.data_ptr(), 0, scratch.data_ptr(), nbytes,
                                       n, fi, fo, st), "dw")
     for s in range(nseg):

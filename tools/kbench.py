@@ -79,7 +79,11 @@ def main():
             L.dc_tag_linear_bwd_dx_split(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld,
                                          wsx.data_ptr(), wsb, n, fi, fo, st)
 
-        for kn, fn in (("fwd", fwd), ("dX", dx), ("dW", dw), ("fwd6", fwd_s), ("dX6", dx_s)):
+        def dw_s():
+            L.dc_tag_linear_bwd_dw_split(g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
+                                         gb.data_ptr(), 0, scratch.data_ptr(), nbytes, n, fi, fo, st)
+
+        for kn, fn in (("fwd", fwd), ("dX", dx), ("dW", dw), ("fwd6", fwd_s), ("dX6", dx_s), ("dW6", dw_s)):
             ms = timeit(fn, args.reps)
             print(f"{name:13s} {kn:4s} N={n} Fi={fi}x{nseg} Fo={fo}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TF/s")
 
