@@ -45,12 +45,16 @@ class ContactEncoder(nn.Module):
             conv(a, b) for a, b in zip(widths_rig[:-1], widths_rig[1:]))
 
     def _branch(self, layers, x, edge_index):
-        for conv in layers:
+        drop = self.dropout_rate > 0.0 and self.training
+        for i, conv in enumerate(layers):
             if getattr(conv, "supports_fused_relu", False):
-                x = conv(x, edge_index, relu=True)        # ReLU in the MFMA epilogue
+                # ReLU in the MFMA epilogue; output written into the next layer's hop slab
+                nxt = layers[i + 1] if (i + 1 < len(layers) and not drop) else None
+                x = conv(x, edge_index, relu=True, next_conv=nxt)
             else:
                 x = F.relu(conv(x, edge_index))
-            x = F.dropout(x, p=self.dropout_rate, training=self.training)
+            if drop:
+                x = F.dropout(x, p=self.dropout_rate, training=True)
         return x
 
     #: run the soft and the rigid branch on two HIP streams (they are independent until the

@@ -81,12 +81,22 @@ class TAGConv(nn.Module):
 
     supports_fused_relu = True
 
-    def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False) -> Tensor:
-        """``conv(x, edge_index)`` as PyG; ``relu=True`` (extension) fuses the ReLU the
-        reference applies right after (``models/model.py:71,77``) into the MFMA epilogue."""
+    def slab_width(self) -> int:
+        return ops.tag_slab_geometry(self.in_channels, self.K)[2]
+
+    def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False,
+                next_conv: "Optional[TAGConv]" = None) -> Tensor:
+        """``conv(x, edge_index)`` as PyG.  Extensions: ``relu=True`` fuses the ReLU the reference
+        applies right after (``models/model.py:71,77``) into the MFMA epilogue; ``next_conv`` (the
+        TAGConv that consumes this output) lets the output be written straight into that
+        layer's hop slab."""
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
-        return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu)
+        nxt = 0
+        if isinstance(next_conv, TAGConv) and next_conv.in_channels == self.out_channels:
+            nxt = next_conv.slab_width()
+        return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu,
+                            next_wpad=nxt)
 
     def extra_repr(self) -> str:
         return f"{self.in_channels}, {self.out_channels}, K={self.K}"

@@ -105,6 +105,25 @@ def _grad_sink(p) -> bool:
             and g.device == p.device and g.shape == p.shape)
 
 
+def tag_slab_geometry(fi: int, k: int):
+    """(concat, width, padded width) of the ``[N, (K+1)*Fi]`` hop slab of a TAGConv layer."""
+    concat = (fi * (k + 1) <= 128) or (fi % 16 != 0)
+    width = (k + 1) * fi
+    wpad = (width + 15) // 16 * 16 if concat else width
+    return concat, width, wpad
+
+
+def _as_slab_block0(x: torch.Tensor, n: int, fi: int, wpad: int):
+    """If ``x`` already is column block 0 of a ``[n, wpad]`` buffer (the previous layer wrote
+    its output there), return that buffer; else None."""
+    base = x._base
+    if (base is not None and base.dim() == 2 and tuple(base.shape) == (n, wpad)
+            and base.is_contiguous() and x.stride() == (wpad, 1) and x.shape == (n, fi)
+            and x.data_ptr() == base.data_ptr() and base.dtype == torch.float32):
+        return base
+    return None
+
+
 class _TagConvFn(torch.autograd.Function):
     """Whole TAGConv layer (+ optional fused ReLU): K hops into one ``[N, (K+1)*Fi]`` slab, then
     ONE fp32-MFMA kernel for ``act(x W_0^T + sum_k (A^k x) W_k^T + b)`` - PyG ``tag_conv.py``
@@ -117,23 +136,23 @@ class _TagConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g: GraphIndex, x: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
-                *weights):
+                next_wpad: int, *weights):
         n, fi = x.shape
         k = len(weights) - 1
         fo = weights[0].size(0)
         if k + 1 > MAX_SEG:
             raise NotImplementedError(f"TAGConv K={k} > {MAX_SEG - 1} is not supported by the fused dense block")
         dev = x.device
-        concat = (fi * (k + 1) <= 128) or (fi % 16 != 0)
-        width = (k + 1) * fi
+        concat, width, wpad = tag_slab_geometry(fi, k)
         # narrow layers: one K segment over the whole slab, zero-padded to a multiple of 16 so
         # the lean MFMA path (aligned float4 loads, no K tail) applies (84 -> 96, 100 -> 112)
-        wpad = (width + 15) // 16 * 16 if concat else width
-        slab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
-        if wpad > width:
-            slab[:, width:].zero_()
+        slab = _as_slab_block0(x, n, fi, wpad)
+        if slab is None:
+            slab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
+            if wpad > width:
+                slab[:, width:].zero_()
+            slab[:, :fi].copy_(x)
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-        blocks[0].copy_(x)
         for j in range(k):
             hop(g.fwd, blocks[j], out=blocks[j + 1], weighted=g.normalize)
         if concat:
@@ -145,13 +164,19 @@ class _TagConvFn(torch.autograd.Function):
         else:
             ws = [w.contiguous() for w in weights]
             xs, ldxs, fi_eff = blocks, [wpad] * (k + 1), fi
-        out = torch.empty((n, fo), dtype=torch.float32, device=dev)
+        if next_wpad and next_wpad >= fo:
+            # the output IS column block 0 of the next TAGConv layer's hop slab (no copy there)
+            nxt = torch.empty((n, next_wpad), dtype=torch.float32, device=dev)
+            out = nxt[:, :fo]
+        else:
+            out = torch.empty((n, fo), dtype=torch.float32, device=dev)
+        ldo = out.stride(0)
         b = bias.contiguous() if bias is not None else None
         L = _lib.lib()
         fwd = L.dc_tag_linear_fwd_split if DENSE_SPLIT_BF16 else L.dc_tag_linear_fwd
         rc = fwd(
             _ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
-            b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), fo, n, fi_eff, fo,
+            b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n, fi_eff, fo,
             current_stream_ptr(dev))
         _lib.check(rc, "dc_tag_linear_fwd")
         ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu, ctx.concat = \
@@ -165,13 +190,16 @@ class _TagConvFn(torch.autograd.Function):
         slab, out, *ws = ctx.saved_tensors
         g, k, fi, fo, concat = ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.concat
         L = _lib.lib()
-        gout = gout.contiguous()
+        if gout.stride(1) != 1 or gout.stride(0) % 4 != 0 or gout.data_ptr() % 16 != 0:
+            gout = gout.contiguous()
+        ldg = gout.stride(0)                 # column-slice views (e.g. the dX slab) pass as is
         n = slab.size(0)
         dev = slab.device
         st = current_stream_ptr(dev)
         need_x, need_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        need_w = any(ctx.needs_input_grad[4:])
+        need_w = any(ctx.needs_input_grad[5:])
         mask_ptr = out.data_ptr() if out is not None else None
+        ldm = out.stride(0) if out is not None else fo
         wpad = slab.size(1)
         if concat:
             xs, ldxs, fi_eff, nseg = [slab], [wpad], wpad, 1
@@ -196,12 +224,12 @@ class _TagConvFn(torch.autograd.Function):
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             dw = L.dc_tag_linear_bwd_dw_split if DENSE_SPLIT_BF16 else L.dc_tag_linear_bwd_dw
             rc = dw(
-                gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(xs), _i64_array(ldxs), nseg,
+                gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
                 _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
                 int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo, st)
             _lib.check(rc, "dc_tag_linear_bwd_dw")
             if not direct:
-                gws = [outs[j] if ctx.needs_input_grad[4 + j] else None for j in range(k + 1)]
+                gws = [outs[j] if ctx.needs_input_grad[5 + j] else None for j in range(k + 1)]
                 gb = gb_out
 
         gx = None
@@ -212,22 +240,25 @@ class _TagConvFn(torch.autograd.Function):
             if DENSE_SPLIT_BF16:
                 wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi_eff, fo, nseg)
                 wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
-                rc = L.dc_tag_linear_bwd_dx_split(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws),
+                rc = L.dc_tag_linear_bwd_dx_split(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws),
                                                   nseg, _ptr_array(gxs), _i64_array(ldxs),
                                                   wsx.data_ptr(), wsb, n, fi_eff, fo, st)
             else:
-                rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), fo, mask_ptr, fo, _ptr_array(ws), nseg,
+                rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg,
                                             _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
             _lib.check(rc, "dc_tag_linear_bwd_dx")
             for j in range(k, 0, -1):                   # g_{j-1} = G_{j-1} + A^T g_j
                 hop(g.bwd, gblocks[j], out=gblocks[j - 1], addend=gblocks[j - 1],
                     weighted=g.normalize)
             gx = gblocks[0]
-        return (None, gx, gb, None, *gws)
+        return (None, gx, gb, None, None, *gws)
 
 
-def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False) -> torch.Tensor:
-    return _TagConvFn.apply(g, x, bias, bool(relu), *weights)
+def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
+             next_wpad: int = 0) -> torch.Tensor:
+    """``next_wpad``: padded slab width of the TAGConv layer that consumes this output (0 = none):
+    the output is then allocated as column block 0 of that slab."""
+    return _TagConvFn.apply(g, x, bias, bool(relu), int(next_wpad), *weights)
 
 
 # --------------------------------------------------------------------------- #
