@@ -132,12 +132,6 @@ int dc_tag_linear_bwd_dx_split(const float *g, int64_t ldg, const float *out_for
                                const int64_t *ldgxs, void *workspace, int64_t workspace_bytes,
                                int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream);
 
-int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const float *out_for_mask,
-                               int64_t ldo, const float *const *xs, const int64_t *ldxs, int nseg,
-                               float *const *gws, int ngw, int64_t gw_cols, float *gbias,
-                               int accumulate, void *partials, int64_t partials_bytes, int64_t N,
-                               int64_t Fi, int64_t Fo, dc_stream_t stream);
-
 /* dW-side: (g*relu')^T[Fo,N] . xs[s][N,Fi] (same optional ReLU mask), gbias[Fo] = column
  * sums of g*relu' (NULL to skip).  The result is delivered as `ngw` output blocks (ngw a
  * multiple of nseg): block j = columns [(j % bps)*gw_cols, +gw_cols) of segment j / bps,
@@ -154,6 +148,12 @@ int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask,
                          float *const *gws, int ngw, int64_t gw_cols, float *gbias,
                          int accumulate, void *partials, int64_t partials_bytes, int64_t N,
                          int64_t Fi, int64_t Fo, dc_stream_t stream);
+/* split-bf16x6 variant of the above (operands read through ds_read_b64_tr_b16) */
+int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const float *out_for_mask,
+                               int64_t ldo, const float *const *xs, const int64_t *ldxs, int nseg,
+                               float *const *gws, int ngw, int64_t gw_cols, float *gbias,
+                               int accumulate, void *partials, int64_t partials_bytes, int64_t N,
+                               int64_t Fi, int64_t Fo, dc_stream_t stream);
 
 /* pos_of[perm[p]] = p  (inverse permutation over the E' = *ptr_last sorted edges) */
 int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last /* &ptr[N] */, int32_t *pos_of,
