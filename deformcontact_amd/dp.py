@@ -73,5 +73,47 @@ class GradBucket:
         ws = world_size(self.group)
         if ws == 1:
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(ws)
+        if dist.get_backend(self.group) == "nccl":       # RCCL averages in the collective itself
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                            # gloo (CPU tests) has no AVG
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(ws)
+
+
+class FlatAdam:
+    """``torch.optim.Adam(params, lr)`` at its defaults (``/root/reference/train.py:20``) over flat
+    buckets: parameters are re-pointed to views of one flat fp32 buffer (as ``GradBucket`` does for
+    gradients), and a step is ONE elementwise HIP kernel (``dc_adam_flat``) instead of torch's
+    multi-tensor launch sequence.  hipGraph-replayable (the step count lives on the device)."""
+
+    def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        from . import _lib
+        from .graph import _require_cuda
+        self._lib = _lib
+        self.bucket, self.lr, self.betas, self.eps = bucket, float(lr), betas, float(eps)
+        _require_cuda(bucket.flat, "FlatAdam parameters")
+        dev = bucket.flat.device
+        self.flat_param = torch.empty_like(bucket.flat)
+        off = 0
+        with torch.no_grad():
+            for p in bucket.params:
+                n = p.numel()
+                view = self.flat_param[off:off + n].view_as(p)
+                view.copy_(p)
+                p.data = view                      # parameter storage now lives in the bucket
+                off += n
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def zero_grad(self) -> None:
+        self.bucket.zero()
+
+    def step(self) -> None:
+        from .graph import current_stream_ptr
+        b = self.bucket
+        rc = self._lib.lib().dc_adam_flat(
+            self.flat_param.data_ptr(), b.flat.data_ptr(), self.exp_avg.data_ptr(),
+            self.exp_avg_sq.data_ptr(), b.numel, self.step_count.data_ptr(), self.lr,
+            self.betas[0], self.betas[1], self.eps, current_stream_ptr(b.flat.device))
+        self._lib.check(rc, "dc_adam_flat")

@@ -192,6 +192,14 @@ int dc_segment_sum_f32(const int32_t *ptr, const int32_t *map, const float *v, f
 int dc_gather_f32(const float *v, const int32_t *idx, float *out, const int32_t *count_ptr,
                   int64_t cap, dc_stream_t stream);
 
+/* ---- optimizer step of the path's training loop -----------------------------
+ * torch.optim.Adam(lr) at its defaults (train.py:20: no weight decay, no amsgrad) over ONE
+ * flat fp32 bucket of parameters / gradients / moments: a single elementwise pass.  The step
+ * count `step` is a device scalar (float), incremented on the device before the update, so the
+ * call is replayable inside a hipGraph. */
+int dc_adam_flat(float *p, const float *g, float *m, float *v, int64_t n, float *step, float lr,
+                 float beta1, float beta2, float eps, dc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
