@@ -63,3 +63,70 @@ extern "C" int dc_adam_flat(float *p, const float *g, float *m, float *v, int64_
                        (hipStream_t)stream, p, g, m, v, n, step, lr, beta1, beta2, eps);
     return dc::check_launch("dc_adam_flat");
 }
+
+// ---- small packing helpers of the narrow-layer (concatenated K segment) path --------------
+namespace dc {
+
+// slab[i, 0:F] = x[i, 0:F]; slab[i, width:wpad] = 0   (one launch instead of copy + fill)
+__global__ void __launch_bounds__(256)
+k_pack_input(const float *__restrict__ x, int64_t ldx, float *__restrict__ slab, int64_t lds,
+             int64_t N, int F, int width, int wpad) {
+    const int per_row = F + (wpad - width);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * per_row) return;
+    const int64_t row = i / per_row;
+    const int c = (int)(i % per_row);
+    if (c < F)
+        slab[row * lds + c] = x[row * ldx + c];
+    else
+        slab[row * lds + width + (c - F)] = 0.f;
+}
+
+struct PackWParams {
+    const float *w[2 * DC_MAX_SEG];
+    float *wcat;
+    int64_t Fo;
+    int nw, fi, wpad;
+};
+
+// wcat[o, j*fi + f] = w[j][o, f], zero in [nw*fi, wpad)
+__global__ void __launch_bounds__(256)
+k_pack_weights(PackWParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.Fo * p.wpad) return;
+    const int64_t o = i / p.wpad;
+    const int c = (int)(i % p.wpad), j = c / p.fi;
+    p.wcat[i] = j < p.nw ? p.w[j][o * p.fi + (c - j * p.fi)] : 0.f;
+}
+
+}  // namespace dc
+
+extern "C" int dc_tag_pack_input(const float *x, int64_t ldx, float *slab, int64_t ld_slab,
+                                 int64_t N, int64_t F, int64_t width, int64_t wpad,
+                                 dc_stream_t stream) {
+    DC_REQUIRE(N >= 0 && F >= 1 && width >= F && wpad >= width && ld_slab >= wpad && ldx >= F,
+               "dc_tag_pack_input: bad sizes");
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(x && slab, "dc_tag_pack_input: null pointer");
+    const int64_t total = N * (F + (wpad - width));
+    hipLaunchKernelGGL(dc::k_pack_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, slab, ld_slab, N, (int)F, (int)width, (int)wpad);
+    return dc::check_launch("dc_tag_pack_input");
+}
+
+extern "C" int dc_tag_pack_weights(const float *const *ws, int nw, float *wcat, int64_t Fo,
+                                   int64_t fi, int64_t wpad, dc_stream_t stream) {
+    DC_REQUIRE(nw >= 1 && nw <= 2 * DC_MAX_SEG && Fo >= 1 && fi >= 1 && wpad >= nw * fi,
+               "dc_tag_pack_weights: bad sizes");
+    DC_REQUIRE(ws && wcat, "dc_tag_pack_weights: null pointer");
+    dc::PackWParams p{};
+    for (int j = 0; j < nw; ++j) {
+        DC_REQUIRE(ws[j], "dc_tag_pack_weights: null weight %d", j);
+        p.w[j] = ws[j];
+    }
+    p.wcat = wcat, p.Fo = Fo, p.nw = nw, p.fi = (int)fi, p.wpad = (int)wpad;
+    const int64_t total = Fo * wpad;
+    hipLaunchKernelGGL(dc::k_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    return dc::check_launch("dc_tag_pack_weights");
+}

@@ -92,11 +92,11 @@ class TAGConv(nn.Module):
         layer's hop slab."""
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
-        nxt = 0
+        nxt = None
         if isinstance(next_conv, TAGConv) and next_conv.in_channels == self.out_channels:
-            nxt = next_conv.slab_width()
+            nxt = ops.tag_slab_geometry(next_conv.in_channels, next_conv.K)[1:]
         return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu,
-                            next_wpad=nxt)
+                            next_geom=nxt)
 
     def extra_repr(self) -> str:
         return f"{self.in_channels}, {self.out_channels}, K={self.K}"

@@ -136,7 +136,7 @@ class _TagConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g: GraphIndex, x: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
-                next_wpad: int, *weights):
+                next_geom, *weights):
         n, fi = x.shape
         k = len(weights) - 1
         fo = weights[0].size(0)
@@ -147,37 +147,42 @@ class _TagConvFn(torch.autograd.Function):
         # narrow layers: one K segment over the whole slab, zero-padded to a multiple of 16 so
         # the lean MFMA path (aligned float4 loads, no K tail) applies (84 -> 96, 100 -> 112)
         slab = _as_slab_block0(x, n, fi, wpad)
+        L = _lib.lib()
+        st = current_stream_ptr(dev)
         if slab is None:
             slab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
-            if wpad > width:
-                slab[:, width:].zero_()
-            slab[:, :fi].copy_(x)
+            xin = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
+            _lib.check(L.dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), wpad, n,
+                                           fi, width, wpad, st), "dc_tag_pack_input")
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
         for j in range(k):
             hop(g.fwd, blocks[j], out=blocks[j + 1], weighted=g.normalize)
         if concat:
-            parts = [w for w in weights]
-            if wpad > width:
-                parts.append(torch.zeros((fo, wpad - width), dtype=torch.float32, device=dev))
-            ws = [torch.cat(parts, dim=1)]                           # [Fo, wpad]
+            wc = [w.contiguous() for w in weights]
+            wcat = torch.empty((fo, wpad), dtype=torch.float32, device=dev)
+            _lib.check(L.dc_tag_pack_weights(_ptr_array(wc), k + 1, wcat.data_ptr(), fo, fi, wpad,
+                                             st), "dc_tag_pack_weights")
+            ws = [wcat]                                              # [Fo, wpad]
             xs, ldxs, fi_eff = [slab], [wpad], wpad
         else:
             ws = [w.contiguous() for w in weights]
             xs, ldxs, fi_eff = blocks, [wpad] * (k + 1), fi
-        if next_wpad and next_wpad >= fo:
+        if next_geom is not None:
             # the output IS column block 0 of the next TAGConv layer's hop slab (no copy there)
+            next_width, next_wpad = next_geom
             nxt = torch.empty((n, next_wpad), dtype=torch.float32, device=dev)
+            if next_wpad > next_width:
+                nxt[:, next_width:].zero_()          # K padding of a narrow next layer
             out = nxt[:, :fo]
         else:
             out = torch.empty((n, fo), dtype=torch.float32, device=dev)
         ldo = out.stride(0)
         b = bias.contiguous() if bias is not None else None
-        L = _lib.lib()
         fwd = L.dc_tag_linear_fwd_split if DENSE_SPLIT_BF16 else L.dc_tag_linear_fwd
         rc = fwd(
             _ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
             b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n, fi_eff, fo,
-            current_stream_ptr(dev))
+            st)
         _lib.check(rc, "dc_tag_linear_fwd")
         ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu, ctx.concat = \
             g, k, fi, fo, bias is not None, relu, concat
@@ -255,10 +260,10 @@ class _TagConvFn(torch.autograd.Function):
 
 
 def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
-             next_wpad: int = 0) -> torch.Tensor:
-    """``next_wpad``: padded slab width of the TAGConv layer that consumes this output (0 = none):
-    the output is then allocated as column block 0 of that slab."""
-    return _TagConvFn.apply(g, x, bias, bool(relu), int(next_wpad), *weights)
+             next_geom=None) -> torch.Tensor:
+    """``next_geom``: ``(width, padded width)`` of the hop slab of the TAGConv layer that consumes
+    this output (None = none): the output is then allocated as column block 0 of that slab."""
+    return _TagConvFn.apply(g, x, bias, bool(relu), next_geom, *weights)
 
 
 # --------------------------------------------------------------------------- #

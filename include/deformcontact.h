@@ -192,6 +192,15 @@ int dc_segment_sum_f32(const int32_t *ptr, const int32_t *map, const float *v, f
 int dc_gather_f32(const float *v, const int32_t *idx, float *out, const int32_t *count_ptr,
                   int64_t cap, dc_stream_t stream);
 
+/* ---- packing helpers of the narrow-layer path (F_in = 21 / 25) ----------------
+ * A TAGConv layer whose K+1 column blocks are narrow runs its dense block over ONE K segment:
+ * the hop slab [N, wpad] (wpad = (K+1)*F rounded up to 16).  pack_input: slab[:, 0:F] = x and
+ * slab[:, width:wpad] = 0.  pack_weights: wcat[Fo, wpad] = [ws[0] | ... | ws[nw-1] | 0]. */
+int dc_tag_pack_input(const float *x, int64_t ldx, float *slab, int64_t ld_slab, int64_t N,
+                      int64_t F, int64_t width, int64_t wpad, dc_stream_t stream);
+int dc_tag_pack_weights(const float *const *ws, int nw, float *wcat, int64_t Fo, int64_t fi,
+                        int64_t wpad, dc_stream_t stream);
+
 /* ---- optimizer step of the path's training loop -----------------------------
  * torch.optim.Adam(lr) at its defaults (train.py:20: no weight decay, no amsgrad) over ONE
  * flat fp32 bucket of parameters / gradients / moments: a single elementwise pass.  The step

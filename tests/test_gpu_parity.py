@@ -467,3 +467,24 @@ def test_flat_adam_matches_torch_adam():
     for a, b in zip(ref.parameters(), mine.parameters()):
         assert rel_err(_np(b), _np(a)) < 1e-6
     assert float(o_mine.step_count) == 25.0
+
+
+@pytest.mark.parametrize("hidden", [21, 32, 40, 256])
+def test_encoder_slab_handoff_any_hidden_width(hidden):
+    """Layer output written into the next layer's (possibly K-padded) hop slab: vs oracle."""
+    from deformcontact_amd import synth
+    from deformcontact_amd.graphnet import ContactEncoder
+    rest, _, rig = synth.make_batch(2, soft_vertices=64, sphere_resolution=4)
+    torch.manual_seed(hidden)
+    enc = ContactEncoder([21, 25], hidden, encoder_layers=3)
+    ref = ContactEncoder([21, 25], hidden, encoder_layers=3, conv_module=pyg_ref)
+    ref.load_state_dict(enc.state_dict())
+    enc = enc.to(DEV)
+    a, b = enc(rest.clone().to(DEV), rig.clone().to(DEV))
+    ra, rb = ref(rest, rig)
+    assert rel_err(_np(a), _np(ra)) < TOL and rel_err(_np(b), _np(rb)) < TOL
+    (a.square().sum() + b.square().sum()).backward()
+    (ra.square().sum() + rb.square().sum()).backward()
+    rp = dict(ref.named_parameters())
+    for name, p in enc.named_parameters():
+        assert rel_err(_np(p.grad), _np(rp[name].grad)) < 3 * TOL, name
