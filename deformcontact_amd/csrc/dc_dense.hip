@@ -422,10 +422,16 @@ static inline int pick_mb(int64_t rows, int64_t col_tiles) {
     return (((rows + 127) / 128) * col_tiles >= 512) ? 2 : 1;
 }
 
+// 128-row tiles move 1/3 less L2 traffic per FLOP, 64-row tiles balance better when the tile
+// count is not a multiple of the 256 CUs (the rigid branch: 381 tiles of 64 rows): compare the
+// blocks-per-CU makespans, with a 12 % efficiency handicap on the small tile.
 static inline int split_mb(int64_t rows, int64_t col_tiles) {
     static const int forced = env_int("DC_SPLIT_MB", 0);
     if (forced == 1 || forced == 2) return forced;
-    return (((rows + 127) / 128) * col_tiles >= 256) ? 2 : 1;
+    const int64_t nb2 = ((rows + 127) / 128) * col_tiles, nb1 = ((rows + 63) / 64) * col_tiles;
+    const double t2 = (double)((nb2 + 255) / 256);
+    const double t1 = (double)((nb1 + 255) / 256) * 0.5 * 1.12;
+    return t1 < t2 ? 1 : 2;
 }
 
 static inline bool use_fast() {
