@@ -31,11 +31,11 @@ _SIGNATURES = {
                                      POINTER(_vp), POINTER(c_int64), c_int64, c_int64, c_int64,
                                      _vp]),
     "dc_tag_linear_fwd_split": (c_int, [POINTER(_vp), POINTER(c_int64), POINTER(_vp), c_int, _vp,
-                                        c_int, _vp, c_int64, c_int64, c_int64, c_int64, _vp]),
+                                        c_int, _vp, c_int64, c_int64, c_int64, c_int64, c_int, _vp]),
     "dc_tag_linear_bwd_dx_split_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "dc_tag_linear_bwd_dx_split": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp), c_int,
                                            POINTER(_vp), POINTER(c_int64), _vp, c_int64, c_int64,
-                                           c_int64, c_int64, _vp]),
+                                           c_int64, c_int64, c_int, _vp]),
     "dc_tag_linear_bwd_dw_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int]),
     "dc_tag_linear_bwd_dw": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp), POINTER(c_int64),
                                      c_int, POINTER(_vp), c_int, c_int64, _vp, c_int, _vp, c_int64,
@@ -43,7 +43,7 @@ _SIGNATURES = {
     "dc_tag_linear_bwd_dw_split": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp),
                                            POINTER(c_int64), c_int, POINTER(_vp), c_int, c_int64,
                                            _vp, c_int, _vp, c_int64, c_int64, c_int64, c_int64,
-                                           _vp]),
+                                           c_int, _vp]),
     "dc_tag_pack_input": (c_int, [_vp, c_int64, _vp, c_int64, c_int64, c_int64, c_int64, c_int64, _vp]),
     "dc_tag_pack_weights": (c_int, [POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp]),
     "dc_adam_flat": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_float, c_float, c_float, c_float,

@@ -132,8 +132,8 @@ bool fwd_fast_launch(const FwdParams &p, int mb, hipStream_t hs);
 bool dx_fast_launch(const DxParams &p, int mb, hipStream_t hs);
 bool dw_fast_launch(const DwParams &p, int mb, hipStream_t hs);
 // split-bf16 (fp32-accurate, 6 bf16 MFMA products) launchers (dc_dense_split.hip)
-bool fwd_split_launch(const FwdParams &p, int mb, hipStream_t hs);
-bool dx_split_launch(DxParams p, float *wt, int mb, hipStream_t hs);
-bool dw_split_launch(const DwParams &p, int mb, hipStream_t hs);
+bool fwd_split_launch(const FwdParams &p, int mb, int products, hipStream_t hs);
+bool dx_split_launch(DxParams p, float *wt, int mb, int products, hipStream_t hs);
+bool dw_split_launch(const DwParams &p, int mb, int products, hipStream_t hs);
 
 }  // namespace dc

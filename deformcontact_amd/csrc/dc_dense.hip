@@ -466,7 +466,7 @@ using namespace dc;
 
 static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *const *ws, int nseg,
                     const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t Fi,
-                    int64_t Fo, dc_stream_t stream, bool split) {
+                    int64_t Fo, dc_stream_t stream, int products) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_fwd: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_fwd: bad sizes");
     if (N == 0) return DC_OK;
@@ -486,7 +486,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     DC_REQUIRE(grid < (int64_t)INT32_MAX, "dc_tag_linear_fwd: grid too large");
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
-    if (split && vec && fwd_split_launch(p, split_mb(N, ntn), hs))
+    if (products && vec && fwd_split_launch(p, split_mb(N, ntn), products, hs))
         return check_launch("dc_tag_linear_fwd_split");
     if (use_fast() && vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
     if (mb == 2 && vec)
@@ -502,7 +502,8 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
 
 static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
                    const float *const *ws, int nseg, float *const *gxs, const int64_t *ldgxs,
-                   int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream, float *split_ws) {
+                   int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream, float *split_ws,
+                   int products) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dx: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dx: bad sizes");
     if (N == 0) return DC_OK;
@@ -527,7 +528,7 @@ static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     if (!p.has_mask) p.mask = p.g;
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
-    if (split_ws && vec && dx_split_launch(p, split_ws, split_mb(N, ntn), hs))
+    if (split_ws && vec && dx_split_launch(p, split_ws, split_mb(N, ntn), products, hs))
         return check_launch("dc_tag_linear_bwd_dx_split");
     if (use_fast() && vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
 #define DC_DX(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
@@ -550,21 +551,23 @@ extern "C" int dc_tag_linear_fwd(const float *const *xs, const int64_t *ldxs,
                                  const float *const *ws, int nseg, const float *bias, int relu,
                                  float *out, int64_t ldo, int64_t N, int64_t Fi, int64_t Fo,
                                  dc_stream_t stream) {
-    return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, false);
+    return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, 0);
 }
 
 extern "C" int dc_tag_linear_fwd_split(const float *const *xs, const int64_t *ldxs,
                                        const float *const *ws, int nseg, const float *bias,
                                        int relu, float *out, int64_t ldo, int64_t N, int64_t Fi,
-                                       int64_t Fo, dc_stream_t stream) {
-    return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, true);
+                                       int64_t Fo, int products, dc_stream_t stream) {
+    DC_REQUIRE(products == 6 || products == 3 || products == 1,
+               "dc_tag_linear_fwd_split: products must be 6, 3 or 1");
+    return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, products);
 }
 
 extern "C" int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *out_for_mask,
                                     int64_t ldo, const float *const *ws, int nseg,
                                     float *const *gxs, const int64_t *ldgxs, int64_t N, int64_t Fi,
                                     int64_t Fo, dc_stream_t stream) {
-    return dx_impl(g, ldg, out_for_mask, ldo, ws, nseg, gxs, ldgxs, N, Fi, Fo, stream, nullptr);
+    return dx_impl(g, ldg, out_for_mask, ldo, ws, nseg, gxs, ldgxs, N, Fi, Fo, stream, nullptr, 0);
 }
 
 extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *out_for_mask,
@@ -578,7 +581,7 @@ extern "C" int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const flo
                                           int nseg, float *const *gws, int ngw, int64_t gw_cols,
                                           float *gbias, int accumulate, void *partials,
                                           int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
-                                          dc_stream_t stream);
+                                          int products, dc_stream_t stream);
 
 extern "C" int64_t dc_tag_linear_bwd_dx_split_workspace_bytes(int64_t Fi, int64_t Fo, int nseg) {
     if (Fi < 1 || Fo < 1 || nseg < 1 || nseg > kMaxSeg) return DC_EINVAL;
@@ -589,12 +592,14 @@ extern "C" int dc_tag_linear_bwd_dx_split(const float *g, int64_t ldg, const flo
                                           int64_t ldo, const float *const *ws, int nseg,
                                           float *const *gxs, const int64_t *ldgxs, void *workspace,
                                           int64_t workspace_bytes, int64_t N, int64_t Fi,
-                                          int64_t Fo, dc_stream_t stream) {
+                                          int64_t Fo, int products, dc_stream_t stream) {
+    DC_REQUIRE(products == 6 || products == 3 || products == 1,
+               "dc_tag_linear_bwd_dx_split: products must be 6, 3 or 1");
     DC_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 &&
                    workspace_bytes >= dc_tag_linear_bwd_dx_split_workspace_bytes(Fi, Fo, nseg),
                "dc_tag_linear_bwd_dx_split: workspace missing, misaligned or too small");
     return dx_impl(g, ldg, out_for_mask, ldo, ws, nseg, gxs, ldgxs, N, Fi, Fo, stream,
-                   (float *)workspace);
+                   (float *)workspace, products);
 }
 
 extern "C" int64_t dc_tag_linear_bwd_dw_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo,
@@ -610,7 +615,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
                    const float *const *xs, const int64_t *ldxs, int nseg, float *const *gws, int ngw,
                    int64_t gw_cols, float *gbias, int accumulate, void *partials,
                    int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream,
-                   bool split) {
+                   int products) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dw: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dw: bad sizes");
     DC_REQUIRE(g && xs && ldxs && gws && partials && ldg >= Fo,
@@ -647,7 +652,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     if (!p.has_mask) p.mask = p.g;
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
-    bool fast_done = (split && vec && dw_split_launch(p, mb, hs)) ||
+    bool fast_done = (products && vec && dw_split_launch(p, mb, products, hs)) ||
                      (use_fast() && vec && dw_fast_launch(p, mb, hs));
 #define DC_DW(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (fast_done) {
@@ -680,7 +685,7 @@ extern "C" int dc_tag_linear_bwd_dw(const float *g, int64_t ldg, const float *ou
                                     int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
                                     dc_stream_t stream) {
     return dw_impl(g, ldg, out_for_mask, ldo, xs, ldxs, nseg, gws, ngw, gw_cols, gbias, accumulate,
-                   partials, partials_bytes, N, Fi, Fo, stream, false);
+                   partials, partials_bytes, N, Fi, Fo, stream, 0);
 }
 
 extern "C" int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const float *out_for_mask,
@@ -688,7 +693,9 @@ extern "C" int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const flo
                                           int nseg, float *const *gws, int ngw, int64_t gw_cols,
                                           float *gbias, int accumulate, void *partials,
                                           int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
-                                          dc_stream_t stream) {
+                                          int products, dc_stream_t stream) {
+    DC_REQUIRE(products == 6 || products == 3 || products == 1,
+               "dc_tag_linear_bwd_dw_split: products must be 6, 3 or 1");
     return dw_impl(g, ldg, out_for_mask, ldo, xs, ldxs, nseg, gws, ngw, gw_cols, gbias, accumulate,
-                   partials, partials_bytes, N, Fi, Fo, stream, true);
+                   partials, partials_bytes, N, Fi, Fo, stream, products);
 }

@@ -25,8 +25,15 @@ namespace dc {
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
-constexpr int SROW = 112;                 // LDS bytes per operand row per stage
 constexpr int kPlane = 32;                // bytes per plane inside a row (16 bf16)
+
+// NP = number of bf16 MFMA products per tile: 6 = fp32-accurate (hi, mid, lo planes),
+// 3 = hi/mid planes, products hi*hi + hi*mid + mid*hi (~4e-6 relative), 1 = plain bf16.
+template <int NP> struct Planes {
+    static_assert(NP == 6 || NP == 3 || NP == 1, "products per tile: 6, 3 or 1");
+    static constexpr int P = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
+    static constexpr int SROW = P * kPlane + 16;     // 112 / 80 / 48 B: conflict-free b128 reads
+};
 
 __device__ __forceinline__ void split1(float x, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
     hi = (__bf16)x;
@@ -45,8 +52,9 @@ __device__ __forceinline__ void split4(const float4 &v, bf16x4 &hi, bf16x4 &mid,
 }
 
 // fp32 [rows][K] (k contiguous) operand: per-thread float4 pointers, split at LDS-store time
-template <int ROWS, bool MASK>
+template <int ROWS, bool MASK, int NP>
 struct SplitOp {
+    static constexpr int SROW = Planes<NP>::SROW, P = Planes<NP>::P;
     static constexpr int NV = ROWS / 64;
     const float *p[NV];
     const float *pm[MASK ? NV : 1];
@@ -91,55 +99,60 @@ struct SplitOp {
             bf16x4 hi, mid, lo;
             split4(x, hi, mid, lo);
             *reinterpret_cast<bf16x4 *>(lds + off[j]) = hi;
-            *reinterpret_cast<bf16x4 *>(lds + off[j] + kPlane) = mid;
-            *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * kPlane) = lo;
+            if (P > 1) *reinterpret_cast<bf16x4 *>(lds + off[j] + kPlane) = mid;
+            if (P > 2) *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * kPlane) = lo;
         }
     }
 };
 
-template <int MB>
+template <int MB, int NP>
 struct SplitFrag {
-    bf16x8 a[MB][3];
-    bf16x8 b[2][3];
+    bf16x8 a[MB][Planes<NP>::P];
+    bf16x8 b[2][Planes<NP>::P];
 };
 
-template <int MB>
-__device__ __forceinline__ void load_split_frag(SplitFrag<MB> &f, const char *As, const char *Bs,
-                                                int wm, int wn) {
+template <int MB, int NP>
+__device__ __forceinline__ void load_split_frag(SplitFrag<MB, NP> &f, const char *As,
+                                                const char *Bs, int wm, int wn) {
+    constexpr int SROW = Planes<NP>::SROW, P = Planes<NP>::P;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < P; ++pl)
             f.a[mb][pl] = *reinterpret_cast<const bf16x8 *>(
                 As + (wm * 32 * MB + mb * 32 + r) * SROW + pl * kPlane + 16 * h);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < P; ++pl)
             f.b[nb][pl] = *reinterpret_cast<const bf16x8 *>(
                 Bs + (wn * 64 + nb * 32 + r) * SROW + pl * kPlane + 16 * h);
 }
 
-// six products, smallest terms first
-template <int MB>
-__device__ __forceinline__ void mma_split(const SplitFrag<MB> &f, f32x16 (&acc)[MB][2]) {
+// NP products, smallest terms first
+template <int MB, int NP>
+__device__ __forceinline__ void mma_split(const SplitFrag<MB, NP> &f, f32x16 (&acc)[MB][2]) {
     constexpr int HI = 0, MID = 1, LO = 2;
-    constexpr int pa[6] = {LO, HI, MID, MID, HI, HI};
-    constexpr int pb[6] = {HI, LO, MID, HI, MID, HI};
+    constexpr int pa6[6] = {LO, HI, MID, MID, HI, HI}, pb6[6] = {HI, LO, MID, HI, MID, HI};
+    constexpr int pa3[3] = {MID, HI, HI}, pb3[3] = {HI, MID, HI};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < NP; ++t) {
+        const int ia = NP == 6 ? pa6[t] : (NP == 3 ? pa3[t] : HI);
+        const int ib = NP == 6 ? pb6[t] : (NP == 3 ? pb3[t] : HI);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mb][pa[t]], f.b[nb][pb[t]],
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mb][ia], f.b[nb][ib],
                                                                       acc[mb][nb], 0, 0, 0);
+    }
 }
 
-template <int MB, typename OA, typename OB, typename Next>
+template <int MB, int NP, typename OA, typename OB, typename Next>
 __device__ __forceinline__ void split_loop(char *lds, int nst, OA &A, OB &B, Next &&next_stage,
                                            f32x16 (&acc)[MB][2], int wm, int wn) {
+    constexpr int SROW = Planes<NP>::SROW;
     constexpr int BM = 64 * MB, kOffB = BM * SROW, kStage = (BM + BN) * SROW;
     if (nst <= 0) return;
     A.load();
@@ -155,8 +168,8 @@ __device__ __forceinline__ void split_loop(char *lds, int nst, OA &A, OB &B, Nex
     __syncthreads();
     for (int it = 0; it < nst; ++it) {
         char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
-        SplitFrag<MB> f;
-        load_split_frag<MB>(f, cur, cur + kOffB, wm, wn);
+        SplitFrag<MB, NP> f;
+        load_split_frag<MB, NP>(f, cur, cur + kOffB, wm, wn);
         if (it + 1 < nst) {
             A.store(nxt);
             B.store(nxt + kOffB);
@@ -166,16 +179,16 @@ __device__ __forceinline__ void split_loop(char *lds, int nst, OA &A, OB &B, Nex
             B.load();
             next_stage();
         }
-        mma_split<MB>(f, acc);
+        mma_split<MB, NP>(f, acc);
         __syncthreads();
     }
 }
 
 // ------------------------------- forward -------------------------------------------
-template <int MB>
+template <int MB, int NP>
 __global__ void __launch_bounds__(256)
 k_fwd_split(FwdParams p) {
-    constexpr int BM = 64 * MB;
+    constexpr int BM = 64 * MB, SROW = Planes<NP>::SROW;
     __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * SROW];
     const unsigned ntn = (unsigned)((p.Fo + BN - 1) / BN);
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -184,8 +197,8 @@ k_fwd_split(FwdParams p) {
 
     f32x16 acc[MB][2];
     zero_acc<MB>(acc);
-    SplitOp<BM, false> A;
-    SplitOp<BN, false> B;
+    SplitOp<BM, false, NP> A;
+    SplitOp<BN, false, NP> B;
     A.init(p.x[0].p, nullptr, p.x[0].ld, row0, p.N);
     B.init(p.w[0].p, nullptr, p.Fi, col0, p.Fo);
     const int kst = (int)(p.Fi / BK), nst = kst * p.nseg;
@@ -198,7 +211,7 @@ k_fwd_split(FwdParams p) {
             ++seg;
         }
     };
-    split_loop<MB>(lds, nst, A, B, next_stage, acc, wm, wn);
+    split_loop<MB, NP>(lds, nst, A, B, next_stage, acc, wm, wn);
 
     float bcol[2];
 #pragma unroll
@@ -219,10 +232,10 @@ k_fwd_split(FwdParams p) {
 
 // ------------------------------- backward: dX --------------------------------------
 // p.w[s] here are the TRANSPOSED weights wt[s] [Fi, Fo] (ld = Fo)
-template <int MB, bool MASK>
+template <int MB, bool MASK, int NP>
 __global__ void __launch_bounds__(256)
 k_dx_split(DxParams p) {
-    constexpr int BM = 64 * MB;
+    constexpr int BM = 64 * MB, SROW = Planes<NP>::SROW;
     __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * SROW];
     const unsigned ntn = (unsigned)((p.Fi + BN - 1) / BN), per_row = ntn * p.nseg;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -233,11 +246,11 @@ k_dx_split(DxParams p) {
 
     f32x16 acc[MB][2];
     zero_acc<MB>(acc);
-    SplitOp<BM, MASK> A;
-    SplitOp<BN, false> B;
+    SplitOp<BM, MASK, NP> A;
+    SplitOp<BN, false, NP> B;
     A.init(p.g.p, p.mask.p, p.g.ld, row0, p.N);
     B.init(p.w[s].p, nullptr, p.Fo, col0, p.Fi);
-    split_loop<MB>(lds, (int)(p.Fo / BK), A, B, []() {}, acc, wm, wn);
+    split_loop<MB, NP>(lds, (int)(p.Fo / BK), A, B, []() {}, acc, wm, wn);
     float *out = p.gx[s];
     const int64_t ldo = p.ldgx[s];
     for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
@@ -253,18 +266,19 @@ k_dx_split(DxParams p) {
 // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of (row q, columns
 // 4p..4p+3) of a 4 x 16 block and lane i receives column i of the 4 rows.  Rows are padded by
 // 64 B so the four rows of a block land on disjoint bank quarters.
-template <int COLS> struct TrImage {
+template <int COLS, int NP> struct TrImage {
     static constexpr int ROWB = COLS * 2 + 64;          // bytes per k row of one plane
     static constexpr int PLANE = BK * ROWB;             // bytes per plane
-    static constexpr int BYTES = 3 * PLANE;
+    static constexpr int BYTES = Planes<NP>::P * PLANE;
 };
 
 // fp32 [K][cols] (col contiguous) operand tile BK x COLS: split at LDS-store time into 3 images
-template <int COLS, bool MASK>
+template <int COLS, bool MASK, int NP>
 struct SplitOpRC {
+    static constexpr int P = Planes<NP>::P;
     static constexpr int NV = COLS / 64;
     static constexpr int PER = COLS / 4, KPER = 256 / PER;
-    using Img = TrImage<COLS>;
+    using Img = TrImage<COLS, NP>;
     const float *p[NV];
     const float *pm[MASK ? NV : 1];
     float4 v[NV];
@@ -308,8 +322,8 @@ struct SplitOpRC {
             bf16x4 hi, mid, lo;
             split4(value(j), hi, mid, lo);
             *reinterpret_cast<bf16x4 *>(lds + off[j]) = hi;
-            *reinterpret_cast<bf16x4 *>(lds + off[j] + Img::PLANE) = mid;
-            *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * Img::PLANE) = lo;
+            if (P > 1) *reinterpret_cast<bf16x4 *>(lds + off[j] + Img::PLANE) = mid;
+            if (P > 2) *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * Img::PLANE) = lo;
         }
     }
 };
@@ -318,25 +332,25 @@ using s16x4 = __attribute__((ext_vector_type(4))) short;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // one MFMA operand (8 consecutive k for column m0 + (lane & 31)) from a [k][m] plane image
-template <int COLS>
+template <int ROWB>
 __device__ __forceinline__ bf16x8 tr_operand(const char *plane, int m0) {
     const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int h = g >> 1;
-    const char *a = plane + (8 * h + q) * TrImage<COLS>::ROWB + (m0 + 16 * (g & 1) + 4 * pp) * 2;
+    const char *a = plane + (8 * h + q) * ROWB + (m0 + 16 * (g & 1) + 4 * pp) * 2;
     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(a));
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_s16x4 *)(uintptr_t)(a + 4 * TrImage<COLS>::ROWB));
+        (lds_s16x4 *)(uintptr_t)(a + 4 * ROWB));
     union { s16x4 s[2]; bf16x8 b; } u;
     u.s[0] = lo4, u.s[1] = hi4;
     return u.b;
 }
 
-template <int MB, bool MASK>
+template <int MB, bool MASK, int NP>
 __global__ void __launch_bounds__(256)
 k_dw_split(DwParams p) {
-    constexpr int BM = 64 * MB;
-    using IA = TrImage<BM>;
-    using IB = TrImage<BN>;
+    constexpr int BM = 64 * MB, P = Planes<NP>::P;
+    using IA = TrImage<BM, NP>;
+    using IB = TrImage<BN, NP>;
     constexpr int kStage = IA::BYTES + IB::BYTES, kOffB = IA::BYTES;
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
     const unsigned ntm = (unsigned)((p.Fo + BM - 1) / BM), ntn = (unsigned)((p.Fi + BN - 1) / BN);
@@ -353,9 +367,9 @@ k_dw_split(DwParams p) {
     f32x16 acc[MB][2];
     zero_acc<MB>(acc);
     float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    using OA = SplitOpRC<BM, MASK>;
+    using OA = SplitOpRC<BM, MASK, NP>;
     OA A;
-    SplitOpRC<BN, false> B;
+    SplitOpRC<BN, false, NP> B;
     A.init(p.g.p, p.mask.p, p.g.ld, n_beg, o0, p.Fo);
     B.init(p.x[s].p, nullptr, p.x[s].ld, n_beg, f0, p.Fi);
     auto bias_acc = [&]() {
@@ -383,15 +397,15 @@ k_dw_split(DwParams p) {
     for (int it = 0; it < nst; ++it) {
         const char *cur = lds + (it & 1) * kStage;
         char *nxt = lds + ((it + 1) & 1) * kStage;
-        SplitFrag<MB> f;
+        SplitFrag<MB, NP> f;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < P; ++pl) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
-                f.a[mb][pl] = tr_operand<BM>(cur + pl * IA::PLANE, wm * 32 * MB + mb * 32);
+                f.a[mb][pl] = tr_operand<IA::ROWB>(cur + pl * IA::PLANE, wm * 32 * MB + mb * 32);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-                f.b[nb][pl] = tr_operand<BN>(cur + kOffB + pl * IB::PLANE, wn * 64 + nb * 32);
+                f.b[nb][pl] = tr_operand<IB::ROWB>(cur + kOffB + pl * IB::PLANE, wn * 64 + nb * 32);
         }
         if (it + 1 < nst) {
             A.store(nxt);
@@ -402,7 +416,7 @@ k_dw_split(DwParams p) {
             A.load();
             B.load();
         }
-        mma_split<MB>(f, acc);
+        mma_split<MB, NP>(f, acc);
         __syncthreads();
     }
     float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
@@ -458,17 +472,18 @@ k_transpose_w(TransposeParams p) {
 
 static inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
 
-bool fwd_split_launch(const FwdParams &p, int mb, hipStream_t hs) {
+bool fwd_split_launch(const FwdParams &p, int mb, int np, hipStream_t hs) {
+    if (np != 6 && np != 3 && np != 1) return false;
     if (p.Fi % BK != 0 || p.Fi < BK) return false;
     for (int s = 0; s < p.nseg; ++s)
         if (!al16(p.x[s].p) || !al16(p.w[s].p) || p.x[s].ld % 4 != 0 || p.x[s].ld != p.x[0].ld)
             return false;
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
     const dim3 gd((unsigned)grid), bd(256);
-    if (mb == 2)
-        hipLaunchKernelGGL((k_fwd_split<2>), gd, bd, 0, hs, p);
-    else
-        hipLaunchKernelGGL((k_fwd_split<1>), gd, bd, 0, hs, p);
+#define DC_L(MB_, NP_) hipLaunchKernelGGL((k_fwd_split<MB_, NP_>), gd, bd, 0, hs, p)
+    if (mb == 2) { if (np == 6) DC_L(2, 6); else if (np == 3) DC_L(2, 3); else DC_L(2, 1); }
+    else { if (np == 6) DC_L(1, 6); else if (np == 3) DC_L(1, 3); else DC_L(1, 1); }
+#undef DC_L
     return true;
 }
 
@@ -479,8 +494,8 @@ bool dx_split_eligible(const DxParams &p) {
 }
 
 // `p.w[s]` = original weights [Fo,Fi]; `wt` = workspace of nseg*Fi*Fo floats (16-B aligned)
-bool dx_split_launch(DxParams p, float *wt, int mb, hipStream_t hs) {
-    if (!dx_split_eligible(p) || !al16(wt)) return false;
+bool dx_split_launch(DxParams p, float *wt, int mb, int np, hipStream_t hs) {
+    if (!dx_split_eligible(p) || !al16(wt) || (np != 6 && np != 3 && np != 1)) return false;
     TransposeParams t{};
     for (int s = 0; s < p.nseg; ++s) t.w[s] = p.w[s].p;
     t.wt = wt, t.Fi = p.Fi, t.Fo = p.Fo, t.nseg = p.nseg;
@@ -489,14 +504,20 @@ bool dx_split_launch(DxParams p, float *wt, int mb, hipStream_t hs) {
     for (int s = 0; s < p.nseg; ++s) p.w[s] = Mat{wt + (int64_t)s * p.Fi * p.Fo, p.Fo};
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN) * p.nseg;
     const dim3 gd((unsigned)grid), bd(256);
-#define DC_L(MB_, M_) hipLaunchKernelGGL((k_dx_split<MB_, M_>), gd, bd, 0, hs, p)
+#define DC_L(MB_, M_)                                                                 \
+    do {                                                                              \
+        if (np == 6) hipLaunchKernelGGL((k_dx_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
+        else if (np == 3) hipLaunchKernelGGL((k_dx_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
+        else hipLaunchKernelGGL((k_dx_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
+    } while (0)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
     else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
 #undef DC_L
     return true;
 }
 
-bool dw_split_launch(const DwParams &p, int mb, hipStream_t hs) {
+bool dw_split_launch(const DwParams &p, int mb, int np, hipStream_t hs) {
+    if (np != 6 && np != 3 && np != 1) return false;
     if (p.N % BK != 0 || p.chunk_rows % BK != 0 || p.Fi % 4 != 0 || p.Fo % 4 != 0 || p.Fi < 4 ||
         p.Fo < 4 || !al16(p.g.p) || p.g.ld % 4 != 0)
         return false;
@@ -505,7 +526,12 @@ bool dw_split_launch(const DwParams &p, int mb, hipStream_t hs) {
         if (!al16(p.x[s].p) || p.x[s].ld % 4 != 0) return false;
     const int64_t tiles = ((p.Fo + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN);
     const dim3 gd((unsigned)(tiles * p.nseg * p.nchunks)), bd(256);
-#define DC_L(MB_, M_) hipLaunchKernelGGL((k_dw_split<MB_, M_>), gd, bd, 0, hs, p)
+#define DC_L(MB_, M_)                                                                 \
+    do {                                                                              \
+        if (np == 6) hipLaunchKernelGGL((k_dw_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
+        else if (np == 3) hipLaunchKernelGGL((k_dw_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
+        else hipLaunchKernelGGL((k_dw_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
+    } while (0)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
     else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
 #undef DC_L

@@ -98,6 +98,10 @@ DIRECT_PARAM_GRAD = True
 #: (or setting this to False) keeps everything on ``v_mfma_f32_32x32x2_f32``.
 DENSE_SPLIT_BF16 = os.environ.get("DC_DENSE_SPLIT", "1") != "0"
 
+#: bf16 MFMA products per tile in split mode: 6 = fp32-accurate (default), 3 = ~4e-6 relative,
+#: 1 = plain bf16 operands with fp32 accumulation (``DC_DENSE_PRODUCTS``).
+DENSE_PRODUCTS = int(os.environ.get("DC_DENSE_PRODUCTS", "6"))
+
 
 def _grad_sink(p) -> bool:
     g = getattr(p, "grad", None)
@@ -178,11 +182,12 @@ class _TagConvFn(torch.autograd.Function):
             out = torch.empty((n, fo), dtype=torch.float32, device=dev)
         ldo = out.stride(0)
         b = bias.contiguous() if bias is not None else None
-        fwd = L.dc_tag_linear_fwd_split if DENSE_SPLIT_BF16 else L.dc_tag_linear_fwd
-        rc = fwd(
-            _ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
-            b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n, fi_eff, fo,
-            st)
+        args = (_ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
+                b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n, fi_eff, fo)
+        if DENSE_SPLIT_BF16:
+            rc = L.dc_tag_linear_fwd_split(*args, DENSE_PRODUCTS, st)
+        else:
+            rc = L.dc_tag_linear_fwd(*args, st)
         _lib.check(rc, "dc_tag_linear_fwd")
         ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu, ctx.concat = \
             g, k, fi, fo, bias is not None, relu, concat
@@ -227,11 +232,13 @@ class _TagConvFn(torch.autograd.Function):
                 gb_out = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
             nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi_eff, fo, nseg)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            dw = L.dc_tag_linear_bwd_dw_split if DENSE_SPLIT_BF16 else L.dc_tag_linear_bwd_dw
-            rc = dw(
-                gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
-                _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
-                int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo, st)
+            args = (gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
+                    _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
+                    int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo)
+            if DENSE_SPLIT_BF16:
+                rc = L.dc_tag_linear_bwd_dw_split(*args, DENSE_PRODUCTS, st)
+            else:
+                rc = L.dc_tag_linear_bwd_dw(*args, st)
             _lib.check(rc, "dc_tag_linear_bwd_dw")
             if not direct:
                 gws = [outs[j] if ctx.needs_input_grad[5 + j] else None for j in range(k + 1)]
@@ -247,7 +254,8 @@ class _TagConvFn(torch.autograd.Function):
                 wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
                 rc = L.dc_tag_linear_bwd_dx_split(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws),
                                                   nseg, _ptr_array(gxs), _i64_array(ldxs),
-                                                  wsx.data_ptr(), wsb, n, fi_eff, fo, st)
+                                                  wsx.data_ptr(), wsb, n, fi_eff, fo,
+                                                  DENSE_PRODUCTS, st)
             else:
                 rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg,
                                             _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)

@@ -116,21 +116,25 @@ int dc_tag_linear_bwd_dx(const float *g, int64_t ldg, const float *out_for_mask,
                          const int64_t *ldgxs, int64_t N, int64_t Fi, int64_t Fo,
                          dc_stream_t stream);
 
-/* fp32-accurate variants on the bf16 matrix cores: every fp32 operand is split exactly into
- * three bf16 terms (hi + mid + lo) while it is staged into LDS and the product is formed from
- * six v_mfma_f32_32x32x16_bf16 (terms down to 2^-16 kept, fp32 accumulate): error of the split
- * ~6e-9 relative, i.e. below the rounding of the fp32 accumulation itself, at 2.7x the fp32
- * MFMA peak.  Same arguments and semantics as the functions above; shapes the split kernels
- * do not cover (unaligned operands, reduction extent not a multiple of 16) silently take the
- * fp32 path.  The dX variant needs a scratch of ..._workspace_bytes() for transposed weights. */
+/* Variants on the bf16 matrix cores.  Every fp32 operand is split exactly into bf16 terms
+ * (hi + mid + lo) while it is staged into LDS and a product tile is `products`
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+ *   products = 6 : hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid - fp32-accurate (split error
+ *                  ~6e-9 relative, below the rounding of the fp32 accumulation), 2.7x the
+ *                  fp32 MFMA peak;
+ *   products = 3 : hi*hi, hi*mid, mid*hi (~4e-6 relative);
+ *   products = 1 : plain bf16 operands, fp32 accumulate (BASELINE.json configs[4]).
+ * Same arguments and semantics as the functions above; shapes the split kernels do not cover
+ * (unaligned operands, reduction extent not a multiple of 16) silently take the fp32 path.
+ * The dX variant needs a scratch of ..._workspace_bytes() for transposed weights. */
 int dc_tag_linear_fwd_split(const float *const *xs, const int64_t *ldxs, const float *const *ws,
                             int nseg, const float *bias, int relu, float *out, int64_t ldo,
-                            int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream);
+                            int64_t N, int64_t Fi, int64_t Fo, int products, dc_stream_t stream);
 int64_t dc_tag_linear_bwd_dx_split_workspace_bytes(int64_t Fi, int64_t Fo, int nseg);
 int dc_tag_linear_bwd_dx_split(const float *g, int64_t ldg, const float *out_for_mask,
                                int64_t ldo, const float *const *ws, int nseg, float *const *gxs,
                                const int64_t *ldgxs, void *workspace, int64_t workspace_bytes,
-                               int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream);
+                               int64_t N, int64_t Fi, int64_t Fo, int products, dc_stream_t stream);
 
 /* dW-side: (g*relu')^T[Fo,N] . xs[s][N,Fi] (same optional ReLU mask), gbias[Fo] = column
  * sums of g*relu' (NULL to skip).  The result is delivered as `ngw` output blocks (ngw a
@@ -153,7 +157,7 @@ int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const float *out_for
                                int64_t ldo, const float *const *xs, const int64_t *ldxs, int nseg,
                                float *const *gws, int ngw, int64_t gw_cols, float *gbias,
                                int accumulate, void *partials, int64_t partials_bytes, int64_t N,
-                               int64_t Fi, int64_t Fo, dc_stream_t stream);
+                               int64_t Fi, int64_t Fo, int products, dc_stream_t stream);
 
 /* pos_of[perm[p]] = p  (inverse permutation over the E' = *ptr_last sorted edges) */
 int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last /* &ptr[N] */, int32_t *pos_of,

@@ -154,8 +154,11 @@ def test_empty_graph_and_isolated_nodes():
 @pytest.mark.parametrize("n,fi,fo,nseg,relu", [
     (1, 21, 256, 4, True), (63, 25, 256, 4, False), (65, 32, 32, 4, True), (200, 256, 256, 4, True),
     (130, 256, 130, 2, False), (64, 16, 3, 1, True), (257, 84, 260, 3, True), (1000, 256, 256, 1, False)])
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [0, 6, 3, 1])
 def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu, split):
+    # tolerance vs float64 by products per tile: fp32 MFMA / 6 products are fp32-accurate,
+    # 3 products keep terms down to 2^-8 * 2^-8, 1 product is plain bf16
+    tol = {0: 2e-6, 6: 2e-6, 3: 3e-5, 1: 2e-2}[split]
     import ctypes
     from deformcontact_amd import _lib
     from deformcontact_amd.graph import current_stream_ptr
@@ -168,14 +171,15 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu, split):
     bias = torch.from_numpy(hashed_uniform((fo,), 77, 0.5)).to(DEV)
     out = torch.empty(n, fo, device=DEV)
     st = current_stream_ptr(torch.device(DEV))
-    fwd = L.dc_tag_linear_fwd_split if split else L.dc_tag_linear_fwd
-    _lib.check(fwd(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
-                   int(relu), out.data_ptr(), fo, n, fi, fo, st), "fwd")
+    fargs = (_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(), int(relu),
+             out.data_ptr(), fo, n, fi, fo)
+    _lib.check(L.dc_tag_linear_fwd_split(*fargs, split, st) if split else L.dc_tag_linear_fwd(*fargs, st),
+               "fwd")
     ref = sum(xs[s].double().cpu() @ ws[s].double().cpu().t() for s in range(nseg)) + bias.double().cpu()
     pre = ref.clone()
     if relu:
         ref = ref.clamp_min(0)
-    assert rel_err(_np(out), ref.numpy()) < 2e-6
+    assert rel_err(_np(out), ref.numpy()) < tol
     # backward
     g = torch.from_numpy(hashed_uniform((n, fo), 91, 2.0)).to(DEV)
     gm = g.double().cpu() * ((pre > 0).double() if relu else 1.0)
@@ -187,13 +191,13 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu, split):
     nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     mask = out.data_ptr() if relu else None
-    dw = L.dc_tag_linear_bwd_dw_split if split else L.dc_tag_linear_bwd_dw
-    _lib.check(dw(g.data_ptr(), fo, mask, fo, _ptr_array(xs), _i64_array(ld), nseg,
-                                      _ptr_array(gws), nseg, fi, gb.data_ptr(), 0, scratch.data_ptr(), nbytes,
-                                      n, fi, fo, st), "dw")
+    wargs = (g.data_ptr(), fo, mask, fo, _ptr_array(xs), _i64_array(ld), nseg, _ptr_array(gws), nseg,
+             fi, gb.data_ptr(), 0, scratch.data_ptr(), nbytes, n, fi, fo)
+    _lib.check(L.dc_tag_linear_bwd_dw_split(*wargs, split, st) if split
+               else L.dc_tag_linear_bwd_dw(*wargs, st), "dw")
     for s in range(nseg):
-        assert rel_err(_np(gws[s]), (gm.t() @ xs[s].double().cpu()).numpy()) < 2e-6, s
-    assert rel_err(_np(gb), gm.sum(0).numpy()) < 2e-6
+        assert rel_err(_np(gws[s]), (gm.t() @ xs[s].double().cpu()).numpy()) < tol, s
+    assert rel_err(_np(gb), gm.sum(0).numpy()) < 2e-6          # bias sums stay fp32 VALU
     gslab = torch.zeros(n, nseg * fi, device=DEV)
     gxs = [gslab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
     if split:
@@ -201,12 +205,12 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu, split):
         wsx = torch.empty(wsb, dtype=torch.uint8, device=DEV)
         _lib.check(L.dc_tag_linear_bwd_dx_split(g.data_ptr(), fo, mask, fo, _ptr_array(ws), nseg,
                                                 _ptr_array(gxs), _i64_array(ld), wsx.data_ptr(), wsb,
-                                                n, fi, fo, st), "dx_split")
+                                                n, fi, fo, split, st), "dx_split")
     else:
         _lib.check(L.dc_tag_linear_bwd_dx(g.data_ptr(), fo, mask, fo, _ptr_array(ws), nseg, _ptr_array(gxs),
                                           _i64_array(ld), n, fi, fo, st), "dx")
     for s in range(nseg):
-        assert rel_err(_np(gxs[s]), (gm @ ws[s].double().cpu()).numpy()) < 2e-6, s
+        assert rel_err(_np(gxs[s]), (gm @ ws[s].double().cpu()).numpy()) < tol, s
 
 
 # --------------------------------------------------------------------------- #

@@ -36,7 +36,10 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--products", type=int, default=6, help="bf16 products per tile for the *6 rows")
     args = ap.parse_args()
+    global NP
+    NP = args.products
     dev = torch.device("cuda:0")
     L = _lib.lib()
     st = current_stream_ptr(dev)
@@ -73,15 +76,15 @@ def main():
         wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
         def fwd_s():
-            L.dc_tag_linear_fwd_split(pa_x, pa_ld, pa_w, nseg, bias.data_ptr(), 1, out.data_ptr(), fo, n, fi, fo, st)
+            L.dc_tag_linear_fwd_split(pa_x, pa_ld, pa_w, nseg, bias.data_ptr(), 1, out.data_ptr(), fo, n, fi, fo, NP, st)
 
         def dx_s():
             L.dc_tag_linear_bwd_dx_split(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld,
-                                         wsx.data_ptr(), wsb, n, fi, fo, st)
+                                         wsx.data_ptr(), wsb, n, fi, fo, NP, st)
 
         def dw_s():
             L.dc_tag_linear_bwd_dw_split(g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
-                                         gb.data_ptr(), 0, scratch.data_ptr(), nbytes, n, fi, fo, st)
+                                         gb.data_ptr(), 0, scratch.data_ptr(), nbytes, n, fi, fo, NP, st)
 
         for kn, fn in (("fwd", fwd), ("dX", dx), ("dW", dw), ("fwd6", fwd_s), ("dX6", dx_s), ("dW6", dw_s)):
             ms = timeit(fn, args.reps)

@@ -18,9 +18,10 @@ for name, mk in (("gauss", lambda *s: torch.randn(*s, device=dev)),
     bias = torch.randn(fo, device=dev)
     ref = sum(x.double() @ w.double().t() for x, w in zip(xs, ws)) + bias.double()
     sc = ref.abs().max()
-    for kind, fn in (("fp32 mfma", L.dc_tag_linear_fwd), ("bf16x6   ", L.dc_tag_linear_fwd_split)):
+    for kind, np_ in (("fp32 mfma", 0), ("bf16x6   ", 6), ("bf16x3   ", 3), ("bf16x1   ", 1)):
         out = torch.empty(n, fo, device=dev)
-        fn(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(), 0, out.data_ptr(), fo, n, fi, fo, st)
+        a = (_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(), 0, out.data_ptr(), fo, n, fi, fo)
+        L.dc_tag_linear_fwd_split(*a, np_, st) if np_ else L.dc_tag_linear_fwd(*a, st)
         err = (out.double() - ref).abs()
         print(f"{name:16s} {kind}: max|err|/max|ref| = {float(err.max() / sc):.3e}   rms rel = {float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.3e}")
     t = (slab.float() @ torch.cat(ws, 1).t() + bias)
