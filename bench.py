@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--kernel-reps", type=int, default=100)
+    ap.add_argument("--no-full-step", action="store_true",
+                    help="skip the extra full-model (encoder + attention + decoder + losses + Adam) B=4 timing")
     return ap.parse_args()
 
 
@@ -92,6 +94,30 @@ def cpu_baseline(batch: int, budget_s: float):
             "sample": f"{len(times)} timed iterations (1 warm-up) of the same B={batch} encoder "
                       f"fwd+bwd, median {med * 1e3:.1f} ms, torch {torch.__version__} CPU ops, "
                       f"{cores} threads (of {os.cpu_count()} logical CPUs; best-scaling setting)"}
+
+
+def full_step_b4(dev, steps: int = 20):
+    """Extra, not the headline: the reference's whole train step (train.py:46-58,71-73) at its
+    shipped batch size 4 (configs/everyday.json:26) - encoder on the HIP path, unmasked
+    cross-attention + decoder + L1 / gradient-consistency losses on stock PyTorch, Adam."""
+    from deformcontact_amd import synth
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
+    from deformcontact_amd.train import train_step
+    rest, deff, rig = (b.to(dev) for b in synth.make_batch(4))
+    torch.manual_seed(0)
+    model = load_model(EVERYDAY_NETWORK).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=4e-4)
+    for _ in range(3):
+        train_step(model, opt, rest, deff, rig)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = train_step(model, opt, rest, deff, rig)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    edges = rest.edge_index.shape[1] + rig.edge_index.shape[1]
+    return {"ms_per_step": round(ms, 3), "M_edges_per_s": round(edges / ms / 1e3, 2), "batch": 4,
+            "loss": round(float(out["loss"]), 6), "note": "eager (no hipGraph), attention/decoder on torch"}
 
 
 def main():
@@ -273,6 +299,8 @@ def main():
             "cases_isolated": {"soft_fwd": per_case[0], "soft_bwd": per_case[1],
                                "rigid_fwd": per_case[2], "rigid_bwd": per_case[3]},
         }
+        if world == 1 and not args.no_full_step:
+            out["full_train_step_b4"] = full_step_b4(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -112,3 +112,30 @@ def test_oracle_batch_matches_golden():
     assert np.array_equal(b.ptr.numpy(), z["batch_ptr"])
     assert np.array_equal(b.batch.numpy(), z["batch_vec"])
     assert np.array_equal(b[1].edge_index.numpy(), z["ei2"])
+
+
+def test_c_csr_property_random_graphs():
+    """hypothesis: the C counting sort equals numpy's stable argsort on arbitrary multigraphs
+    (duplicates, self loops, isolated nodes, empty edge lists)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 40).flatmap(lambda n: st.tuples(
+        st.just(n), st.lists(st.tuples(st.integers(0, n - 1), st.integers(0, n - 1)), max_size=200))))
+    def check(args):
+        n, edges = args
+        ei = np.array(edges, dtype=np.int64).reshape(-1, 2).T if edges else np.zeros((2, 0), np.int64)
+        ei = np.ascontiguousarray(ei)
+        for key_row in (0, 1):
+            ptr, other, perm = hop_c.csr_build(ei, n, key_row)
+            order = np.argsort(ei[key_row], kind="stable")
+            assert np.array_equal(perm, order.astype(np.int32))
+            assert np.array_equal(other, ei[1 - key_row][order].astype(np.int32))
+            assert np.array_equal(ptr[1:], np.cumsum(np.bincount(ei[key_row], minlength=n)))
+        if ei.shape[1]:
+            w = hop_c.gcn_norm(ei, n)
+            deg = np.bincount(ei[1], minlength=n).astype(np.float64)
+            dis = np.where(deg > 0, deg ** -0.5, 0.0)
+            assert np.allclose(w, dis[ei[0]] * dis[ei[1]], rtol=1e-6)
+
+    check()
