@@ -96,6 +96,78 @@ def cpu_baseline(batch: int, budget_s: float):
                       f"{cores} threads (of {os.cpu_count()} logical CPUs; best-scaling setting)"}
 
 
+def dense_roofline(dev, n_s: int, n_r: int, reps: int):
+    """Second roofline object: the dense block (66 % of the step), MFMA-bound.  The six layer-2
+    launches of a step (fwd, dX, dW for the soft and the rigid branch; F = 256, K = 4 x 256)
+    interleaved, HIP events.  `achieved` counts the bf16 MFMA FLOPs actually executed
+    (products x algorithmic); `fp32_equivalent` is algorithmic FLOPs / time."""
+    from deformcontact_amd import _lib, ops
+    from deformcontact_amd.graph import current_stream_ptr
+    from deformcontact_amd.ops import _i64_array, _ptr_array
+    L = _lib.lib()
+    st = current_stream_ptr(dev)
+    fi = fo = 256
+    nseg = 4
+    launches, flops = [], 0.0
+    keep = []
+    for n in (n_s, n_r):
+        slab = torch.randn(n, nseg * fi, device=dev)
+        xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+        ws = [torch.randn(fo, fi, device=dev) / 16 for _ in range(nseg)]
+        bias, out, g = torch.randn(fo, device=dev), torch.empty(n, fo, device=dev), torch.randn(n, fo, device=dev)
+        gws = [torch.empty(fo, fi, device=dev) for _ in range(nseg)]
+        gb = torch.empty(fo, device=dev)
+        gslab = torch.empty(n, nseg * fi, device=dev)
+        gxs = [gslab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+        nb = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi, fo, nseg)
+        wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        pa_x, pa_w, pa_gw, pa_gx, pa_ld = (_ptr_array(xs), _ptr_array(ws), _ptr_array(gws),
+                                            _ptr_array(gxs), _i64_array([nseg * fi] * nseg))
+        keep += [slab, ws, bias, out, g, gws, gb, gslab, scratch, wsx, pa_x, pa_w, pa_gw, pa_gx, pa_ld]
+        split, npd = ops.DENSE_SPLIT_BF16, ops.DENSE_PRODUCTS
+
+        def fwd(n=n, pa_x=pa_x, pa_ld=pa_ld, pa_w=pa_w, bias=bias, out=out):
+            a = (pa_x, pa_ld, pa_w, nseg, bias.data_ptr(), 1, out.data_ptr(), fo, n, fi, fo)
+            L.dc_tag_linear_fwd_split(*a, npd, st) if split else L.dc_tag_linear_fwd(*a, st)
+
+        def dx(n=n, g=g, out=out, pa_w=pa_w, pa_gx=pa_gx, pa_ld=pa_ld, wsx=wsx, wsb=wsb):
+            if split:
+                L.dc_tag_linear_bwd_dx_split(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld,
+                                             wsx.data_ptr(), wsb, n, fi, fo, npd, st)
+            else:
+                L.dc_tag_linear_bwd_dx(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld, n, fi, fo, st)
+
+        def dw(n=n, g=g, out=out, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb):
+            a = (g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi, gb.data_ptr(), 0,
+                 scratch.data_ptr(), nb, n, fi, fo)
+            L.dc_tag_linear_bwd_dw_split(*a, npd, st) if split else L.dc_tag_linear_bwd_dw(*a, st)
+
+        launches += [fwd, dx, dw]
+        flops += 3 * 2.0 * n * fi * nseg * fo
+    for f in launches:
+        f()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        for f in launches:
+            f()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    prod = ops.DENSE_PRODUCTS if ops.DENSE_SPLIT_BF16 else 1
+    peak = 2500.0 if ops.DENSE_SPLIT_BF16 else 157.3
+    achieved = prod * flops / ms / 1e9
+    return {"bound": "mfma", "kernel": "dc::k_fwd_split / k_dx_split / k_dw_split (layer-2 dense block)"
+            if ops.DENSE_SPLIT_BF16 else "dc::k_fwd_fast / k_dx_fast / k_dw_fast",
+            "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "executed": f"{prod} bf16 MFMA products per fp32 product tile" if ops.DENSE_SPLIT_BF16 else "fp32 MFMA",
+            "fp32_equivalent_TFLOPs": round(flops / ms / 1e9, 1), "fp32_mfma_peak": 157.3,
+            "algorithmic_flop_per_step_l2": flops, "us_per_6_launches": round(ms * 1e3, 1),
+            "sustained_bf16_peak_measured": "1.5-1.86 PF/s under DVFS (tools/mfma_peak_bf16.hip)"}
+
+
 def full_step_b4(dev, steps: int = 20):
     """Extra, not the headline: the reference's whole train step (train.py:46-58,71-73) at its
     shipped batch size 4 (configs/everyday.json:26) - encoder on the HIP path, unmasked
@@ -299,6 +371,7 @@ def main():
             "cases_isolated": {"soft_fwd": per_case[0], "soft_bwd": per_case[1],
                                "rigid_fwd": per_case[2], "rigid_bwd": per_case[3]},
         }
+        out["roofline_mfma"] = dense_roofline(dev, n_s, n_r, args.kernel_reps // 4 or 1)
         if world == 1 and not args.no_full_step:
             out["full_train_step_b4"] = full_step_b4(dev)
         if world == 1 and not args.no_cpu_baseline:
