@@ -203,11 +203,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in deformcontact_amd)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)     # == local_rank on a real N-GPU node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") over xGMI; DC_DIST_BACKEND=gloo only exists to smoke-test the N > 1 code
+        # path on a single-GPU box (several ranks sharing one device)
+        backend = os.environ.get("DC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from deformcontact_amd import dp, ops, synth
     from deformcontact_amd.graph import graph_index
