@@ -103,6 +103,40 @@ DENSE_SPLIT_BF16 = os.environ.get("DC_DENSE_SPLIT", "1") != "0"
 DENSE_PRODUCTS = int(os.environ.get("DC_DENSE_PRODUCTS", "6"))
 
 
+#: Run the K chained hops of a TAGConv layer (forward: x_k = A x_{k-1}; backward: g_{k-1} = G_{k-1}
+#: + A^T g_k) as ONE launch with the features and adjacency of each mesh resident in LDS
+#: (``dc_multihop_f32``) whenever the batch splits into small enough segments; bit-identical to
+#: hop-by-hop.  OFF by default: measured on MI355X (r01, ``tools/kbench.py --multihop``) the
+#: L2-served single hops are faster at the everyday-deform shape (F = 256: 47 vs 54 us forward,
+#: 52 vs 74 us backward for three hops) - one 1024-thread workgroup per CU cannot hide the
+#: dependent LDS gathers the way 32 resident waves hide L2 latency.  ``DC_MULTIHOP=1`` enables it.
+MULTIHOP = os.environ.get("DC_MULTIHOP", "0") == "1"
+
+
+def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool) -> None:
+    """In place on ``slab`` ([N, ld], K+1 column blocks of width ``f``).  Forward: block j+1 =
+    A block j (j = 0..k-1).  Backward: block j-1 += A^T block j (j = k..1)."""
+    if k == 0:
+        return
+    adj = g.bwd if backward else g.fwd
+    seg = g.segments() if MULTIHOP else None
+    if seg is not None:
+        w = adj.w if g.normalize else None
+        rc = _lib.lib().dc_multihop_f32(
+            adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+            seg[0].data_ptr(), seg[1], slab.data_ptr(), slab.stride(0), f, k,
+            k if backward else 0, -1 if backward else 1, int(backward), current_stream_ptr(slab.device))
+        _lib.check(rc, "dc_multihop_f32")
+        return
+    blocks = [slab[:, j * f:(j + 1) * f] for j in range(k + 1)]
+    if backward:
+        for j in range(k, 0, -1):
+            hop(adj, blocks[j], out=blocks[j - 1], addend=blocks[j - 1], weighted=g.normalize)
+    else:
+        for j in range(k):
+            hop(adj, blocks[j], out=blocks[j + 1], weighted=g.normalize)
+
+
 def _grad_sink(p) -> bool:
     g = getattr(p, "grad", None)
     return (g is not None and g.dtype == torch.float32 and g.is_contiguous()
@@ -159,8 +193,7 @@ class _TagConvFn(torch.autograd.Function):
             _lib.check(L.dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), wpad, n,
                                            fi, width, wpad, st), "dc_tag_pack_input")
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-        for j in range(k):
-            hop(g.fwd, blocks[j], out=blocks[j + 1], weighted=g.normalize)
+        chained_hops(g, slab, fi, k, backward=False)
         if concat:
             wc = [w.contiguous() for w in weights]
             wcat = torch.empty((fo, wpad), dtype=torch.float32, device=dev)
@@ -260,9 +293,7 @@ class _TagConvFn(torch.autograd.Function):
                 rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg,
                                             _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
             _lib.check(rc, "dc_tag_linear_bwd_dx")
-            for j in range(k, 0, -1):                   # g_{j-1} = G_{j-1} + A^T g_j
-                hop(g.bwd, gblocks[j], out=gblocks[j - 1], addend=gblocks[j - 1],
-                    weighted=g.normalize)
+            chained_hops(g, gslab, fi, k, backward=True)  # g_{j-1} = G_{j-1} + A^T g_j
             gx = gblocks[0]
         return (None, gx, gb, None, None, *gws)
 
