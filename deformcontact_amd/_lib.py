@@ -25,6 +25,8 @@ _SIGNATURES = {
     "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
     "dc_spmm_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                             c_int64, _vp]),
+    "dc_spmm_bf16": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
+                             c_int64, c_int, _vp]),
     "dc_multihop_max_segment_nodes": (c_int64, []),
     "dc_multihop_max_segment_edges": (c_int64, []),
     "dc_multihop_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, c_int64, c_int, c_int,

@@ -84,6 +84,7 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     }
 }
 
+
 // ---- L lanes per row, 64/L rows per wave (narrow feature rows) -------------
 template <int VEC, int L, int U>
 __global__ void __launch_bounds__(256)
@@ -136,6 +137,267 @@ static void launch_sub(const int32_t *ptr, const int32_t *other, const float *w,
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+// ---- bf16 feature rows, fp32 accumulation -------------------------
+// x is stored as bf16 (half the gather bytes of the fp32 hop); products and the running sum are
+// fp32 exactly as in the fp32 kernels (bf16 -> fp32 is exact, multiply and add rounded
+// separately, p order), and the result is stored as fp32 or rounded once (nearest-even) to bf16.
+// L lanes share one row, 8 columns (one 16-byte load) per lane and step: F = 256 is 32 lanes,
+// two destination rows per wave.
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct Bf16x8 { uint4 q; };
+__device__ __forceinline__ void unpack8(const uint4 &q, float (&v)[8]) {
+    const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(d[i] << 16);
+        v[2 * i + 1] = __uint_as_float(d[i] & 0xffff0000u);
+    }
+}
+
+template <int L, int U, bool OUT_F32>
+__global__ void __launch_bounds__(256)
+k_spmm_bf16x8(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
+              const float *__restrict__ w, const uint16_t *__restrict__ x, int64_t ldx,
+              const void *addend, int64_t ldadd, void *y, int64_t ldy, int64_t N, int F) {
+    constexpr int kRows = 256 / L;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = (int64_t)lb * kRows + threadIdx.x / L;
+    if (row >= N) return;
+    const int sub = threadIdx.x % L;
+    const int beg = ptr[row], end = ptr[row + 1];
+
+    for (int c = sub * 8; c < F; c += L * 8) {
+        float acc[8];
+        if (addend) {
+            if (OUT_F32) {
+                const float4 *a = reinterpret_cast<const float4 *>((const float *)addend + row * ldadd + c);
+                const float4 a0 = a[0], a1 = a[1];
+                acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w;
+                acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
+            } else {
+                unpack8(*reinterpret_cast<const uint4 *>((const uint16_t *)addend + row * ldadd + c), acc);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+        }
+        for (int p = beg; p < end; p += U) {
+            int s[U];
+            float ww[U];
+            uint4 q[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const bool ok = p + j < end;
+                s[j] = ok ? other[p + j] : 0;
+                ww[j] = ok ? (w ? w[p + j] : 1.0f) : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                q[j] = (p + j < end) ? *reinterpret_cast<const uint4 *>(x + (int64_t)s[j] * ldx + c)
+                                     : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (p + j < end) {
+                    float v[8];
+                    unpack8(q[j], v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float m = ww[j] * v[i];
+                        acc[i] = acc[i] + m;
+                    }
+                }
+        }
+        if (OUT_F32) {
+            float4 *o = reinterpret_cast<float4 *>((float *)y + row * ldy + c);
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else {
+            uint4 o;
+            o.x = f32_to_bf16_rne(acc[0]) | ((uint32_t)f32_to_bf16_rne(acc[1]) << 16);
+            o.y = f32_to_bf16_rne(acc[2]) | ((uint32_t)f32_to_bf16_rne(acc[3]) << 16);
+            o.z = f32_to_bf16_rne(acc[4]) | ((uint32_t)f32_to_bf16_rne(acc[5]) << 16);
+            o.w = f32_to_bf16_rne(acc[6]) | ((uint32_t)f32_to_bf16_rne(acc[7]) << 16);
+            *reinterpret_cast<uint4 *>((uint16_t *)y + row * ldy + c) = o;
+        }
+    }
+}
+
+
+// one wave per PAIR of destination rows, 32 lanes x 8 bf16 (16 bytes) each: every gather
+// instruction still moves 1 KiB, and the bounds / neighbour ids / weights of BOTH rows are
+// wave-uniform scalar loads (the half-wave picks its own with a select), so a pair of edges costs
+// one vector-memory instruction instead of the three of k_spmm_bf16x8.
+template <int U, bool OUT_F32>
+__global__ void __launch_bounds__(256)
+k_spmm_bf16_pair(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
+                 const float *__restrict__ w, const uint16_t *__restrict__ x, int64_t ldx,
+                 const void *addend, int64_t ldadd, void *y, int64_t ldy, int64_t N, int F) {
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = 2 * (int64_t)__builtin_amdgcn_readfirstlane((int)(lb * 4u + (threadIdx.x >> 6)));
+    if (row0 >= N) return;
+    const bool has1 = row0 + 1 < N;
+    const int lane = threadIdx.x & 63;
+    const bool hi = lane >= 32;
+    const int beg0 = ptr[row0], beg1 = ptr[row0 + 1];
+    const int len0 = beg1 - beg0, len1 = has1 ? ptr[row0 + 2] - beg1 : 0;
+    const int lmax = len0 > len1 ? len0 : len1;
+    const int64_t row = row0 + (hi ? 1 : 0);
+    const bool live = !hi || has1;
+
+    for (int c = (lane & 31) * 8; c < F; c += 256) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+        if (addend && live) {
+            if (OUT_F32) {
+                const float4 *a = reinterpret_cast<const float4 *>((const float *)addend + row * ldadd + c);
+                const float4 a0 = a[0], a1 = a[1];
+                acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w;
+                acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
+            } else {
+                unpack8(*reinterpret_cast<const uint4 *>((const uint16_t *)addend + row * ldadd + c), acc);
+            }
+        }
+        for (int t = 0; t < lmax; t += U) {
+            int s[U];
+            float ww[U];
+            bool ok[U];
+            uint4 q[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                int sa = 0, sb = 0;
+                float wa = 0.0f, wb = 0.0f;
+                if (t + j < len0) {              // wave-uniform: scalar loads
+                    sa = other[beg0 + t + j];
+                    wa = w ? w[beg0 + t + j] : 1.0f;
+                }
+                if (t + j < len1) {
+                    sb = other[beg1 + t + j];
+                    wb = w ? w[beg1 + t + j] : 1.0f;
+                }
+                s[j] = hi ? sb : sa;
+                ww[j] = hi ? wb : wa;
+                ok[j] = hi ? (t + j < len1) : (t + j < len0);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (t + j < lmax)
+                    q[j] = ok[j] ? *reinterpret_cast<const uint4 *>(x + (int64_t)s[j] * ldx + c)
+                                 : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (t + j < lmax && ok[j]) {
+                    float v[8];
+                    unpack8(q[j], v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float m = ww[j] * v[i];
+                        acc[i] = acc[i] + m;
+                    }
+                }
+        }
+        if (!live) continue;
+        if (OUT_F32) {
+            float4 *o = reinterpret_cast<float4 *>((float *)y + row * ldy + c);
+            o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else {
+            uint4 o;
+            o.x = f32_to_bf16_rne(acc[0]) | ((uint32_t)f32_to_bf16_rne(acc[1]) << 16);
+            o.y = f32_to_bf16_rne(acc[2]) | ((uint32_t)f32_to_bf16_rne(acc[3]) << 16);
+            o.z = f32_to_bf16_rne(acc[4]) | ((uint32_t)f32_to_bf16_rne(acc[5]) << 16);
+            o.w = f32_to_bf16_rne(acc[6]) | ((uint32_t)f32_to_bf16_rne(acc[7]) << 16);
+            *reinterpret_cast<uint4 *>((uint16_t *)y + row * ldy + c) = o;
+        }
+    }
+}
+
+// any F / alignment: one column per lane and step
+template <int L, int U, bool OUT_F32>
+__global__ void __launch_bounds__(256)
+k_spmm_bf16x1(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
+              const float *__restrict__ w, const uint16_t *__restrict__ x, int64_t ldx,
+              const void *addend, int64_t ldadd, void *y, int64_t ldy, int64_t N, int F) {
+    constexpr int kRows = 256 / L;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = (int64_t)lb * kRows + threadIdx.x / L;
+    if (row >= N) return;
+    const int sub = threadIdx.x % L;
+    const int beg = ptr[row], end = ptr[row + 1];
+    for (int c = sub; c < F; c += L) {
+        float acc = 0.0f;
+        if (addend)
+            acc = OUT_F32 ? ((const float *)addend)[row * ldadd + c]
+                          : bf16_to_f32(((const uint16_t *)addend)[row * ldadd + c]);
+        for (int p = beg; p < end; p += U) {
+            int s[U];
+            float ww[U], v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const bool ok = p + j < end;
+                s[j] = ok ? other[p + j] : 0;
+                ww[j] = ok ? (w ? w[p + j] : 1.0f) : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                v[j] = (p + j < end) ? bf16_to_f32(x[(int64_t)s[j] * ldx + c]) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (p + j < end) {
+                    const float m = ww[j] * v[j];
+                    acc = acc + m;
+                }
+        }
+        if (OUT_F32) ((float *)y)[row * ldy + c] = acc;
+        else ((uint16_t *)y)[row * ldy + c] = f32_to_bf16_rne(acc);
+    }
+}
+
+template <int L, bool X8, bool OUT_F32>
+static void launch_bf16(const int32_t *ptr, const int32_t *other, const float *w, const uint16_t *x,
+                        int64_t ldx, const void *addend, int64_t ldadd, void *y, int64_t ldy,
+                        int64_t N, int F, hipStream_t stream) {
+    constexpr int kRows = 256 / L;
+    const unsigned grid = (unsigned)((N + kRows - 1) / kRows);
+    if (X8)
+        hipLaunchKernelGGL((k_spmm_bf16x8<L, 8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
+                           other, w, x, ldx, addend, ldadd, y, ldy, N, F);
+    else
+        hipLaunchKernelGGL((k_spmm_bf16x1<L, 8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
+                           other, w, x, ldx, addend, ldadd, y, ldy, N, F);
+}
+
+template <bool OUT_F32>
+static void dispatch_bf16(const int32_t *ptr, const int32_t *other, const float *w,
+                          const uint16_t *x, int64_t ldx, const void *addend, int64_t ldadd,
+                          void *y, int64_t ldy, int64_t N, int F, bool x8, hipStream_t stream) {
+    // measured (tools/hop_stress.py, r01): while x sits in L2 / the Infinity Cache the plain
+    // half-wave kernel is as fast or faster (14.3 vs 16.3 us at the everyday shape); once x spills
+    // to HBM the scalar-index row-pair kernel wins (842 vs 990 us at 2.1 M rows)
+    if (x8 && F >= 256 && N * ldx * 2 > (int64_t)128 << 20) {
+        const unsigned grid = (unsigned)((N + 7) / 8);
+        hipLaunchKernelGGL((k_spmm_bf16_pair<8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
+                           other, w, x, ldx, addend, ldadd, y, ldy, N, F);
+    } else if (x8) {
+        const int v = F / 8;
+        if (v > 16) launch_bf16<32, true, OUT_F32>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, stream);
+        else if (v > 8) launch_bf16<16, true, OUT_F32>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, stream);
+        else if (v > 4) launch_bf16<8, true, OUT_F32>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, stream);
+        else launch_bf16<4, true, OUT_F32>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, stream);
+    } else {
+        if (F > 32) launch_bf16<64, false, OUT_F32>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, stream);
+        else if (F > 16) launch_bf16<32, false, OUT_F32>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, stream);
+        else launch_bf16<16, false, OUT_F32>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, stream);
+    }
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -183,4 +445,29 @@ extern "C" int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float
             launch_sub<1, 8, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
     }
     return check_launch("dc_spmm_f32");
+}
+
+
+extern "C" int dc_spmm_bf16(const int32_t *ptr, const int32_t *other, const float *w,
+                            const uint16_t *x, int64_t ldx, const void *addend, int64_t ldadd,
+                            void *y, int64_t ldy, int64_t N, int64_t F, int y_is_f32,
+                            dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(N >= 0 && F >= 0, "dc_spmm_bf16: negative size N=%lld F=%lld", (long long)N,
+               (long long)F);
+    if (N == 0 || F == 0) return DC_OK;
+    DC_REQUIRE(ptr && x && y, "dc_spmm_bf16: null ptr/x/y");
+    DC_REQUIRE(N < (int64_t)INT32_MAX / 8 && F < (1 << 24), "dc_spmm_bf16: size out of range");
+    DC_REQUIRE(ldx >= F && ldy >= F && (!addend || ldadd >= F),
+               "dc_spmm_bf16: leading dimension smaller than F");
+    DC_REQUIRE((const void *)x != (const void *)y, "dc_spmm_bf16: y must not alias x");
+    // 16-byte accesses: 8 bf16 of x; 8 bf16 or 2 x 4 fp32 of y / addend
+    const int64_t ymod = y_is_f32 ? 4 : 8;
+    const bool x8 = (F % 8 == 0) && (ldx % 8 == 0) && aligned16(x) && (ldy % ymod == 0) &&
+                    aligned16(y) && (!addend || ((ldadd % ymod == 0) && aligned16(addend)));
+    if (y_is_f32)
+        dispatch_bf16<true>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, (int)F, x8, stream);
+    else
+        dispatch_bf16<false>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, (int)F, x8, stream);
+    return check_launch("dc_spmm_bf16");
 }

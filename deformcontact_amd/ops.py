@@ -55,6 +55,47 @@ def hop(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = Non
     return out
 
 
+def _rowmajor_any(t: torch.Tensor, what: str, dtypes) -> int:
+    if t.dim() != 2 or t.dtype not in dtypes:
+        raise ValueError(f"{what}: expected a 2-D tensor of {dtypes}, got {tuple(t.shape)} {t.dtype}")
+    if t.size(1) > 1 and t.stride(1) != 1:
+        raise ValueError(f"{what}: innermost dimension must be contiguous")
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+def hop_bf16(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = None,
+             addend: Optional[torch.Tensor] = None, weighted: bool = True,
+             out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """The hop over bf16-stored features with fp32 accumulation (``dc_spmm_bf16``; SURVEY.md 8(d)
+    config 5).  ``x`` is bfloat16; ``out`` / ``addend`` are ``out_dtype`` (bfloat16: the fp32 sum
+    is rounded once on store; float32: the fp32 sum itself)."""
+    _require_cuda(x, "x")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("hop_bf16: out_dtype must be bfloat16 or float32")
+    ldx = _rowmajor_any(x, "x", (torch.bfloat16,))
+    n, f = x.shape
+    if adj.ptr.numel() != n + 1:
+        raise ValueError(f"hop_bf16: x has {n} rows but the graph has {adj.ptr.numel() - 1} nodes")
+    if out is None:
+        out = torch.empty((n, f), dtype=out_dtype, device=x.device)
+    if out.shape != x.shape:
+        raise ValueError("hop_bf16: out shape mismatch")
+    ldy = _rowmajor_any(out, "out", (out_dtype,))
+    lda = 0
+    if addend is not None:
+        if addend.shape != x.shape:
+            raise ValueError("hop_bf16: addend shape mismatch")
+        lda = _rowmajor_any(addend, "addend", (out_dtype,))
+    w = adj.w if weighted else None
+    rc = _lib.lib().dc_spmm_bf16(
+        adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+        x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,
+        out.data_ptr(), ldy, n, f, 1 if out_dtype == torch.float32 else 0,
+        current_stream_ptr(x.device))
+    _lib.check(rc, "dc_spmm_bf16")
+    return out
+
+
 class _HopFn(torch.autograd.Function):
     """Differentiable single hop ``y = A x`` (``A`` = weighted sorted adjacency)."""
 

@@ -93,6 +93,18 @@ int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w, const 
                 int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
                 int64_t N, int64_t F, dc_stream_t stream);
 
+/* The same hop over bf16-STORED feature rows ("bf16 features, fp32
+ * accumulate"; PyG reaches it as conv(x.bfloat16(), edge_index) under autocast, where
+ * index_select/mul/scatter_add_ run in bf16 -- this entry keeps the sum in fp32 instead).
+ * x is bf16 (uint16 bit patterns, row-major, ldx in elements).  Every term is
+ * fp32(w[p]) * fp32(x[other[p]]) with the running sum in fp32, rounded and ordered exactly as
+ * dc_spmm_f32.  y_is_f32 != 0: y / addend are fp32 and receive the fp32 sum; y_is_f32 == 0:
+ * y / addend are bf16 and the sum is rounded ONCE, to nearest even, on store.  Half the gather
+ * bytes of the fp32 hop: algorithmic bytes E*(8 + 2F) + N*(sizeof(y)*F + 4). */
+int dc_spmm_bf16(const int32_t *ptr, const int32_t *other, const float *w, const uint16_t *x,
+                 int64_t ldx, const void *addend, int64_t ldadd, void *y, int64_t ldy, int64_t N,
+                 int64_t F, int y_is_f32, dc_stream_t stream);
+
 /* ---- K chained hops in one launch (block-diagonal batches) -------------------
  * TAGConv.forward calls propagate K = 3 times in a row (x_k = A_hat x_{k-1}); its backward runs
  * the chain g_{k-1} = G_{k-1} + A_hat^T g_k.  For a batch whose nodes split into segments no edge

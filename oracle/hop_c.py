@@ -63,3 +63,20 @@ def hop(edge_index: np.ndarray, w: np.ndarray, x: np.ndarray) -> np.ndarray:
                   ctypes.c_int64(f), ctypes.c_int64(ei.shape[1]), ctypes.c_int64(n),
                   ctypes.c_int64(f), _p(y, ctypes.c_float), ctypes.c_int64(f))
     return y
+
+
+def hop_bf16(edge_index: np.ndarray, w, x_bits: np.ndarray, out_f32: bool) -> np.ndarray:
+    """``x_bits``: uint16 bf16 bit patterns [N,F]; returns fp32 [N,F] or uint16 bit patterns."""
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    x_bits = np.ascontiguousarray(x_bits, dtype=np.uint16)
+    n, f = x_bits.shape
+    y = np.empty((n, f), np.float32 if out_f32 else np.uint16)
+    wp = None
+    if w is not None:
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        wp = _p(w, ctypes.c_float)
+    lib().ref_hop_bf16(_p(ei, ctypes.c_int64), wp, _p(x_bits, ctypes.c_uint16), ctypes.c_int64(f),
+                       ctypes.c_int64(ei.shape[1]), ctypes.c_int64(n), ctypes.c_int64(f),
+                       y.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(f),
+                       ctypes.c_int(1 if out_f32 else 0))
+    return y

@@ -79,6 +79,39 @@ void ref_hop(const int64_t *edge_index, const float *w, const float *x, int64_t 
     }
 }
 
+/* bf16-stored features, fp32 accumulation: every term is
+ * fp32(w_e) * fp32(x[row_e,f]) added to an fp32 running sum in edge order; y_is_f32 selects an
+ * fp32 result or ONE round-to-nearest-even to bf16 at the end. */
+static float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+void ref_hop_bf16(const int64_t *edge_index, const float *w, const uint16_t *x, int64_t ldx,
+                  int64_t E, int64_t N, int64_t F, void *y, int64_t ldy, int y_is_f32)
+{
+    const int64_t *row = edge_index, *col = edge_index + E;
+    float *acc = (float *)calloc((size_t)(N * F > 0 ? N * F : 1), sizeof(float));
+    for (int64_t e = 0; e < E; ++e) {
+        const uint16_t *xs = x + row[e] * ldx;
+        float *yd = acc + col[e] * F;
+        const float we = w ? w[e] : 1.0f;
+        for (int64_t f = 0; f < F; ++f) {
+            volatile float m = we * bf16_to_f32(xs[f]);
+            yd[f] += m;
+        }
+    }
+    for (int64_t i = 0; i < N; ++i)
+        for (int64_t f = 0; f < F; ++f) {
+            if (y_is_f32) ((float *)y)[i * ldy + f] = acc[i * F + f];
+            else ((uint16_t *)y)[i * ldy + f] = f32_to_bf16_rne(acc[i * F + f]);
+        }
+    free(acc);
+}
+
 /* out[N,Fo] = sum_k xs[k][N,Fi] . W[k][Fo,Fi]^T + b ; K1 = K+1 operand pairs */
 void ref_tag_linear(const float *const *xs, const float *const *Ws, const float *b,
                     int K1, int64_t N, int64_t Fi, int64_t Fo, float *out)

@@ -118,6 +118,90 @@ def test_hop_bit_exact_vs_c_oracle(n, e, f):
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
 
 
+def _bf16_bits(t: torch.Tensor) -> np.ndarray:
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("n,e,f", [(300, 3000, 256), (57, 400, 21), (129, 900, 64), (40, 300, 264),
+                                   (33, 200, 1), (64, 700, 8), (500, 9000, 16), (40, 300, 1024)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_hop_bf16_storage_bit_exact_vs_c_oracle(n, e, f, out_f32):
+    """bf16-stored features, fp32 accumulation; bit-exact (fp32 result,
+    or the bf16 bit patterns after the single final rounding)."""
+    ei = random_multigraph(n, e, n + f + 5)
+    xb = torch.from_numpy(hashed_uniform((n, f), f + 3, 2.0)).to(DEV).bfloat16()
+    g = GraphIndex(torch.from_numpy(ei).to(DEV), n)
+    w_dev = np.zeros(e, np.float32)
+    w_dev[_np(g.fwd.perm)[:e]] = _np(g.fwd.w)[:e]
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    y = ops.hop_bf16(g.fwd, xb, out_dtype=odt)
+    yc = hop_c.hop_bf16(ei, w_dev, _bf16_bits(xb), out_f32)
+    got = _np(y) if out_f32 else _bf16_bits(y)
+    assert np.array_equal(got, yc)
+    # unweighted (w == NULL) and the fp32 result agrees with the fp32 hop on the widened rows
+    y1 = ops.hop_bf16(g.fwd, xb, weighted=False, out_dtype=torch.float32)
+    assert torch.equal(y1, ops.hop(g.fwd, xb.float(), weighted=False))
+
+
+def test_hop_bf16_strided_views_addend_and_errors():
+    n, e, f = 200, 1500, 256
+    ei = random_multigraph(n, e, 11)
+    g = GraphIndex(torch.from_numpy(ei).to(DEV), n)
+    slab = torch.from_numpy(hashed_uniform((n, 3 * f), 9, 2.0)).to(DEV).bfloat16()
+    x = slab[:, f:2 * f]
+    ref32 = ops.hop_bf16(g.fwd, x.contiguous(), out_dtype=torch.float32)
+    out = slab[:, 2 * f:]
+    add = out.clone()
+    ops.hop_bf16(g.fwd, x, out=out)                                  # strided bf16 in / out
+    assert torch.equal(out, ref32.bfloat16())
+    ops.hop_bf16(g.fwd, x, out=out, addend=add)                      # y = bf16(add + A x)
+    add32 = add.float()
+    exp = ops.hop(g.fwd, x.float(), addend=add32)                    # same fp32 running sum
+    assert torch.equal(out, exp.bfloat16())
+    o32 = ops.hop_bf16(g.fwd, x, addend=add32, out_dtype=torch.float32)
+    assert torch.equal(o32, exp)
+    with pytest.raises(ValueError):
+        ops.hop_bf16(g.fwd, x.float())
+    with pytest.raises(Exception):
+        ops.hop_bf16(g.fwd, x, out=x)
+    # isolated nodes / empty rows give exact zeros
+    g0 = GraphIndex(torch.zeros((2, 0), dtype=torch.int64, device=DEV), 5)
+    z = ops.hop_bf16(g0.fwd, torch.ones(5, 24, device=DEV).bfloat16())
+    assert z.dtype == torch.bfloat16 and not z.any()
+
+
+def test_hop_bf16_beyond_cache_row_pair_kernel_and_radius_graph():
+    """The row-pair kernel that takes over once x exceeds 128 MiB (odd N: the last pair is half
+    empty), bit-exact against the C oracle; and BASELINE configs[4]: the 100k-point radius graph
+    with bf16 features equals the fp32 hop over the widened rows bit for bit."""
+    n, f = 270_001, 256
+    rng = np.random.default_rng(5)
+    e = 6 * n
+    src = rng.integers(0, n, e)
+    dst = np.minimum(n - 1, (src + rng.integers(-40, 41, e)).clip(0))       # banded, like a mesh
+    ei = np.stack([src, dst]).astype(np.int64)
+    g = GraphIndex(torch.from_numpy(ei).to(DEV), n)
+    xb = (torch.rand(n, f, device=DEV) * 2 - 1).bfloat16()
+    assert xb.numel() * 2 > 128 << 20
+    w_dev = np.zeros(e, np.float32)
+    w_dev[_np(g.fwd.perm)[:e]] = _np(g.fwd.w)[:e]
+    for out_f32 in (False, True):
+        y = ops.hop_bf16(g.fwd, xb, out_dtype=torch.float32 if out_f32 else torch.bfloat16)
+        yc = hop_c.hop_bf16(ei, w_dev, _bf16_bits(xb), out_f32)
+        assert np.array_equal(_np(y) if out_f32 else _bf16_bits(y), yc)
+    add = torch.rand(n, f, device=DEV)
+    assert torch.equal(ops.hop_bf16(g.bwd, xb, addend=add, out_dtype=torch.float32),
+                       ops.hop(g.bwd, xb.float(), addend=add))
+    del g, xb, add, y
+    from deformcontact_amd import synth
+    pos, ei = synth.radius_graph_points(100_000, radius=0.02, max_num_neighbors=32)
+    g = GraphIndex(ei.to(DEV), pos.shape[0])
+    xb = (torch.rand(pos.shape[0], f, device=DEV) * 2 - 1).bfloat16()
+    y32 = ops.hop_bf16(g.fwd, xb, out_dtype=torch.float32)
+    assert torch.equal(y32, ops.hop(g.fwd, xb.float()))
+    assert torch.equal(ops.hop_bf16(g.fwd, xb), y32.bfloat16())
+
+
 def test_hop_strided_views_and_addend():
     n, e, f = 200, 1500, 256
     ei = random_multigraph(n, e, 3)

@@ -139,3 +139,24 @@ def test_c_csr_property_random_graphs():
             assert np.allclose(w, dis[ei[0]] * dis[ei[1]], rtol=1e-6)
 
     check()
+
+
+def test_bf16_hop_oracle_against_float64_and_fp32_oracle():
+    """ref_hop_bf16: the fp32 result equals ref_hop over the widened rows bit
+    for bit; the bf16 result is that sum rounded once to nearest even; both agree with float64."""
+    n, e, f = 120, 900, 40
+    ei = random_multigraph(n, e, 77)
+    w = hop_c.gcn_norm(ei, n)
+    xb = torch.from_numpy(hashed_uniform((n, f), 5, 2.0)).bfloat16()
+    bits = xb.view(torch.int16).numpy().view(np.uint16)
+    wide = xb.float().numpy()
+    y32 = hop_c.hop_bf16(ei, w, bits, True)
+    assert np.array_equal(y32, hop_c.hop(ei, w, wide))
+    y16 = hop_c.hop_bf16(ei, w, bits, False)
+    exp16 = torch.from_numpy(y32).bfloat16().view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(y16, exp16)
+    dense = np.zeros((n, n))
+    np.add.at(dense, (ei[1], ei[0]), w.astype(np.float64))
+    assert rel_err(y32, dense @ wide.astype(np.float64)) < 1e-6
+    ones = hop_c.hop_bf16(ei, None, bits, True)                  # w == NULL: weight 1
+    assert np.array_equal(ones, hop_c.hop(ei, np.ones(e, np.float32), wide))

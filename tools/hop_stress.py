@@ -34,6 +34,17 @@ def report(name, g, n, e, f, dev):
     msb = timeit(lambda: ops.hop(g.bwd, x, out=y, addend=y), 10)
     print(f"{'':{len(name)}}  transposed + addend: {msb * 1e3:9.1f} us  algorithmic "
           f"{(alg + n * 4 * f) / msb / 1e6:8.0f} GB/s")
+    # bf16-stored features, fp32 accumulate (configs[4] / SURVEY 8(d) config 5)
+    xb = x.bfloat16()
+    for odt, ob in ((torch.bfloat16, 2), (torch.float32, 4)):
+        yb = torch.empty(n, f, device=dev, dtype=odt)
+        msh = timeit(lambda: ops.hop_bf16(g.fwd, xb, out=yb, out_dtype=odt), 10)
+        algb = e * (8 + 2 * f) + n * (ob * f + 4)
+        compb = e * 8 + n * ((2 + ob) * f + 4)
+        print(f"{'':{len(name)}}  bf16 x -> {str(odt)[6:]:8s}: {msh * 1e3:9.1f} us  algorithmic "
+              f"{algb / msh / 1e6:8.0f} GB/s ({algb / msh / 1e6 / 8000:.2f})  compulsory "
+              f"{compb / msh / 1e6:8.0f} GB/s ({compb / msh / 1e6 / 8000:.2f})  "
+              f"{e / msh / 1e6:7.2f} G edge-hops/s (fp32: {e / ms / 1e6:7.2f})")
 
 
 def main():
@@ -50,6 +61,10 @@ def main():
     pos, ei = synth.radius_graph_points(100_000, radius=0.02, max_num_neighbors=32)
     g = GraphIndex(ei.to(dev), pos.shape[0])
     report("radius graph 100k", g, pos.shape[0], ei.shape[1], 256, dev)
+    del g
+    rest, rig, _ = synth.make_batch(32)
+    g = GraphIndex(rest.edge_index.to(dev), rest.x.shape[0])
+    report("everyday B=32 soft", g, rest.x.shape[0], rest.edge_index.shape[1], 256, dev)
 
 
 if __name__ == "__main__":
