@@ -50,6 +50,19 @@ _SIGNATURES = {
                                            POINTER(c_int64), c_int, POINTER(_vp), c_int, c_int64,
                                            _vp, c_int, _vp, c_int64, c_int64, c_int64, c_int64,
                                            c_int, _vp]),
+    "dc_tag_linear_fwd_h2": (c_int, [POINTER(_vp), POINTER(c_int64), POINTER(_vp), c_int, _vp,
+                                     c_int, _vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp, _vp]),
+    "dc_tag_linear_bwd_dx_h2": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp), c_int,
+                                        POINTER(_vp), POINTER(c_int64), _vp, c_int64, c_int64,
+                                        c_int64, c_int64, _vp, _vp, _vp]),
+    "dc_tag_linear_bwd_dw_h2": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp),
+                                        POINTER(c_int64), c_int, POINTER(_vp), c_int, c_int64,
+                                        _vp, c_int, _vp, c_int64, c_int64, c_int64, c_int64,
+                                        _vp, _vp, _vp]),
+    "dc_rowabsmax_f32": (c_int, [_vp, c_int64, c_int64, c_int64, _vp, _vp]),
+    "dc_tag_weight_rowmax": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp]),
+    "dc_spmm_f32_rowmax": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
+                                   c_int64, _vp, c_int, _vp]),
     "dc_tag_pack_input": (c_int, [_vp, c_int64, _vp, c_int64, c_int64, c_int64, c_int64, c_int64, _vp]),
     "dc_tag_pack_weights": (c_int, [POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp]),
     "dc_adam_flat": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_float, c_float, c_float, c_float,

@@ -97,6 +97,36 @@ __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[MB][2], int wm,
             }
 }
 
+// Power-of-two operand scaling of the fp16x2 ("h2") kernels: an operand row / tensor whose
+// largest magnitude is m is multiplied by 2^(141 - e(m)) (e = biased fp32 exponent, clamped to
+// >= 15) so that it lands in [2^14, 2^15) - inside the fp16 range with 2x headroom - and the
+// accumulator is multiplied back by 2^(e(m) - 141); both factors are exact.
+struct H2Scales {
+    const float *a_rowmax;   // fwd: [N] max |x[row, :]| over all segments; dX, dW: [N] max |g[row, :]|
+    const float *b_rowmax;   // fwd / dX: [Fo] max_s,f |W_s[o, f]|;  dW: [N] max |x[row, :]|
+};
+
+__device__ __forceinline__ unsigned h2_exp(float m) {
+    unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
+    e = e < 15u ? 15u : e;
+    return e > 254u ? 254u : e;
+}
+__device__ __forceinline__ float h2_scale(float m) { return __uint_as_float((268u - h2_exp(m)) << 23); }
+__device__ __forceinline__ float h2_unscale(float m) { return __uint_as_float((h2_exp(m) - 14u) << 23); }
+
+// max of v[beg..end) over a 256-thread block (every thread gets the result); `red` = 4 floats of LDS
+__device__ __forceinline__ float h2_block_max(const float *v, int64_t beg, int64_t end, float *red) {
+    float m = 0.f;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) m = fmaxf(m, v[i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return m;
+}
+
 struct FwdParams {
     Mat x[kMaxSeg];
     Mat w[kMaxSeg];
@@ -104,6 +134,7 @@ struct FwdParams {
     float *out;
     int64_t ldo, N, Fi, Fo;
     int nseg, relu;
+    H2Scales h2;
 };
 
 struct DxParams {
@@ -114,6 +145,7 @@ struct DxParams {
     int64_t ldgx[kMaxSeg];
     int64_t N, Fi, Fo;
     int nseg;
+    H2Scales h2;
 };
 
 struct DwParams {
@@ -124,6 +156,7 @@ struct DwParams {
     float *bias_partial;   // [nchunks][Fo] or null
     int64_t N, Fi, Fo, chunk_rows;
     int nseg, nchunks;
+    H2Scales h2;
 };
 
 
@@ -131,7 +164,8 @@ struct DwParams {
 bool fwd_fast_launch(const FwdParams &p, int mb, hipStream_t hs);
 bool dx_fast_launch(const DxParams &p, int mb, hipStream_t hs);
 bool dw_fast_launch(const DwParams &p, int mb, hipStream_t hs);
-// split-bf16 (fp32-accurate, 6 bf16 MFMA products) launchers (dc_dense_split.hip)
+// split launchers (dc_dense_split.hip): products = 6 / 3 / 1 bf16 planes, or 2 = the scaled
+// fp16x2 mode (two fp16 planes, 3 MFMA products, fp32-accurate; needs p.h2)
 bool fwd_split_launch(const FwdParams &p, int mb, int products, hipStream_t hs);
 bool dx_split_launch(DxParams p, float *wt, int mb, int products, hipStream_t hs);
 bool dw_split_launch(const DwParams &p, int mb, int products, hipStream_t hs);

@@ -466,7 +466,7 @@ using namespace dc;
 
 static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *const *ws, int nseg,
                     const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t Fi,
-                    int64_t Fo, dc_stream_t stream, int products) {
+                    int64_t Fo, dc_stream_t stream, int products, H2Scales h2 = H2Scales{}) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_fwd: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_fwd: bad sizes");
     if (N == 0) return DC_OK;
@@ -480,6 +480,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     }
     p.bias = bias, p.out = out, p.ldo = ldo, p.N = N, p.Fi = Fi, p.Fo = Fo;
     p.nseg = nseg, p.relu = relu;
+    p.h2 = h2;
     const int64_t ntn = (Fo + BN - 1) / BN;
     const int mb = pick_mb(N, ntn);
     const int64_t grid = ((N + 64 * mb - 1) / (64 * mb)) * ntn;
@@ -488,6 +489,8 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     hipStream_t hs = (hipStream_t)stream;
     if (products && vec && fwd_split_launch(p, split_mb(N, ntn), products, hs))
         return check_launch("dc_tag_linear_fwd_split");
+    DC_REQUIRE(products != 2, "dc_tag_linear_fwd_h2: needs Fi %% 16 == 0, 16-byte aligned operands, "
+                              "equal leading dimensions (Fi=%lld)", (long long)Fi);
     if (use_fast() && vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
     if (mb == 2 && vec)
         hipLaunchKernelGGL((k_tag_linear_fwd<2, true>), gd, bd, 0, hs, p);
@@ -503,7 +506,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
 static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
                    const float *const *ws, int nseg, float *const *gxs, const int64_t *ldgxs,
                    int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream, float *split_ws,
-                   int products) {
+                   int products, H2Scales h2 = H2Scales{}) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dx: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dx: bad sizes");
     if (N == 0) return DC_OK;
@@ -521,6 +524,7 @@ static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
         p.ldgx[s] = ldgxs[s];
     }
     p.N = N, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg;
+    p.h2 = h2;
     const int64_t ntn = ((Fi + BN - 1) / BN) * nseg;
     const int mb = pick_mb(N, ntn);
     const int64_t grid = ((N + 64 * mb - 1) / (64 * mb)) * ntn;
@@ -530,6 +534,8 @@ static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     hipStream_t hs = (hipStream_t)stream;
     if (split_ws && vec && dx_split_launch(p, split_ws, split_mb(N, ntn), products, hs))
         return check_launch("dc_tag_linear_bwd_dx_split");
+    DC_REQUIRE(products != 2, "dc_tag_linear_bwd_dx_h2: needs Fo %% 16 == 0, Fi %% 4 == 0 and 16-byte "
+                              "aligned operands (Fi=%lld Fo=%lld)", (long long)Fi, (long long)Fo);
     if (use_fast() && vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
 #define DC_DX(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) {
@@ -615,7 +621,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
                    const float *const *xs, const int64_t *ldxs, int nseg, float *const *gws, int ngw,
                    int64_t gw_cols, float *gbias, int accumulate, void *partials,
                    int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream,
-                   int products) {
+                   int products, H2Scales h2 = H2Scales{}) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dw: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dw: bad sizes");
     DC_REQUIRE(g && xs && ldxs && gws && partials && ldg >= Fo,
@@ -644,6 +650,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     }
     dw_plan(N, Fi, Fo, nseg, &p.chunk_rows, &p.nchunks);
     p.N = N, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg;
+    p.h2 = h2;
     p.partial = (float *)partials;
     p.bias_partial = gbias ? p.partial + (int64_t)p.nchunks * nseg * Fo * Fi : nullptr;
     const int mb = dw_mb(Fo);
@@ -652,8 +659,10 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     if (!p.has_mask) p.mask = p.g;
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
-    bool fast_done = (products && vec && dw_split_launch(p, mb, products, hs)) ||
-                     (use_fast() && vec && dw_fast_launch(p, mb, hs));
+    bool fast_done = products && vec && dw_split_launch(p, mb, products, hs);
+    DC_REQUIRE(fast_done || products != 2, "dc_tag_linear_bwd_dw_h2: needs N %% 16 == 0, Fi %% 4 == 0, "
+               "Fo %% 4 == 0 and 16-byte aligned operands (N=%lld)", (long long)N);
+    fast_done = fast_done || (use_fast() && vec && dw_fast_launch(p, mb, hs));
 #define DC_DW(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (fast_done) {
     } else
@@ -698,4 +707,117 @@ extern "C" int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const flo
                "dc_tag_linear_bwd_dw_split: products must be 6, 3 or 1");
     return dw_impl(g, ldg, out_for_mask, ldo, xs, ldxs, nseg, gws, ngw, gw_cols, gbias, accumulate,
                    partials, partials_bytes, N, Fi, Fo, stream, products);
+}
+
+
+// ---- fp16x2 ("h2") entry points: two scaled fp16 planes, 3 MFMA products -------------------
+extern "C" int dc_tag_linear_fwd_h2(const float *const *xs, const int64_t *ldxs,
+                                    const float *const *ws, int nseg, const float *bias, int relu,
+                                    float *out, int64_t ldo, int64_t N, int64_t Fi, int64_t Fo,
+                                    const float *x_rowmax, const float *w_rowmax,
+                                    dc_stream_t stream) {
+    DC_REQUIRE(x_rowmax && w_rowmax, "dc_tag_linear_fwd_h2: x_rowmax / w_rowmax missing");
+    H2Scales h{};
+    h.a_rowmax = x_rowmax, h.b_rowmax = w_rowmax;
+    return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, 2, h);
+}
+
+extern "C" int dc_tag_linear_bwd_dx_h2(const float *g, int64_t ldg, const float *out_for_mask,
+                                       int64_t ldo, const float *const *ws, int nseg,
+                                       float *const *gxs, const int64_t *ldgxs, void *workspace,
+                                       int64_t workspace_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                                       const float *g_rowmax, const float *w_rowmax,
+                                       dc_stream_t stream) {
+    DC_REQUIRE(w_rowmax && g_rowmax, "dc_tag_linear_bwd_dx_h2: g_rowmax / w_rowmax missing");
+    DC_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 &&
+                   workspace_bytes >= dc_tag_linear_bwd_dx_split_workspace_bytes(Fi, Fo, nseg),
+               "dc_tag_linear_bwd_dx_h2: workspace missing, misaligned or too small");
+    H2Scales h{};
+    h.a_rowmax = g_rowmax, h.b_rowmax = w_rowmax;
+    return dx_impl(g, ldg, out_for_mask, ldo, ws, nseg, gxs, ldgxs, N, Fi, Fo, stream,
+                   (float *)workspace, 2, h);
+}
+
+extern "C" int dc_tag_linear_bwd_dw_h2(const float *g, int64_t ldg, const float *out_for_mask,
+                                       int64_t ldo, const float *const *xs, const int64_t *ldxs,
+                                       int nseg, float *const *gws, int ngw, int64_t gw_cols,
+                                       float *gbias, int accumulate, void *partials,
+                                       int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                                       const float *g_rowmax, const float *x_rowmax,
+                                       dc_stream_t stream) {
+    DC_REQUIRE(g_rowmax && x_rowmax, "dc_tag_linear_bwd_dw_h2: g_rowmax / x_rowmax missing");
+    H2Scales h{};
+    h.a_rowmax = g_rowmax, h.b_rowmax = x_rowmax;
+    return dw_impl(g, ldg, out_for_mask, ldo, xs, ldxs, nseg, gws, ngw, gw_cols, gbias, accumulate,
+                   partials, partials_bytes, N, Fi, Fo, stream, 2, h);
+}
+
+namespace dc {
+// rowmax[i] = max |x[i, 0:F]| : one wave per row
+__global__ void __launch_bounds__(256)
+k_rowabsmax(const float *__restrict__ x, int64_t ld, int64_t N, int F, float *__restrict__ rowmax,
+            bool vec4) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float *xr = x + row * ld;
+    float m = 0.f;
+    if (vec4) {
+        for (int c = lane * 4; c < F; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(xr + c);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    } else {
+        for (int c = lane; c < F; c += 64) m = fmaxf(m, fabsf(xr[c]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) rowmax[row] = m;
+}
+
+// out[o] = max over segments s and columns f of |W_s[o, f]| : one wave per output row
+struct WRowmaxParams {
+    const float *w[kMaxSeg];
+    int nseg;
+    int64_t Fo, Fi;
+    float *out;
+};
+__global__ void __launch_bounds__(256) k_w_rowmax(WRowmaxParams p) {
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= p.Fo) return;
+    const int lane = threadIdx.x & 63;
+    float m = 0.f;
+    for (int s = 0; s < p.nseg; ++s) {
+        const float *wr = p.w[s] + o * p.Fi;
+        for (int64_t c = lane; c < p.Fi; c += 64) m = fmaxf(m, fabsf(wr[c]));
+    }
+#pragma unroll
+    for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
+    if (lane == 0) p.out[o] = m;
+}
+}  // namespace dc
+
+extern "C" int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
+                                dc_stream_t stream) {
+    DC_REQUIRE(N >= 0 && F >= 1 && F < (1 << 24) && ld >= F, "dc_rowabsmax_f32: bad sizes");
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(x && rowmax, "dc_rowabsmax_f32: null pointer");
+    const bool vec4 = (F % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) & 15) == 0;
+    hipLaunchKernelGGL(k_rowabsmax, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, ld, N, (int)F, rowmax, vec4);
+    return check_launch("dc_rowabsmax_f32");
+}
+
+extern "C" int dc_tag_weight_rowmax(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,
+                                    float *w_rowmax, dc_stream_t stream) {
+    DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && Fo >= 1 && Fi >= 1 && ws && w_rowmax,
+               "dc_tag_weight_rowmax: bad arguments");
+    WRowmaxParams p{};
+    for (int s = 0; s < nseg; ++s) {
+        DC_REQUIRE(ws[s], "dc_tag_weight_rowmax: null segment %d", s);
+        p.w[s] = ws[s];
+    }
+    p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.out = w_rowmax;
+    hipLaunchKernelGGL(k_w_rowmax, dim3((unsigned)((Fo + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dc_tag_weight_rowmax");
 }

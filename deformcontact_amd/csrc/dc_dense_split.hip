@@ -29,11 +29,34 @@ constexpr int kPlane = 32;                // bytes per plane inside a row (16 bf
 
 // NP = number of bf16 MFMA products per tile: 6 = fp32-accurate (hi, mid, lo planes),
 // 3 = hi/mid planes, products hi*hi + hi*mid + mid*hi (~4e-6 relative), 1 = plain bf16.
+//
+// NP = 2 is the fp16x2 ("h2") mode: each operand is first multiplied by an exact power of two
+// that puts its row / tensor maximum in [2^14, 2^15) (dc_dense.h: H2Scales) and then written as
+// TWO fp16 planes, x*s = h1 + h2 + O(2^-23 |x*s|)  (11 + 11 significant bits + the sign of the
+// remainder; v_mfma_f32_32x32x16_f16 honours fp16 denormals, so elements down to 2^-39 of the
+// maximum keep absolute accuracy).  THREE products h1*h1 + h1*h2 + h2*h1 then carry the fp32
+// product to 2^-22 relative (simulated: 8e-8 on the dense block, below the 4e-7 of fp32
+// accumulation) at half the matrix work of the 6-product bf16 form.
 template <int NP> struct Planes {
-    static_assert(NP == 6 || NP == 3 || NP == 1, "products per tile: 6, 3 or 1");
-    static constexpr int P = NP == 6 ? 3 : (NP == 3 ? 2 : 1);
+    static_assert(NP == 6 || NP == 3 || NP == 1 || NP == 2, "products per tile: 6, 3, 1 or 2 (= fp16x2)");
+    static constexpr bool F16 = NP == 2;
+    static constexpr int P = NP == 6 ? 3 : ((NP == 3 || NP == 2) ? 2 : 1);
+    static constexpr int NPROD = NP == 2 ? 3 : NP;
     static constexpr int SROW = P * kPlane + 16;     // 112 / 80 / 48 B: conflict-free b128 reads
 };
+
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+__device__ __forceinline__ void split4_h2(const float4 &v, f16x4 &h, f16x4 &l) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 a = (_Float16)x[i];
+        h[i] = a;
+        l[i] = (_Float16)(x[i] - (float)a);          // remainder is exact in fp32
+    }
+}
 
 __device__ __forceinline__ void split1(float x, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
     hi = (__bf16)x;
@@ -61,6 +84,7 @@ struct SplitOp {
     float4 v[NV];
     float4 m[MASK ? NV : 1];
     int off[NV];                                     // LDS byte offsets of the hi plane
+    float sc[NV];                                    // fp16x2 mode: power-of-two scale of row j
 
     __device__ __forceinline__ void init(const float *base, const float *mbase, int64_t ld,
                                          int64_t row0, int64_t nrows) {
@@ -96,12 +120,24 @@ struct SplitOp {
             if (MASK)
                 x = make_float4(m[j].x > 0.f ? x.x : 0.f, m[j].y > 0.f ? x.y : 0.f,
                                 m[j].z > 0.f ? x.z : 0.f, m[j].w > 0.f ? x.w : 0.f);
+            if (Planes<NP>::F16) {
+                x = make_float4(x.x * sc[j], x.y * sc[j], x.z * sc[j], x.w * sc[j]);
+                f16x4 h, l;
+                split4_h2(x, h, l);
+                *reinterpret_cast<f16x4 *>(lds + off[j]) = h;
+                *reinterpret_cast<f16x4 *>(lds + off[j] + kPlane) = l;
+                continue;
+            }
             bf16x4 hi, mid, lo;
             split4(x, hi, mid, lo);
             *reinterpret_cast<bf16x4 *>(lds + off[j]) = hi;
             if (P > 1) *reinterpret_cast<bf16x4 *>(lds + off[j] + kPlane) = mid;
             if (P > 2) *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * kPlane) = lo;
         }
+    }
+    __device__ __forceinline__ void set_scale(float s) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) sc[j] = s;
     }
 };
 
@@ -136,16 +172,23 @@ __device__ __forceinline__ void mma_split(const SplitFrag<MB, NP> &f, f32x16 (&a
     constexpr int HI = 0, MID = 1, LO = 2;
     constexpr int pa6[6] = {LO, HI, MID, MID, HI, HI}, pb6[6] = {HI, LO, MID, HI, MID, HI};
     constexpr int pa3[3] = {MID, HI, HI}, pb3[3] = {HI, MID, HI};
+    constexpr int NPROD = Planes<NP>::NPROD;
 #pragma unroll
-    for (int t = 0; t < NP; ++t) {
-        const int ia = NP == 6 ? pa6[t] : (NP == 3 ? pa3[t] : HI);
-        const int ib = NP == 6 ? pb6[t] : (NP == 3 ? pb3[t] : HI);
+    for (int t = 0; t < NPROD; ++t) {
+        const int ia = NPROD == 6 ? pa6[t] : (NPROD == 3 ? pa3[t] : HI);
+        const int ib = NPROD == 6 ? pb6[t] : (NPROD == 3 ? pb3[t] : HI);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mb][ia], f.b[nb][ib],
-                                                                      acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < 2; ++nb) {
+                if (Planes<NP>::F16)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, f.a[mb][ia]), __builtin_bit_cast(f16x8, f.b[nb][ib]),
+                        acc[mb][nb], 0, 0, 0);
+                else
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mb][ia], f.b[nb][ib],
+                                                                          acc[mb][nb], 0, 0, 0);
+            }
     }
 }
 
@@ -201,6 +244,25 @@ k_fwd_split(FwdParams p) {
     SplitOp<BN, false, NP> B;
     A.init(p.x[0].p, nullptr, p.x[0].ld, row0, p.N);
     B.init(p.w[0].p, nullptr, p.Fi, col0, p.Fo);
+    constexpr bool F16 = Planes<NP>::F16;
+    __shared__ float s_inv[F16 ? BM : 1];           // fp16x2: per-row unscale factors
+    if (F16) {
+        const int r = threadIdx.x >> 2;
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j) {
+            int64_t row = row0 + r + 64 * j;
+            row = row < p.N ? row : p.N - 1;
+            const float m = p.h2.a_rowmax[row];
+            A.sc[j] = h2_scale(m);
+            if ((threadIdx.x & 3) == 0) s_inv[r + 64 * j] = h2_unscale(m);
+        }
+#pragma unroll
+        for (int j = 0; j < BN / 64; ++j) {          // B rows = output columns: one scale each
+            int64_t col = col0 + r + 64 * j;
+            col = col < p.Fo ? col : p.Fo - 1;
+            B.sc[j] = h2_scale(p.h2.b_rowmax[col]);
+        }
+    }
     const int kst = (int)(p.Fi / BK), nst = kst * p.nseg;
     int kk = 0, seg = 0;
     auto next_stage = [&]() {
@@ -213,16 +275,18 @@ k_fwd_split(FwdParams p) {
     };
     split_loop<MB, NP>(lds, nst, A, B, next_stage, acc, wm, wn);
 
-    float bcol[2];
+    float bcol[2], icol[2] = {1.f, 1.f};
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int64_t col = col0 + wn * 64 + nb * 32 + (threadIdx.x & 31);
         bcol[nb] = (p.bias && col < p.Fo) ? p.bias[col] : 0.f;
+        if (F16) icol[nb] = h2_unscale(p.h2.b_rowmax[col < p.Fo ? col : p.Fo - 1]);
     }
     const bool relu = p.relu != 0;
     for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
         const int64_t row = row0 + r, col = col0 + c;
         if (row < p.N && col < p.Fo) {
+            if (F16) v = (v * s_inv[r]) * icol[(c >> 5) & 1];
             v += bcol[(c >> 5) & 1];
             if (relu) v = fmaxf(v, 0.f);
             p.out[row * p.ldo + col] = v;
@@ -250,11 +314,30 @@ k_dx_split(DxParams p) {
     SplitOp<BN, false, NP> B;
     A.init(p.g.p, p.mask.p, p.g.ld, row0, p.N);
     B.init(p.w[s].p, nullptr, p.Fo, col0, p.Fi);
+    constexpr bool F16 = Planes<NP>::F16;
+    __shared__ float s_inv[F16 ? BM : 1];
+    float invb = 1.f;
+    if (F16) {
+        const int r = threadIdx.x >> 2;
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j) {
+            int64_t row = row0 + r + 64 * j;
+            row = row < p.N ? row : p.N - 1;
+            const float m = p.h2.a_rowmax[row];      // >= max |(g * relu')[row, :]|
+            A.sc[j] = h2_scale(m);
+            if ((threadIdx.x & 3) == 0) s_inv[r + 64 * j] = h2_unscale(m);
+        }
+        // B = W^T: one scale for the whole weight tensor, the max of the [Fo] row maxima
+        const float bm = h2_block_max(p.h2.b_rowmax, 0, p.Fo, reinterpret_cast<float *>(lds));
+        B.set_scale(h2_scale(bm));
+        invb = h2_unscale(bm);
+    }
     split_loop<MB, NP>(lds, (int)(p.Fo / BK), A, B, []() {}, acc, wm, wn);
     float *out = p.gx[s];
     const int64_t ldo = p.ldgx[s];
     for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
         const int64_t row = row0 + r, col = col0 + c;
+        if (F16) v = (v * s_inv[r]) * invb;
         if (row < p.N && col < p.Fi) out[row * ldo + col] = v;
     });
 }
@@ -285,6 +368,7 @@ struct SplitOpRC {
     float4 m[MASK ? NV : 1];
     int off[NV];
     int64_t step;
+    float sc;                                        // fp16x2 mode: power-of-two tensor scale
 
     __device__ __forceinline__ void init(const float *base, const float *mbase, int64_t ld,
                                          int64_t k0, int64_t col0, int64_t ncols) {
@@ -319,6 +403,15 @@ struct SplitOpRC {
     __device__ __forceinline__ void store(char *lds) const {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
+            if (Planes<NP>::F16) {
+                float4 x = value(j);
+                x = make_float4(x.x * sc, x.y * sc, x.z * sc, x.w * sc);
+                f16x4 h, l;
+                split4_h2(x, h, l);
+                *reinterpret_cast<f16x4 *>(lds + off[j]) = h;
+                *reinterpret_cast<f16x4 *>(lds + off[j] + Img::PLANE) = l;
+                continue;
+            }
             bf16x4 hi, mid, lo;
             split4(value(j), hi, mid, lo);
             *reinterpret_cast<bf16x4 *>(lds + off[j]) = hi;
@@ -372,6 +465,15 @@ k_dw_split(DwParams p) {
     SplitOpRC<BN, false, NP> B;
     A.init(p.g.p, p.mask.p, p.g.ld, n_beg, o0, p.Fo);
     B.init(p.x[s].p, nullptr, p.x[s].ld, n_beg, f0, p.Fi);
+    float inva = 1.f, invb = 1.f;
+    if (Planes<NP>::F16) {
+        // the contraction runs over this block's node chunk: one scale per operand and chunk
+        // (each chunk's partial product is stored separately and summed in fp32 afterwards)
+        const float am = h2_block_max(p.h2.a_rowmax, n_beg, n_end, reinterpret_cast<float *>(lds));
+        const float bm = h2_block_max(p.h2.b_rowmax, n_beg, n_end, reinterpret_cast<float *>(lds));
+        A.sc = h2_scale(am), B.sc = h2_scale(bm);
+        inva = h2_unscale(am), invb = h2_unscale(bm);
+    }
     auto bias_acc = [&]() {
         if (do_bias) {
 #pragma unroll
@@ -422,6 +524,7 @@ k_dw_split(DwParams p) {
     float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
     for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
         const int64_t o = o0 + r, ff = f0 + c;
+        if (Planes<NP>::F16) v = (v * inva) * invb;
         if (o < p.Fo && ff < p.Fi) out[o * p.Fi + ff] = v;
     });
     if (do_bias) {
@@ -473,7 +576,8 @@ k_transpose_w(TransposeParams p) {
 static inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
 
 bool fwd_split_launch(const FwdParams &p, int mb, int np, hipStream_t hs) {
-    if (np != 6 && np != 3 && np != 1) return false;
+    if (np != 6 && np != 3 && np != 1 && np != 2) return false;
+    if (np == 2 && (!p.h2.a_rowmax || !p.h2.b_rowmax)) return false;
     if (p.Fi % BK != 0 || p.Fi < BK) return false;
     for (int s = 0; s < p.nseg; ++s)
         if (!al16(p.x[s].p) || !al16(p.w[s].p) || p.x[s].ld % 4 != 0 || p.x[s].ld != p.x[0].ld)
@@ -481,8 +585,8 @@ bool fwd_split_launch(const FwdParams &p, int mb, int np, hipStream_t hs) {
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
     const dim3 gd((unsigned)grid), bd(256);
 #define DC_L(MB_, NP_) hipLaunchKernelGGL((k_fwd_split<MB_, NP_>), gd, bd, 0, hs, p)
-    if (mb == 2) { if (np == 6) DC_L(2, 6); else if (np == 3) DC_L(2, 3); else DC_L(2, 1); }
-    else { if (np == 6) DC_L(1, 6); else if (np == 3) DC_L(1, 3); else DC_L(1, 1); }
+    if (mb == 2) { if (np == 6) DC_L(2, 6); else if (np == 3) DC_L(2, 3); else if (np == 2) DC_L(2, 2); else DC_L(2, 1); }
+    else { if (np == 6) DC_L(1, 6); else if (np == 3) DC_L(1, 3); else if (np == 2) DC_L(1, 2); else DC_L(1, 1); }
 #undef DC_L
     return true;
 }
@@ -495,7 +599,8 @@ bool dx_split_eligible(const DxParams &p) {
 
 // `p.w[s]` = original weights [Fo,Fi]; `wt` = workspace of nseg*Fi*Fo floats (16-B aligned)
 bool dx_split_launch(DxParams p, float *wt, int mb, int np, hipStream_t hs) {
-    if (!dx_split_eligible(p) || !al16(wt) || (np != 6 && np != 3 && np != 1)) return false;
+    if (!dx_split_eligible(p) || !al16(wt) || (np != 6 && np != 3 && np != 1 && np != 2)) return false;
+    if (np == 2 && (!p.h2.b_rowmax || !p.h2.a_rowmax)) return false;
     TransposeParams t{};
     for (int s = 0; s < p.nseg; ++s) t.w[s] = p.w[s].p;
     t.wt = wt, t.Fi = p.Fi, t.Fo = p.Fo, t.nseg = p.nseg;
@@ -508,6 +613,7 @@ bool dx_split_launch(DxParams p, float *wt, int mb, int np, hipStream_t hs) {
     do {                                                                              \
         if (np == 6) hipLaunchKernelGGL((k_dx_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
         else if (np == 3) hipLaunchKernelGGL((k_dx_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
+        else if (np == 2) hipLaunchKernelGGL((k_dx_split<MB_, M_, 2>), gd, bd, 0, hs, p);  \
         else hipLaunchKernelGGL((k_dx_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
     } while (0)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
@@ -517,7 +623,8 @@ bool dx_split_launch(DxParams p, float *wt, int mb, int np, hipStream_t hs) {
 }
 
 bool dw_split_launch(const DwParams &p, int mb, int np, hipStream_t hs) {
-    if (np != 6 && np != 3 && np != 1) return false;
+    if (np != 6 && np != 3 && np != 1 && np != 2) return false;
+    if (np == 2 && (!p.h2.a_rowmax || !p.h2.b_rowmax)) return false;
     if (p.N % BK != 0 || p.chunk_rows % BK != 0 || p.Fi % 4 != 0 || p.Fo % 4 != 0 || p.Fi < 4 ||
         p.Fo < 4 || !al16(p.g.p) || p.g.ld % 4 != 0)
         return false;
@@ -530,6 +637,7 @@ bool dw_split_launch(const DwParams &p, int mb, int np, hipStream_t hs) {
     do {                                                                              \
         if (np == 6) hipLaunchKernelGGL((k_dw_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
         else if (np == 3) hipLaunchKernelGGL((k_dw_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
+        else if (np == 2) hipLaunchKernelGGL((k_dw_split<MB_, M_, 2>), gd, bd, 0, hs, p);  \
         else hipLaunchKernelGGL((k_dw_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
     } while (0)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }

@@ -45,12 +45,20 @@ __device__ __forceinline__ void vaxpy(float4 &acc, float w, const float4 &v) {
 }
 
 // ---- one wave per destination row (F >= 64*VEC/2 ... up to any F) ----------
-template <int VEC, int U>
+__device__ __forceinline__ float vabsmax(float v) { return fabsf(v); }
+__device__ __forceinline__ float vabsmax(const float4 &v) {
+    return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
+// RM: also write rowmax[row] = max |y[row,:]| (bit 0 of rm_mode: include |x[row,:]|, the
+// wave's OWN input row; bit 1: keep the larger of the new value and what rowmax[row] holds) -
+// the row scales of the fp16x2 dense block (dc_dense_split.hip) at no extra pass.
+template <int VEC, int U, bool RM = false>
 __global__ void __launch_bounds__(256)
 k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
             const float *__restrict__ w, const float *__restrict__ x, int64_t ldx,
             const float *addend, int64_t ldadd, float *y, int64_t ldy,
-            int64_t N, int F) {
+            int64_t N, int F, float *rowmax = nullptr, int rm_mode = 0) {
     using V = typename Vec<VEC>::T;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     // wave-uniform row: force into an SGPR so bounds / ids / weights use scalar loads
@@ -59,9 +67,12 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     if (row >= N) return;
     const int lane = threadIdx.x & 63;
     const int beg = ptr[row], end = ptr[row + 1];
+    float rmax = 0.f;
 
     for (int c = lane * VEC; c < F; c += kWave * VEC) {
         V acc = addend ? *reinterpret_cast<const V *>(addend + row * ldadd + c) : vzero(V{});
+        V self = vzero(V{});
+        if (RM && (rm_mode & 1)) self = *reinterpret_cast<const V *>(x + row * ldx + c);
         for (int p = beg; p < end; p += U) {
             const int n = end - p;   // wave-uniform
             int s[U];
@@ -81,9 +92,17 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
                 if (j < n) vaxpy(acc, ww[j], v[j]);
         }
         *reinterpret_cast<V *>(y + row * ldy + c) = acc;
+        if (RM) rmax = fmaxf(rmax, fmaxf(vabsmax(acc), vabsmax(self)));
+    }
+    if (RM) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+        if (lane == 0) {
+            if (rm_mode & 2) rmax = fmaxf(rmax, rowmax[row]);
+            rowmax[row] = rmax;
+        }
     }
 }
-
 
 // ---- L lanes per row, 64/L rows per wave (narrow feature rows) -------------
 template <int VEC, int L, int U>
@@ -470,4 +489,30 @@ extern "C" int dc_spmm_bf16(const int32_t *ptr, const int32_t *other, const floa
     else
         dispatch_bf16<false>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, (int)F, x8, stream);
     return check_launch("dc_spmm_bf16");
+}
+
+
+extern "C" int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
+                                  const float *x, int64_t ldx, const float *addend, int64_t ldadd,
+                                  float *y, int64_t ldy, int64_t N, int64_t F, float *rowmax,
+                                  int mode, dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(N >= 0 && F >= 0, "dc_spmm_f32_rowmax: negative size");
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(F >= 1 && ptr && x && y && rowmax, "dc_spmm_f32_rowmax: null ptr/x/y/rowmax or F == 0");
+    DC_REQUIRE(N < (int64_t)INT32_MAX / 4 && F < (1 << 24), "dc_spmm_f32_rowmax: size out of range");
+    DC_REQUIRE(ldx >= F && ldy >= F && (!addend || ldadd >= F),
+               "dc_spmm_f32_rowmax: leading dimension smaller than F");
+    DC_REQUIRE(x != y, "dc_spmm_f32_rowmax: y must not alias x");
+    DC_REQUIRE((mode & ~3) == 0, "dc_spmm_f32_rowmax: mode is a 2-bit mask");
+    const bool vec4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) &&
+                      aligned16(y) && (!addend || ((ldadd % 4 == 0) && aligned16(addend)));
+    const unsigned grid = (unsigned)((N + 3) / 4);
+    if (vec4)
+        hipLaunchKernelGGL((k_spmm_wave<4, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
+                           x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode);
+    else
+        hipLaunchKernelGGL((k_spmm_wave<1, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
+                           x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode);
+    return check_launch("dc_spmm_f32_rowmax");
 }

@@ -28,10 +28,13 @@ def _rowmajor(t: torch.Tensor, what: str) -> int:
 
 
 def hop(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = None,
-        addend: Optional[torch.Tensor] = None, weighted: bool = True) -> torch.Tensor:
+        addend: Optional[torch.Tensor] = None, weighted: bool = True,
+        rowmax: Optional[torch.Tensor] = None, rowmax_mode: int = 0) -> torch.Tensor:
     """``out[i] = addend[i] + sum_{p in seg(i)} w[p] * x[other[p]]`` (one launch).
 
-    ``x`` / ``out`` / ``addend`` may be column slices of wider row-major buffers."""
+    ``x`` / ``out`` / ``addend`` may be column slices of wider row-major buffers.  With ``rowmax``
+    (float32 ``[N]``) the launch also records ``max |out[i, :]|`` there (``rowmax_mode`` bit 0:
+    joined with ``max |x[i, :]|``, bit 1: joined with the value already stored)."""
     _require_cuda(x, "x")
     n, f = x.shape
     if adj.ptr.numel() != n + 1:
@@ -47,11 +50,43 @@ def hop(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = Non
             raise ValueError("hop: addend shape mismatch")
         lda = _rowmajor(addend, "addend")
     w = adj.w if weighted else None
+    if rowmax is not None:
+        if rowmax.dtype != torch.float32 or rowmax.numel() != n or not rowmax.is_contiguous():
+            raise ValueError("hop: rowmax must be a contiguous float32 [N] tensor")
+        rc = _lib.lib().dc_spmm_f32_rowmax(
+            adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+            x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,
+            out.data_ptr(), ldy, n, f, rowmax.data_ptr(), int(rowmax_mode),
+            current_stream_ptr(x.device))
+        _lib.check(rc, "dc_spmm_f32_rowmax")
+        return out
     rc = _lib.lib().dc_spmm_f32(
         adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
         x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,
         out.data_ptr(), ldy, n, f, current_stream_ptr(x.device))
     _lib.check(rc, "dc_spmm_f32")
+    return out
+
+
+def weight_rowmax(ws) -> torch.Tensor:
+    """``out[o] = max_s,f |W_s[o, f]|`` over the K+1 weight blocks of a TAGConv layer
+    (``dc_tag_weight_rowmax``): the per-output-row scale of the fp16x2 dense block."""
+    fo, fi = ws[0].shape
+    out = torch.empty(fo, dtype=torch.float32, device=ws[0].device)
+    rc = _lib.lib().dc_tag_weight_rowmax(_ptr_array(ws), len(ws), fo, fi, out.data_ptr(),
+                                         current_stream_ptr(out.device))
+    _lib.check(rc, "dc_tag_weight_rowmax")
+    return out
+
+
+def rowabsmax(x: torch.Tensor) -> torch.Tensor:
+    """``out[i] = max |x[i, :]|`` of a row-major 2-D float32 view (``dc_rowabsmax_f32``)."""
+    _require_cuda(x, "x")
+    n, f = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dc_rowabsmax_f32(x.data_ptr(), _rowmajor(x, "x"), n, f, out.data_ptr(),
+                                     current_stream_ptr(x.device))
+    _lib.check(rc, "dc_rowabsmax_f32")
     return out
 
 
@@ -144,6 +179,13 @@ DENSE_SPLIT_BF16 = os.environ.get("DC_DENSE_SPLIT", "1") != "0"
 DENSE_PRODUCTS = int(os.environ.get("DC_DENSE_PRODUCTS", "6"))
 
 
+#: fp16x2 mode of the wide (Fi % 16 == 0, unconcatenated) dense blocks: two power-of-two-scaled
+#: fp16 planes per operand and THREE MFMA products instead of the six of the bf16 split - still
+#: fp32-accurate (error below that of fp32 accumulation), half the matrix work.  The row maxima
+#: the scaling needs come out of the hop launches.  ``DC_DENSE_F16X2=0`` keeps the bf16x3 split.
+DENSE_F16X2 = os.environ.get("DC_DENSE_F16X2", "1") != "0"
+
+
 #: Run the K chained hops of a TAGConv layer (forward: x_k = A x_{k-1}; backward: g_{k-1} = G_{k-1}
 #: + A^T g_k) as ONE launch with the features and adjacency of each mesh resident in LDS
 #: (``dc_multihop_f32``) whenever the batch splits into small enough segments; bit-identical to
@@ -154,13 +196,15 @@ DENSE_PRODUCTS = int(os.environ.get("DC_DENSE_PRODUCTS", "6"))
 MULTIHOP = os.environ.get("DC_MULTIHOP", "0") == "1"
 
 
-def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool) -> None:
+def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool,
+                 rowmax: Optional[torch.Tensor] = None) -> None:
     """In place on ``slab`` ([N, ld], K+1 column blocks of width ``f``).  Forward: block j+1 =
-    A block j (j = 0..k-1).  Backward: block j-1 += A^T block j (j = k..1)."""
+    A block j (j = 0..k-1).  Backward: block j-1 += A^T block j (j = k..1).  Forward with
+    ``rowmax`` ([N]): also ``rowmax[i] = max_j max |block j [i, :]|`` (needs k >= 1)."""
     if k == 0:
         return
     adj = g.bwd if backward else g.fwd
-    seg = g.segments() if MULTIHOP else None
+    seg = g.segments() if (MULTIHOP and rowmax is None) else None
     if seg is not None:
         w = adj.w if g.normalize else None
         rc = _lib.lib().dc_multihop_f32(
@@ -175,7 +219,8 @@ def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bo
             hop(adj, blocks[j], out=blocks[j - 1], addend=blocks[j - 1], weighted=g.normalize)
     else:
         for j in range(k):
-            hop(adj, blocks[j], out=blocks[j + 1], weighted=g.normalize)
+            hop(adj, blocks[j], out=blocks[j + 1], weighted=g.normalize, rowmax=rowmax,
+                rowmax_mode=1 if j == 0 else 2)
 
 
 def _grad_sink(p) -> bool:
@@ -234,7 +279,10 @@ class _TagConvFn(torch.autograd.Function):
             _lib.check(L.dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), wpad, n,
                                            fi, width, wpad, st), "dc_tag_pack_input")
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-        chained_hops(g, slab, fi, k, backward=False)
+        h2 = (DENSE_F16X2 and DENSE_SPLIT_BF16 and DENSE_PRODUCTS == 6 and not concat and k >= 1
+              and fi % 16 == 0 and wpad % 4 == 0)
+        rowmax = torch.empty(n, dtype=torch.float32, device=dev) if h2 else None
+        chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax)
         if concat:
             wc = [w.contiguous() for w in weights]
             wcat = torch.empty((fo, wpad), dtype=torch.float32, device=dev)
@@ -258,7 +306,11 @@ class _TagConvFn(torch.autograd.Function):
         b = bias.contiguous() if bias is not None else None
         args = (_ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
                 b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n, fi_eff, fo)
-        if DENSE_SPLIT_BF16:
+        wmax = None
+        if h2:
+            wmax = weight_rowmax(ws)
+            rc = L.dc_tag_linear_fwd_h2(*args, rowmax.data_ptr(), wmax.data_ptr(), st)
+        elif DENSE_SPLIT_BF16:
             rc = L.dc_tag_linear_fwd_split(*args, DENSE_PRODUCTS, st)
         else:
             rc = L.dc_tag_linear_fwd(*args, st)
@@ -266,12 +318,13 @@ class _TagConvFn(torch.autograd.Function):
         ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu, ctx.concat = \
             g, k, fi, fo, bias is not None, relu, concat
         ctx.params, ctx.bias_param = weights, bias       # the Parameter objects themselves
-        ctx.save_for_backward(slab, out if relu else None, *ws)
+        ctx.h2 = h2
+        ctx.save_for_backward(slab, out if relu else None, wmax, rowmax, *ws)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        slab, out, *ws = ctx.saved_tensors
+        slab, out, wmax, xrowmax, *ws = ctx.saved_tensors
         g, k, fi, fo, concat = ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.concat
         L = _lib.lib()
         if gout.stride(1) != 1 or gout.stride(0) % 4 != 0 or gout.data_ptr() % 16 != 0:
@@ -291,6 +344,33 @@ class _TagConvFn(torch.autograd.Function):
             xs = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
             ldxs, fi_eff, nseg = [wpad] * (k + 1), fi, k + 1
 
+        h2 = ctx.h2
+        growmax = None
+
+        def run_dx():
+            gslab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
+            gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
+            gxs = [gslab] if concat else gblocks
+            if DENSE_SPLIT_BF16:
+                wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi_eff, fo, nseg)
+                wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                head = (gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg, _ptr_array(gxs),
+                        _i64_array(ldxs), wsx.data_ptr(), wsb, n, fi_eff, fo)
+                if growmax is not None and fo % 16 == 0:
+                    rc = L.dc_tag_linear_bwd_dx_h2(*head, growmax.data_ptr(), wmax.data_ptr(), st)
+                else:
+                    rc = L.dc_tag_linear_bwd_dx_split(*head, DENSE_PRODUCTS, st)
+            else:
+                rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg,
+                                            _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
+            _lib.check(rc, "dc_tag_linear_bwd_dx")
+            return gslab, gblocks
+
+        gx = None
+        gslab = None
+        if h2:
+            growmax = rowabsmax(gout)        # row scales of g for dX, chunk scales for dW
+
         gws: List[Optional[torch.Tensor]] = [None] * (k + 1)
         gb = None
         if need_w or need_b:
@@ -309,7 +389,9 @@ class _TagConvFn(torch.autograd.Function):
             args = (gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
                     _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
                     int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo)
-            if DENSE_SPLIT_BF16:
+            if growmax is not None and n % 16 == 0:
+                rc = L.dc_tag_linear_bwd_dw_h2(*args, growmax.data_ptr(), xrowmax.data_ptr(), st)
+            elif DENSE_SPLIT_BF16:
                 rc = L.dc_tag_linear_bwd_dw_split(*args, DENSE_PRODUCTS, st)
             else:
                 rc = L.dc_tag_linear_bwd_dw(*args, st)
@@ -318,22 +400,8 @@ class _TagConvFn(torch.autograd.Function):
                 gws = [outs[j] if ctx.needs_input_grad[5 + j] else None for j in range(k + 1)]
                 gb = gb_out
 
-        gx = None
         if need_x:
-            gslab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
-            gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-            gxs = [gslab] if concat else gblocks
-            if DENSE_SPLIT_BF16:
-                wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi_eff, fo, nseg)
-                wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
-                rc = L.dc_tag_linear_bwd_dx_split(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws),
-                                                  nseg, _ptr_array(gxs), _i64_array(ldxs),
-                                                  wsx.data_ptr(), wsb, n, fi_eff, fo,
-                                                  DENSE_PRODUCTS, st)
-            else:
-                rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg,
-                                            _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
-            _lib.check(rc, "dc_tag_linear_bwd_dx")
+            gslab, gblocks = run_dx()
             chained_hops(g, gslab, fi, k, backward=True)  # g_{j-1} = G_{j-1} + A^T g_j
             gx = gblocks[0]
         return (None, gx, gb, None, None, *gws)

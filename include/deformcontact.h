@@ -105,6 +105,13 @@ int dc_spmm_bf16(const int32_t *ptr, const int32_t *other, const float *w, const
                  int64_t ldx, const void *addend, int64_t ldadd, void *y, int64_t ldy, int64_t N,
                  int64_t F, int y_is_f32, dc_stream_t stream);
 
+/* dc_spmm_f32 that also records the row maxima the fp16x2 dense block scales by:
+ * rowmax[i] = max |y[i,:]|, joined with max |x[i,:]| (the row's own input) when mode & 1 and with
+ * the value rowmax[i] already holds when mode & 2.  y is bit-identical to dc_spmm_f32. */
+int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
+                       int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
+                       int64_t N, int64_t F, float *rowmax, int mode, dc_stream_t stream);
+
 /* ---- K chained hops in one launch (block-diagonal batches) -------------------
  * TAGConv.forward calls propagate K = 3 times in a row (x_k = A_hat x_{k-1}); its backward runs
  * the chain g_{k-1} = G_{k-1} + A_hat^T g_k.  For a batch whose nodes split into segments no edge
@@ -186,6 +193,42 @@ int dc_tag_linear_bwd_dw_split(const float *g, int64_t ldg, const float *out_for
                                float *const *gws, int ngw, int64_t gw_cols, float *gbias,
                                int accumulate, void *partials, int64_t partials_bytes, int64_t N,
                                int64_t Fi, int64_t Fo, int products, dc_stream_t stream);
+
+/* ---- fp16x2 ("h2") dense block: two scaled fp16 planes per operand, 3 MFMA products ---------
+ * Same results contract as the *_split entries with products = 6 (fp32-accurate: simulated and
+ * measured error at the level of fp32 accumulation) at half the matrix work.  Every operand is
+ * multiplied by an exact power of two that puts its reference magnitude in [2^14, 2^15) before it
+ * is written as h1 + h2 (fp16), and the accumulator is multiplied back:
+ *   forward : row i of x by x_rowmax[i] >= max_k |x_k[i,:]| (dc_spmm_f32_rowmax records it for
+ *             free), row o of the weights by w_rowmax[o] = max_s,f |W_s[o,f]| (dc_tag_weight_rowmax);
+ *   dX      : row i of g * relu' by g_rowmax[i] >= max |g[i,:]| (dc_rowabsmax_f32), all weights by
+ *             max_o w_rowmax[o] (reduced inside the kernel);
+ *   dW      : the contraction runs over nodes, so g * relu' and x get ONE scale per node chunk of
+ *             the split-N plan: the maxima of g_rowmax / x_rowmax over the chunk (inside the kernel).
+ * Any upper bound is a valid reference.  fp16 denormals are honoured by the matrix core: elements
+ * down to 2^-39 of their reference keep absolute accuracy.  Shapes: Fi % 16 == 0 (forward),
+ * Fo % 16 == 0 (dX), N % 16 == 0 (dW), 16-byte aligned rows; otherwise DC_EINVAL (use *_split). */
+int dc_tag_linear_fwd_h2(const float *const *xs, const int64_t *ldxs, const float *const *ws,
+                         int nseg, const float *bias, int relu, float *out, int64_t ldo, int64_t N,
+                         int64_t Fi, int64_t Fo, const float *x_rowmax, const float *w_rowmax,
+                         dc_stream_t stream);
+int dc_tag_linear_bwd_dx_h2(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
+                            const float *const *ws, int nseg, float *const *gxs,
+                            const int64_t *ldgxs, void *workspace, int64_t workspace_bytes,
+                            int64_t N, int64_t Fi, int64_t Fo, const float *g_rowmax,
+                            const float *w_rowmax, dc_stream_t stream);
+int dc_tag_linear_bwd_dw_h2(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
+                            const float *const *xs, const int64_t *ldxs, int nseg,
+                            float *const *gws, int ngw, int64_t gw_cols, float *gbias,
+                            int accumulate, void *partials, int64_t partials_bytes, int64_t N,
+                            int64_t Fi, int64_t Fo, const float *g_rowmax, const float *x_rowmax,
+                            dc_stream_t stream);
+/* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
+int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
+                     dc_stream_t stream);
+/* w_rowmax[o] = max over the nseg weight blocks W_s [Fo, Fi] and f of |W_s[o, f]|. */
+int dc_tag_weight_rowmax(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
+                         dc_stream_t stream);
 
 /* pos_of[perm[p]] = p  (inverse permutation over the E' = *ptr_last sorted edges) */
 int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last /* &ptr[N] */, int32_t *pos_of,

@@ -297,6 +297,96 @@ def test_dense_block_fwd_bwd_vs_float64(n, fi, fo, nseg, relu, split):
         assert rel_err(_np(gxs[s]), (gm @ ws[s].double().cpu()).numpy()) < tol, s
 
 
+
+@pytest.mark.parametrize("n,fi,fo,nseg,relu", [(208, 256, 256, 4, True), (1008, 256, 256, 1, False),
+                                               (144, 32, 48, 2, True), (4112, 64, 256, 3, True)])
+@pytest.mark.parametrize("regime", ["unit", "wide_rows", "tiny", "huge"])
+def test_dense_block_fp16x2_vs_float64(n, fi, fo, nseg, relu, regime):
+    """The scaled fp16x2 dense block (3 MFMA products) is fp32-accurate: same 2e-6 bound vs float64
+    as the fp32-MFMA / six-product kernels, also per ROW when rows differ by 2^20 in magnitude,
+    and for operands far outside the fp16 range (1e-12 / 1e+12)."""
+    from deformcontact_amd import _lib
+    from deformcontact_amd.graph import current_stream_ptr
+    from deformcontact_amd.ops import _i64_array, _ptr_array
+    L = _lib.lib()
+    st = current_stream_ptr(torch.device(DEV))
+    slab = torch.from_numpy(hashed_uniform((n, nseg * fi), 5, 2.0)).to(DEV)
+    g = torch.from_numpy(hashed_uniform((n, fo), 91, 2.0)).to(DEV)
+    wscale = 2.0 / np.sqrt(fi)
+    if regime == "wide_rows":
+        rs = torch.logspace(-6, 0, n, device=DEV).unsqueeze(1)
+        slab, g = slab * rs, g * rs.flip(0)
+    elif regime == "tiny":
+        slab, g, wscale = slab * 1e-12, g * 1e-12, wscale * 1e-6
+    elif regime == "huge":
+        slab, g, wscale = slab * 1e12, g * 1e10, wscale * 1e3
+    slab, g = slab.contiguous(), g.contiguous()
+    xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+    ld = [nseg * fi] * nseg
+    ws = [torch.from_numpy(hashed_uniform((fo, fi), 40 + s, wscale)).to(DEV) for s in range(nseg)]
+    bias = torch.from_numpy(hashed_uniform((fo,), 77, 0.5)).to(DEV) * float(slab.abs().max()) * wscale
+    rowmax = slab.abs().amax(1).contiguous()
+    wmax = ops.weight_rowmax(ws)
+    assert torch.equal(wmax, torch.stack([w.abs().amax(1) for w in ws]).amax(0))
+    out = torch.empty(n, fo, device=DEV)
+    _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
+                                      int(relu), out.data_ptr(), fo, n, fi, fo, rowmax.data_ptr(),
+                                      wmax.data_ptr(), st), "fwd_h2")
+    ref = sum(xs[s].double().cpu() @ ws[s].double().cpu().t() for s in range(nseg)) + bias.double().cpu()
+    if relu:
+        ref = ref.clamp_min(0)
+
+    def row_rel(a, b):                       # worst row, each row on its own scale
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        den = np.abs(b).max(axis=1, keepdims=True)
+        den[den == 0] = 1.0
+        return float((np.abs(a - b) / den).max())
+    assert row_rel(_np(out), ref.numpy()) < 2e-6
+    # dX: rows of g scaled by their own maxima inside the kernel (also returned)
+    mask = out.data_ptr() if relu else None
+    gm = g.double().cpu() * ((out.double().cpu() > 0).double() if relu else 1.0)
+    gslab = torch.zeros(n, nseg * fi, device=DEV)
+    gxs = [gslab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+    wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi, fo, nseg)
+    wsx = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    growmax = ops.rowabsmax(g)                                     # unmasked: an upper bound is enough
+    assert torch.equal(growmax, g.abs().amax(1))
+    _lib.check(L.dc_tag_linear_bwd_dx_h2(g.data_ptr(), fo, mask, fo, _ptr_array(ws), nseg, _ptr_array(gxs),
+                                         _i64_array(ld), wsx.data_ptr(), wsb, n, fi, fo, growmax.data_ptr(),
+                                         wmax.data_ptr(), st), "dx_h2")
+    for s in range(nseg):
+        assert row_rel(_np(gxs[s]), (gm @ ws[s].double().cpu()).numpy()) < 2e-6, s
+    # dW: one scale per operand and node chunk (the contraction runs over the nodes)
+    gws = [torch.empty(fo, fi, device=DEV) for _ in range(nseg)]
+    gb = torch.empty(fo, device=DEV)
+    nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(L.dc_tag_linear_bwd_dw_h2(g.data_ptr(), fo, mask, fo, _ptr_array(xs), _i64_array(ld), nseg,
+                                         _ptr_array(gws), nseg, fi, gb.data_ptr(), 0, scratch.data_ptr(),
+                                         nbytes, n, fi, fo, growmax.data_ptr(), rowmax.data_ptr(), st), "dw_h2")
+    for s in range(nseg):
+        assert rel_err(_np(gws[s]), (gm.t() @ xs[s].double().cpu()).numpy()) < 2e-6, s
+    assert rel_err(_np(gb), gm.sum(0).numpy()) < 2e-6
+
+
+def test_hop_rowmax_variant_bit_identical_and_exact_maxima():
+    n, e, f = 333, 2500, 256
+    ei = random_multigraph(n, e, 21)
+    g = GraphIndex(torch.from_numpy(ei).to(DEV), n)
+    slab = torch.from_numpy(hashed_uniform((n, 4 * f), 3, 2.0)).to(DEV)
+    ref = slab.clone()
+    rowmax = torch.empty(n, device=DEV)
+    ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rowmax)
+    ops.chained_hops(g, ref, f, 3, backward=False)
+    assert torch.equal(slab, ref)
+    assert torch.equal(rowmax, ref.abs().amax(1))
+    # odd width / unaligned view: scalar path
+    x = torch.from_numpy(hashed_uniform((n, 37), 4, 2.0)).to(DEV)
+    rm = torch.zeros(n, device=DEV)
+    y = ops.hop(g.fwd, x, rowmax=rm, rowmax_mode=0)
+    assert torch.equal(y, ops.hop(g.fwd, x)) and torch.equal(rm, y.abs().amax(1))
+
+
 # --------------------------------------------------------------------------- #
 # conv layers: forward + backward vs the oracle
 # --------------------------------------------------------------------------- #

@@ -86,7 +86,31 @@ def main():
             L.dc_tag_linear_bwd_dw_split(g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
                                          gb.data_ptr(), 0, scratch.data_ptr(), nbytes, n, fi, fo, NP, st)
 
-        for kn, fn in (("fwd", fwd), ("dX", dx), ("dW", dw), ("fwd6", fwd_s), ("dX6", dx_s), ("dW6", dw_s)):
+        rowmax = slab.abs().amax(1).contiguous()
+        growmax = torch.empty(n, device=dev)
+        wmax = ops.weight_rowmax(ws)
+
+        def fwd_h():
+            L.dc_tag_linear_fwd_h2(pa_x, pa_ld, pa_w, nseg, bias.data_ptr(), 1, out.data_ptr(), fo, n, fi, fo,
+                                   rowmax.data_ptr(), wmax.data_ptr(), st)
+
+        def dx_h():
+            L.dc_tag_linear_bwd_dx_h2(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld,
+                                      wsx.data_ptr(), wsb, n, fi, fo, growmax.data_ptr(), wmax.data_ptr(), st)
+
+        def dw_h():
+            L.dc_tag_linear_bwd_dw_h2(g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
+                                      gb.data_ptr(), 0, scratch.data_ptr(), nbytes, n, fi, fo,
+                                      growmax.data_ptr(), rowmax.data_ptr(), st)
+
+        def amax():
+            L.dc_rowabsmax_f32(g.data_ptr(), fo, n, fo, growmax.data_ptr(), st)
+            L.dc_tag_weight_rowmax(pa_w, nseg, fo, fi, wmax.data_ptr(), st)
+
+        amax()
+
+        h2 = (("fwdH", fwd_h), ("dXH", dx_h), ("dWH", dw_h), ("amax", amax)) if fi % 16 == 0 else ()
+        for kn, fn in (("fwd", fwd), ("dX", dx), ("dW", dw), ("fwd6", fwd_s), ("dX6", dx_s), ("dW6", dw_s)) + h2:
             ms = timeit(fn, args.reps)
             print(f"{name:13s} {kn:4s} N={n} Fi={fi}x{nseg} Fo={fo}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TF/s")
 
