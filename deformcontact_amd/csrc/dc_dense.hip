@@ -449,9 +449,11 @@ static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_
                     int *nchunks) {
     const int64_t BM = 64 * dw_mb(Fo);
     const int64_t tiles = ((Fo + BM - 1) / BM) * ((Fi + BN - 1) / BN) * nseg;
-    int64_t want = 1024 / (tiles > 0 ? tiles : 1);
+    static const int target = env_int("DC_DW_BLOCKS", 512);
+    static const int maxchunks = env_int("DC_DW_MAXCHUNKS", 128);
+    int64_t want = target / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
-    if (want > 64) want = 64;                 // keeps the slab-reduce pass short
+    if (want > maxchunks) want = maxchunks;   // keeps the slab-reduce pass short
     int64_t rows = (N + want - 1) / want;
     if (rows < 256) rows = 256;
     rows = (rows + BK - 1) / BK * BK;

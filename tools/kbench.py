@@ -44,7 +44,7 @@ def main():
     L = _lib.lib()
     st = current_stream_ptr(dev)
     for name, n, fi, nseg in (("soft L2", 32768, 256, 4), ("rigid L2", 24384, 256, 4),
-                              ("soft L1 cat", 32768, 84, 1), ("rigid L1 cat", 24384, 100, 1)):
+                              ("soft L1 pad", 32768, 96, 1), ("rigid L1 pad", 24384, 112, 1)):
         fo = 256
         slab = torch.randn(n, nseg * fi, device=dev)
         xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
