@@ -799,6 +799,61 @@ __global__ void __launch_bounds__(256) k_w_rowmax(WRowmaxParams p) {
 }
 }  // namespace dc
 
+namespace dc {
+// gm[i,:] = g[i,:] * (out[i,:] > 0), rowmax[i] = max |gm[i,:]| : one wave per row
+__global__ void __launch_bounds__(256)
+k_mask_grad(const float *__restrict__ g, int64_t ldg, const float *__restrict__ mask, int64_t ldm,
+            float *__restrict__ gm, int64_t ldgm, int64_t N, int F, float *__restrict__ rowmax_a,
+            float *__restrict__ rowmax_b, bool vec4) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float *gr = g + row * ldg, *mr = mask ? mask + row * ldm : nullptr;
+    float *o = gm + row * ldgm;
+    float m = 0.f;
+    if (vec4) {
+        for (int c = lane * 4; c < F; c += 256) {
+            float4 v = *reinterpret_cast<const float4 *>(gr + c);
+            if (mr) {
+                const float4 k = *reinterpret_cast<const float4 *>(mr + c);
+                v = make_float4(k.x > 0.f ? v.x : 0.f, k.y > 0.f ? v.y : 0.f, k.z > 0.f ? v.z : 0.f,
+                                k.w > 0.f ? v.w : 0.f);
+            }
+            *reinterpret_cast<float4 *>(o + c) = v;
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    } else {
+        for (int c = lane; c < F; c += 64) {
+            float v = gr[c];
+            if (mr && !(mr[c] > 0.f)) v = 0.f;
+            o[c] = v;
+            m = fmaxf(m, fabsf(v));
+        }
+    }
+#pragma unroll
+    for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
+    if (lane == 0) {
+        rowmax_a[row] = m;
+        if (rowmax_b) rowmax_b[row] = m;
+    }
+}
+}  // namespace dc
+
+extern "C" int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
+                                float *gm, int64_t ldgm, int64_t N, int64_t F, float *rowmax_a,
+                                float *rowmax_b, dc_stream_t stream) {
+    DC_REQUIRE(N >= 0 && F >= 1 && F < (1 << 24) && ldg >= F && ldgm >= F && (!out_for_mask || ldo >= F),
+               "dc_tag_mask_grad: bad sizes");
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(g && gm && rowmax_a, "dc_tag_mask_grad: null pointer");
+    const bool vec4 = (F % 4 == 0) && (ldg % 4 == 0) && (ldgm % 4 == 0) && (((uintptr_t)g) & 15) == 0 &&
+                      (((uintptr_t)gm) & 15) == 0 &&
+                      (!out_for_mask || ((ldo % 4 == 0) && (((uintptr_t)out_for_mask) & 15) == 0));
+    hipLaunchKernelGGL(k_mask_grad, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g,
+                       ldg, out_for_mask, ldo, gm, ldgm, N, (int)F, rowmax_a, rowmax_b, vec4);
+    return check_launch("dc_tag_mask_grad");
+}
+
 extern "C" int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                                 dc_stream_t stream) {
     DC_REQUIRE(N >= 0 && F >= 1 && F < (1 << 24) && ld >= F, "dc_rowabsmax_f32: bad sizes");
@@ -808,6 +863,15 @@ extern "C" int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F
     hipLaunchKernelGGL(k_rowabsmax, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, ld, N, (int)F, rowmax, vec4);
     return check_launch("dc_rowabsmax_f32");
+}
+
+extern "C" int dc_tag_transpose_weights(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,
+                                        float *wt, dc_stream_t stream) {
+    DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && Fo >= 1 && Fi >= 1 && ws && wt,
+               "dc_tag_transpose_weights: bad arguments");
+    for (int s = 0; s < nseg; ++s) DC_REQUIRE(ws[s], "dc_tag_transpose_weights: null segment %d", s);
+    transpose_weights_launch(ws, nseg, Fo, Fi, wt, (hipStream_t)stream);
+    return check_launch("dc_tag_transpose_weights");
 }
 
 extern "C" int dc_tag_weight_rowmax(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,

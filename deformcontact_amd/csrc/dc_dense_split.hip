@@ -573,6 +573,15 @@ k_transpose_w(TransposeParams p) {
     }
 }
 
+void transpose_weights_launch(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *wt,
+                              hipStream_t hs) {
+    TransposeParams t{};
+    for (int s = 0; s < nseg; ++s) t.w[s] = ws[s];
+    t.wt = wt, t.Fi = Fi, t.Fo = Fo, t.nseg = nseg;
+    const int64_t tiles = ((Fi + 31) / 32) * ((Fo + 31) / 32) * nseg;
+    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)tiles), dim3(256), 0, hs, t);
+}
+
 static inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
 
 bool fwd_split_launch(const FwdParams &p, int mb, int np, hipStream_t hs) {

@@ -197,14 +197,17 @@ MULTIHOP = os.environ.get("DC_MULTIHOP", "0") == "1"
 
 
 def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool,
-                 rowmax: Optional[torch.Tensor] = None) -> None:
+                 rowmax: Optional[torch.Tensor] = None, transposed: bool = False,
+                 rowmax_has_block0: bool = False) -> None:
     """In place on ``slab`` ([N, ld], K+1 column blocks of width ``f``).  Forward: block j+1 =
     A block j (j = 0..k-1).  Backward: block j-1 += A^T block j (j = k..1).  Forward with
-    ``rowmax`` ([N]): also ``rowmax[i] = max_j max |block j [i, :]|`` (needs k >= 1)."""
+    ``rowmax`` ([N]): also ``rowmax[i] = max_j max |block j [i, :]|`` (needs k >= 1;
+    ``rowmax_has_block0``: it already holds the maxima of block 0).  ``transposed`` (forward
+    direction only): block j+1 = A^T block j."""
     if k == 0:
         return
-    adj = g.bwd if backward else g.fwd
-    seg = g.segments() if (MULTIHOP and rowmax is None) else None
+    adj = g.bwd if (backward or transposed) else g.fwd
+    seg = g.segments() if (MULTIHOP and rowmax is None and not transposed) else None
     if seg is not None:
         w = adj.w if g.normalize else None
         rc = _lib.lib().dc_multihop_f32(
@@ -220,7 +223,7 @@ def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bo
     else:
         for j in range(k):
             hop(adj, blocks[j], out=blocks[j + 1], weighted=g.normalize, rowmax=rowmax,
-                rowmax_mode=1 if j == 0 else 2)
+                rowmax_mode=1 if (j == 0 and not rowmax_has_block0) else 2)
 
 
 def _grad_sink(p) -> bool:
@@ -345,34 +348,40 @@ class _TagConvFn(torch.autograd.Function):
             ldxs, fi_eff, nseg = [wpad] * (k + 1), fi, k + 1
 
         h2 = ctx.h2
-        growmax = None
-
-        def run_dx():
-            gslab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
-            gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-            gxs = [gslab] if concat else gblocks
-            if DENSE_SPLIT_BF16:
-                wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi_eff, fo, nseg)
-                wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
-                head = (gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg, _ptr_array(gxs),
-                        _i64_array(ldxs), wsx.data_ptr(), wsb, n, fi_eff, fo)
-                if growmax is not None and fo % 16 == 0:
-                    rc = L.dc_tag_linear_bwd_dx_h2(*head, growmax.data_ptr(), wmax.data_ptr(), st)
-                else:
-                    rc = L.dc_tag_linear_bwd_dx_split(*head, DENSE_PRODUCTS, st)
-            else:
-                rc = L.dc_tag_linear_bwd_dx(gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(ws), nseg,
-                                            _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
-            _lib.check(rc, "dc_tag_linear_bwd_dx")
-            return gslab, gblocks
-
-        gx = None
-        gslab = None
-        if h2:
-            growmax = rowabsmax(gout)        # row scales of g for dX, chunk scales for dW
-
         gws: List[Optional[torch.Tensor]] = [None] * (k + 1)
-        gb = None
+        gb = gx = None
+        g_ptr, g_ld, g_rowmax = gout.data_ptr(), ldg, None
+
+        if h2 and fo % 16 == 0 and fo % 4 == 0:
+            # fp16x2 path, backward in the forward's shape: gx = sum_j ((A^T)^j gm) W_j with
+            # gm = g * relu' - K transposed hops on gm (which also record the row maxima), then
+            # ONE dense block with the (K+1)*Fo reduction and the transposed weights.  gm and its
+            # row maxima also feed dW (no mask reads there).
+            gwid = (k + 1) * fo
+            gslab = torch.empty((n, gwid), dtype=torch.float32, device=dev)
+            g_rowmax = torch.empty(n, dtype=torch.float32, device=dev)
+            hop_rowmax = torch.empty(n, dtype=torch.float32, device=dev) if need_x else None
+            _lib.check(L.dc_tag_mask_grad(gout.data_ptr(), ldg, mask_ptr, ldm, gslab.data_ptr(), gwid, n,
+                                          fo, g_rowmax.data_ptr(),
+                                          hop_rowmax.data_ptr() if need_x else None, st),
+                       "dc_tag_mask_grad")
+            g_ptr, g_ld, mask_ptr = gslab.data_ptr(), gwid, None
+            if need_x:
+                chained_hops(g, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
+                             rowmax_has_block0=True)
+                wt = torch.empty((k + 1, fi, fo), dtype=torch.float32, device=dev)
+                _lib.check(L.dc_tag_transpose_weights(_ptr_array(ws), k + 1, fo, fi, wt.data_ptr(), st),
+                           "dc_tag_transpose_weights")
+                wts = [wt[j] for j in range(k + 1)]
+                wt_rowmax = weight_rowmax(wts)
+                gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
+                gblk = [gslab[:, j * fo:(j + 1) * fo] for j in range(k + 1)]
+                rc = L.dc_tag_linear_fwd_h2(_ptr_array(gblk), _i64_array([gwid] * (k + 1)), _ptr_array(wts),
+                                            k + 1, None, 0, gx.data_ptr(), fi, n, fo, fi,
+                                            hop_rowmax.data_ptr(), wt_rowmax.data_ptr(), st)
+                _lib.check(rc, "dc_tag_linear_fwd_h2 (dX)")
+                need_x = False                               # done
+
         if need_w or need_b:
             # one output block per lins[k].weight, in either layout of the dense block
             direct = (DIRECT_PARAM_GRAD and not torch.is_grad_enabled()
@@ -386,11 +395,11 @@ class _TagConvFn(torch.autograd.Function):
                 gb_out = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
             nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi_eff, fo, nseg)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            args = (gout.data_ptr(), ldg, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
+            args = (g_ptr, g_ld, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
                     _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
                     int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo)
-            if growmax is not None and n % 16 == 0:
-                rc = L.dc_tag_linear_bwd_dw_h2(*args, growmax.data_ptr(), xrowmax.data_ptr(), st)
+            if g_rowmax is not None and n % 16 == 0:
+                rc = L.dc_tag_linear_bwd_dw_h2(*args, g_rowmax.data_ptr(), xrowmax.data_ptr(), st)
             elif DENSE_SPLIT_BF16:
                 rc = L.dc_tag_linear_bwd_dw_split(*args, DENSE_PRODUCTS, st)
             else:
@@ -401,7 +410,19 @@ class _TagConvFn(torch.autograd.Function):
                 gb = gb_out
 
         if need_x:
-            gslab, gblocks = run_dx()
+            gslab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
+            gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
+            gxs = [gslab] if concat else gblocks
+            if DENSE_SPLIT_BF16:
+                wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi_eff, fo, nseg)
+                wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                rc = L.dc_tag_linear_bwd_dx_split(g_ptr, g_ld, mask_ptr, ldm, _ptr_array(ws), nseg,
+                                                  _ptr_array(gxs), _i64_array(ldxs), wsx.data_ptr(), wsb,
+                                                  n, fi_eff, fo, DENSE_PRODUCTS, st)
+            else:
+                rc = L.dc_tag_linear_bwd_dx(g_ptr, g_ld, mask_ptr, ldm, _ptr_array(ws), nseg,
+                                            _ptr_array(gxs), _i64_array(ldxs), n, fi_eff, fo, st)
+            _lib.check(rc, "dc_tag_linear_bwd_dx")
             chained_hops(g, gslab, fi, k, backward=True)  # g_{j-1} = G_{j-1} + A^T g_j
             gx = gblocks[0]
         return (None, gx, gb, None, None, *gws)

@@ -223,6 +223,19 @@ int dc_tag_linear_bwd_dw_h2(const float *g, int64_t ldg, const float *out_for_ma
                             int accumulate, void *partials, int64_t partials_bytes, int64_t N,
                             int64_t Fi, int64_t Fo, const float *g_rowmax, const float *x_rowmax,
                             dc_stream_t stream);
+/* Backward in the forward's shape (used with the h2 entries):  the input gradient of a TAGConv layer
+ *   gx = sum_k (A^T)^k (gm W_k),  gm = g * relu'
+ * equals  sum_k ((A^T)^k gm) W_k  (A acts on rows, W_k on columns), i.e. K transposed hops on gm
+ * followed by ONE dense block with the K = (K+1)*Fo reduction of the forward: dc_tag_linear_fwd_h2
+ * over the hop slab of gm with the transposed weights.  Helpers:
+ *   dc_tag_mask_grad         gm[i,:] = g[i,:] * (out_for_mask[i,:] > 0) into (a column block of) the
+ *                            slab, rowmax_a[i] = rowmax_b[i] = max |gm[i,:]| (rowmax_b may be NULL);
+ *   dc_tag_transpose_weights wt[s] [Fi, Fo] = ws[s]^T, s < nseg, packed back to back. */
+int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo, float *gm,
+                     int64_t ldgm, int64_t N, int64_t F, float *rowmax_a, float *rowmax_b,
+                     dc_stream_t stream);
+int dc_tag_transpose_weights(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *wt,
+                             dc_stream_t stream);
 /* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
 int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                      dc_stream_t stream);
