@@ -144,6 +144,34 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
                  scratch.data_ptr(), nb, n, fi, fo)
             L.dc_tag_linear_bwd_dw_split(*a, npd, st) if split else L.dc_tag_linear_bwd_dw(*a, st)
 
+        if split and ops.DENSE_F16X2:
+            # default path: scaled fp16x2 (3 MFMA products); dX runs as a second forward-shaped
+            # block over the hop slab of the masked gradient with the transposed weights
+            rowmax = slab.abs().amax(1).contiguous()
+            wmax = ops.weight_rowmax(ws)
+            wt = torch.stack([w.t().contiguous() for w in ws])
+            wts = [wt[s] for s in range(nseg)]
+            wtmax = ops.weight_rowmax(wts)
+            pa_wt = _ptr_array(wts)
+            gx = torch.empty(n, fi, device=dev)
+            growmax = gslab.normal_().abs().amax(1).contiguous()
+            g0max = ops.rowabsmax(g)
+            keep += [rowmax, wmax, wt, wts, wtmax, pa_wt, gx, growmax, g0max]
+
+            def fwd(n=n, pa_x=pa_x, pa_ld=pa_ld, pa_w=pa_w, bias=bias, out=out, rowmax=rowmax, wmax=wmax):
+                L.dc_tag_linear_fwd_h2(pa_x, pa_ld, pa_w, nseg, bias.data_ptr(), 1, out.data_ptr(), fo, n,
+                                       fi, fo, rowmax.data_ptr(), wmax.data_ptr(), st)
+
+            def dx(n=n, pa_gx=pa_gx, pa_ld=pa_ld, pa_wt=pa_wt, gx=gx, growmax=growmax, wtmax=wtmax):
+                L.dc_tag_linear_fwd_h2(pa_gx, pa_ld, pa_wt, nseg, None, 0, gx.data_ptr(), fi, n, fo, fi,
+                                       growmax.data_ptr(), wtmax.data_ptr(), st)
+
+            def dw(n=n, g=g, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb,
+                   g0max=g0max, rowmax=rowmax):
+                L.dc_tag_linear_bwd_dw_h2(g.data_ptr(), fo, None, fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
+                                          gb.data_ptr(), 0, scratch.data_ptr(), nb, n, fi, fo,
+                                          g0max.data_ptr(), rowmax.data_ptr(), st)
+
         launches += [fwd, dx, dw]
         flops += 3 * 2.0 * n * fi * nseg * fo
     for f in launches:
@@ -156,13 +184,17 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / reps
-    prod = ops.DENSE_PRODUCTS if ops.DENSE_SPLIT_BF16 else 1
+    h2 = ops.DENSE_SPLIT_BF16 and ops.DENSE_F16X2
+    prod = (3 if h2 else ops.DENSE_PRODUCTS) if ops.DENSE_SPLIT_BF16 else 1
     peak = 2500.0 if ops.DENSE_SPLIT_BF16 else 157.3
     achieved = prod * flops / ms / 1e9
-    return {"bound": "mfma", "kernel": "dc::k_fwd_split / k_dx_split / k_dw_split (layer-2 dense block)"
+    return {"bound": "mfma", "kernel": ("dc::k_fwd_split<*,2> x2 (forward, dX in forward shape) / k_dw_split<*,2> "
+                                        "(layer-2 dense block, fp16x2)" if h2 else
+                                        "dc::k_fwd_split / k_dx_split / k_dw_split (layer-2 dense block)")
             if ops.DENSE_SPLIT_BF16 else "dc::k_fwd_fast / k_dx_fast / k_dw_fast",
             "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "executed": f"{prod} bf16 MFMA products per fp32 product tile" if ops.DENSE_SPLIT_BF16 else "fp32 MFMA",
+            "executed": (f"{prod} {'fp16' if h2 else 'bf16'} MFMA products per fp32 product tile"
+                         if ops.DENSE_SPLIT_BF16 else "fp32 MFMA"),
             "fp32_equivalent_TFLOPs": round(flops / ms / 1e9, 1), "fp32_mfma_peak": 157.3,
             "algorithmic_flop_per_step_l2": flops, "us_per_6_launches": round(ms * 1e3, 1),
             "sustained_bf16_peak_measured": "1.5-1.86 PF/s under DVFS (tools/mfma_peak_bf16.hip)"}
@@ -235,13 +267,17 @@ def main():
     g_rest = torch.randn(n_s, 256, device=dev, generator=gen)
     g_rig = torch.randn(n_r, 256, device=dev, generator=gen)
     bucket = dp.GradBucket(enc.parameters())
-    opt = None if args.no_optim else dp.FlatAdam(bucket, lr=4e-4)     # Adam defaults, one HIP kernel
+    # Adam defaults, one HIP kernel that also clears the gradients it consumed (zero_grad)
+    opt = None if args.no_optim else dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=True)
     # topology is built once per batch (cached on edge_index), as a data loader would
     graph_index(rest.edge_index, n_s)
     graph_index(rig.edge_index, n_r)
 
+    bucket.zero()
+
     def fwd_bwd():
-        bucket.zero()
+        if opt is None:
+            bucket.zero()
         a, b = enc(rest, rig)
         torch.autograd.backward([a, b], [g_rest, g_rig])
 
@@ -311,8 +347,11 @@ def main():
         "value": round(value, 3), "unit": "M edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dense_arithmetic": ("fp32 storage and accumulate; dense products as exact 3-way bf16 splits "
-                             "(6 bf16 MFMAs per product tile, fp32-accurate)") if ops.DENSE_SPLIT_BF16
+        "dense_arithmetic": (("fp32 storage and accumulate; wide dense blocks as power-of-two-scaled 2-way "
+                              "fp16 splits (3 fp16 MFMAs per product tile, fp32-accurate), narrow ones as "
+                              "exact 3-way bf16 splits (6 bf16 MFMAs)") if ops.DENSE_F16X2 else
+                             ("fp32 storage and accumulate; dense products as exact 3-way bf16 splits "
+                              "(6 bf16 MFMAs per product tile, fp32-accurate)")) if ops.DENSE_SPLIT_BF16
         else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
         "config": {
             "workload": f"everyday-deform synthetic, B={args.batch} sample pairs per GPU: soft "

@@ -68,7 +68,7 @@ _SIGNATURES = {
     "dc_tag_pack_input": (c_int, [_vp, c_int64, _vp, c_int64, c_int64, c_int64, c_int64, c_int64, _vp]),
     "dc_tag_pack_weights": (c_int, [POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp]),
     "dc_adam_flat": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_float, c_float, c_float, c_float,
-                             _vp]),
+                             c_int, _vp]),
     "dc_compose_perm": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp]),
     "dc_gat_edge_softmax_fwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, c_int64, _vp]),
     "dc_gat_edge_softmax_bwd": (c_int, [_vp, _vp, _vp, _vp, c_float, _vp, _vp, _vp, _vp, c_int64,

@@ -72,18 +72,50 @@ k_multihop(MultihopParams p) {
     const int e0 = p.ptr[n0], ne = p.ptr[n0 + nn] - e0;
     const bool vec = p.vec != 0;
 
-    for (int i = threadIdx.x; i <= nn; i += blockDim.x) lptr[i] = p.ptr[n0 + i] - e0;
-    for (int i = threadIdx.x; i < ne; i += blockDim.x)
-        edges[i] = EdgeRec{p.other[e0 + i] - n0, p.w ? p.w[e0 + i] : 1.0f};
-    const int ntask = nn * 4;
+    // staging: fixed trip counts, all global loads of a loop issued before the first is used
+    // (a strided "for i < n" loop would pay one memory latency per iteration)
     {
+        int lp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = threadIdx.x + u * 1024;
+            lp[u] = (i <= nn) ? p.ptr[n0 + i] : 0;
+        }
+        constexpr int EU = (kMhEdges + 1023) / 1024;
+        int oj[EU];
+        float ow[EU];
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int i = threadIdx.x + u * 1024;
+            oj[u] = (i < ne) ? p.other[e0 + i] : 0;
+            ow[u] = (i < ne && p.w) ? p.w[e0 + i] : 1.0f;
+        }
         const float *src = p.slab + (int64_t)n0 * p.ld + (int64_t)p.src0 * p.F + c0;
-        for (int t = threadIdx.x; t < ntask; t += blockDim.x) {
+        float4 fv[kMhTasks];
+#pragma unroll
+        for (int u = 0; u < kMhTasks; ++u) {
+            const int t = threadIdx.x + u * 1024;
             const int node = t >> 2, q = t & 3;
-            const float4 v = ld_quad(src + (int64_t)node * p.ld + 4 * q, cw - 4 * q, vec);
-            *reinterpret_cast<float4 *>(feat + node * kMhCols + 4 * q) = v;
+            fv[u] = (t < nn * 4) ? ld_quad(src + (int64_t)node * p.ld + 4 * q, cw - 4 * q, vec)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = threadIdx.x + u * 1024;
+            if (i <= nn) lptr[i] = lp[u] - e0;
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int i = threadIdx.x + u * 1024;
+            if (i < ne) edges[i] = EdgeRec{oj[u] - n0, ow[u]};
+        }
+#pragma unroll
+        for (int u = 0; u < kMhTasks; ++u) {
+            const int t = threadIdx.x + u * 1024;
+            if (t < nn * 4) *reinterpret_cast<float4 *>(feat + (t >> 2) * kMhCols + 4 * (t & 3)) = fv[u];
         }
     }
+    const int ntask = nn * 4;
     __syncthreads();
     for (int s = 0; s < p.K; ++s) {
         const int dstb = p.src0 + (s + 1) * p.dir;

@@ -14,10 +14,12 @@
 namespace dc {
 
 __global__ void __launch_bounds__(256)
-k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-            float *__restrict__ v, int64_t n, const float *__restrict__ step, float lr, float b1,
-            float b2, float eps) {
-    const float t = *step;
+k_adam_flat(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+            float *__restrict__ v, int64_t n, float *step, float lr, float b1, float b2, float eps,
+            int zero_grad) {
+    // step[0] = number of completed updates; this one is update t = step[0] + 1.  The last block
+    // to finish (ticket in step[1], self-resetting) publishes t, after every block has read it.
+    const float t = step[0] + 1.0f;
     const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
     const float step_size = lr / bc1, rbc2 = sqrtf(bc2);
     const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -35,6 +37,7 @@ k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restric
         *reinterpret_cast<float4 *>(m + i4) = mm;
         *reinterpret_cast<float4 *>(v + i4) = vv;
         *reinterpret_cast<float4 *>(p + i4) = pp;
+        if (zero_grad) *reinterpret_cast<float4 *>(g + i4) = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
         for (int64_t i = i4; i < n; ++i) {
             const float gi = g[i];
@@ -42,25 +45,33 @@ k_adam_flat(float *__restrict__ p, const float *__restrict__ g, float *__restric
             const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
             m[i] = mi, v[i] = vi;
             p[i] = p[i] - step_size * (mi / (sqrtf(vi) / rbc2 + eps));
+            if (zero_grad) g[i] = 0.f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned *ticket = reinterpret_cast<unsigned *>(step + 1);
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0u;
+            step[0] = t;
         }
     }
 }
 
-__global__ void k_step_inc(float *step) { *step += 1.0f; }
-
 }  // namespace dc
 
-extern "C" int dc_adam_flat(float *p, const float *g, float *m, float *v, int64_t n, float *step,
-                            float lr, float beta1, float beta2, float eps, dc_stream_t stream) {
+extern "C" int dc_adam_flat(float *p, float *g, float *m, float *v, int64_t n, float *step,
+                            float lr, float beta1, float beta2, float eps, int zero_grad,
+                            dc_stream_t stream) {
     DC_REQUIRE(n >= 0, "dc_adam_flat: negative size");
     if (n == 0) return DC_OK;
     DC_REQUIRE(p && g && m && v && step, "dc_adam_flat: null pointer");
     DC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                "dc_adam_flat: buffers must be 16-byte aligned");
     const int64_t threads = (n + 3) / 4;
-    hipLaunchKernelGGL(dc::k_step_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
     hipLaunchKernelGGL(dc::k_adam_flat, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, p, g, m, v, n, step, lr, beta1, beta2, eps);
+                       (hipStream_t)stream, p, g, m, v, n, step, lr, beta1, beta2, eps, zero_grad);
     return dc::check_launch("dc_adam_flat");
 }
 

@@ -84,9 +84,12 @@ class FlatAdam:
     """``torch.optim.Adam(params, lr)`` at its defaults (``/root/reference/train.py:20``) over flat
     buckets: parameters are re-pointed to views of one flat fp32 buffer (as ``GradBucket`` does for
     gradients), and a step is ONE elementwise HIP kernel (``dc_adam_flat``) instead of torch's
-    multi-tensor launch sequence.  hipGraph-replayable (the step count lives on the device)."""
+    multi-tensor launch sequence.  hipGraph-replayable (the step count lives on the device).
+    ``zero_grad_in_step``: the same kernel also clears the gradients it has just consumed
+    (``optimizer.zero_grad()`` of ``train.py:71`` without a separate memset)."""
 
-    def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 zero_grad_in_step: bool = False):
         from . import _lib
         from .graph import _require_cuda
         self._lib = _lib
@@ -104,7 +107,8 @@ class FlatAdam:
                 off += n
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
-        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.zero_grad_in_step = bool(zero_grad_in_step)
+        self.step_count = torch.zeros(2, dtype=torch.float32, device=dev)   # [count, kernel ticket]
 
     def zero_grad(self) -> None:
         self.bucket.zero()
@@ -115,5 +119,6 @@ class FlatAdam:
         rc = self._lib.lib().dc_adam_flat(
             self.flat_param.data_ptr(), b.flat.data_ptr(), self.exp_avg.data_ptr(),
             self.exp_avg_sq.data_ptr(), b.numel, self.step_count.data_ptr(), self.lr,
-            self.betas[0], self.betas[1], self.eps, current_stream_ptr(b.flat.device))
+            self.betas[0], self.betas[1], self.eps, int(self.zero_grad_in_step),
+            current_stream_ptr(b.flat.device))
         self._lib.check(rc, "dc_adam_flat")

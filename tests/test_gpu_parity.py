@@ -623,28 +623,33 @@ def test_direct_param_grad_accumulation_equals_autograd(fi, fo):
         ops.DIRECT_PARAM_GRAD = old
 
 
-def test_flat_adam_matches_torch_adam():
-    """dc_adam_flat (one kernel over the flat bucket) vs torch.optim.Adam(lr=4e-4) defaults."""
+@pytest.mark.parametrize("fused_zero", [False, True])
+def test_flat_adam_matches_torch_adam(fused_zero):
+    """dc_adam_flat (one kernel over the flat bucket) vs torch.optim.Adam(lr=4e-4) defaults; with
+    ``zero_grad_in_step`` the kernel also clears the gradients (no separate zero_grad)."""
     from deformcontact_amd import dp
     torch.manual_seed(0)
-    ref = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(DEV)
-    mine = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(DEV)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 190), torch.nn.Linear(190, 5)).to(DEV)
+    mine = torch.nn.Sequential(torch.nn.Linear(37, 190), torch.nn.Linear(190, 5)).to(DEV)
     mine.load_state_dict(ref.state_dict())
     o_ref = torch.optim.Adam(ref.parameters(), lr=4e-4)
     bucket = dp.GradBucket(mine.parameters())
-    o_mine = dp.FlatAdam(bucket, lr=4e-4)
+    o_mine = dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=fused_zero)
     x = torch.randn(64, 37, device=DEV)
     for step in range(25):
         o_ref.zero_grad()
         ref(x).square().mean().backward()
         o_ref.step()
-        o_mine.zero_grad()
+        if not fused_zero:
+            o_mine.zero_grad()
         mine(x).square().mean().backward()
         bucket.all_reduce_mean()
         o_mine.step()
+        if fused_zero:
+            assert not bucket.flat.any()
     for a, b in zip(ref.parameters(), mine.parameters()):
         assert rel_err(_np(b), _np(a)) < 1e-6
-    assert float(o_mine.step_count) == 25.0
+    assert float(o_mine.step_count[0]) == 25.0 and float(o_mine.step_count[1]) == 0.0
 
 
 @pytest.mark.parametrize("hidden", [21, 32, 40, 256])
