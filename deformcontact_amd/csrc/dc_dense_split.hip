@@ -87,14 +87,14 @@ struct SplitOp {
     float sc[NV];                                    // fp16x2 mode: power-of-two scale of row j
 
     __device__ __forceinline__ void init(const float *base, const float *mbase, int64_t ld,
-                                         int64_t row0, int64_t nrows) {
+                                         int64_t row0, int64_t nrows, int64_t mld = 0) {
         const int k4 = threadIdx.x & 3, r = threadIdx.x >> 2;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             int64_t row = row0 + r + 64 * j;
             row = row < nrows ? row : nrows - 1;
             p[j] = base + row * ld + 4 * k4;
-            if (MASK) pm[j] = mbase + row * ld + 4 * k4;
+            if (MASK) pm[j] = mbase + row * (mld ? mld : ld) + 4 * k4;
             off[j] = (r + 64 * j) * SROW + 8 * k4;
         }
     }
@@ -312,7 +312,7 @@ k_dx_split(DxParams p) {
     zero_acc<MB>(acc);
     SplitOp<BM, MASK, NP> A;
     SplitOp<BN, false, NP> B;
-    A.init(p.g.p, p.mask.p, p.g.ld, row0, p.N);
+    A.init(p.g.p, p.mask.p, p.g.ld, row0, p.N, p.mask.ld);
     B.init(p.w[s].p, nullptr, p.Fo, col0, p.Fi);
     constexpr bool F16 = Planes<NP>::F16;
     __shared__ float s_inv[F16 ? BM : 1];
@@ -367,22 +367,24 @@ struct SplitOpRC {
     float4 v[NV];
     float4 m[MASK ? NV : 1];
     int off[NV];
-    int64_t step;
+    int64_t step, mstep;
     float sc;                                        // fp16x2 mode: power-of-two tensor scale
 
     __device__ __forceinline__ void init(const float *base, const float *mbase, int64_t ld,
-                                         int64_t k0, int64_t col0, int64_t ncols) {
+                                         int64_t k0, int64_t col0, int64_t ncols, int64_t mld = 0) {
         const int c4 = threadIdx.x % PER, kr = threadIdx.x / PER;
         int64_t col = col0 + 4 * c4;
         col = col + 4 <= ncols ? col : ncols - 4;
+        mld = mld ? mld : ld;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int64_t k = k0 + kr + KPER * j;
             p[j] = base + k * ld + col;
-            if (MASK) pm[j] = mbase + k * ld + col;
+            if (MASK) pm[j] = mbase + k * mld + col;
             off[j] = (kr + KPER * j) * Img::ROWB + 8 * c4;
         }
         step = BK * ld;
+        mstep = BK * mld;
     }
     __device__ __forceinline__ void load() {
 #pragma unroll
@@ -391,7 +393,7 @@ struct SplitOpRC {
             p[j] += step;
             if (MASK) {
                 m[j] = *reinterpret_cast<const float4 *>(pm[j]);
-                pm[j] += step;
+                pm[j] += mstep;
             }
         }
     }
@@ -463,7 +465,7 @@ k_dw_split(DwParams p) {
     using OA = SplitOpRC<BM, MASK, NP>;
     OA A;
     SplitOpRC<BN, false, NP> B;
-    A.init(p.g.p, p.mask.p, p.g.ld, n_beg, o0, p.Fo);
+    A.init(p.g.p, p.mask.p, p.g.ld, n_beg, o0, p.Fo, p.mask.ld);
     B.init(p.x[s].p, nullptr, p.x[s].ld, n_beg, f0, p.Fi);
     float inva = 1.f, invb = 1.f;
     if (Planes<NP>::F16) {
@@ -602,7 +604,7 @@ bool fwd_split_launch(const FwdParams &p, int mb, int np, hipStream_t hs) {
 
 bool dx_split_eligible(const DxParams &p) {
     if (p.Fo % BK != 0 || p.Fo < BK || p.Fi % 4 != 0 || !al16(p.g.p) || p.g.ld % 4 != 0) return false;
-    if (p.has_mask && (!al16(p.mask.p) || p.mask.ld != p.g.ld)) return false;
+    if (p.has_mask && (!al16(p.mask.p) || p.mask.ld % 4 != 0)) return false;
     return true;
 }
 
@@ -637,7 +639,7 @@ bool dw_split_launch(const DwParams &p, int mb, int np, hipStream_t hs) {
     if (p.N % BK != 0 || p.chunk_rows % BK != 0 || p.Fi % 4 != 0 || p.Fo % 4 != 0 || p.Fi < 4 ||
         p.Fo < 4 || !al16(p.g.p) || p.g.ld % 4 != 0)
         return false;
-    if (p.has_mask && (!al16(p.mask.p) || p.mask.ld != p.g.ld)) return false;
+    if (p.has_mask && (!al16(p.mask.p) || p.mask.ld % 4 != 0)) return false;
     for (int s = 0; s < p.nseg; ++s)
         if (!al16(p.x[s].p) || p.x[s].ld % 4 != 0) return false;
     const int64_t tiles = ((p.Fo + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN);

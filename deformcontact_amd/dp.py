@@ -108,7 +108,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.zero_grad_in_step = bool(zero_grad_in_step)
-        self.step_count = torch.zeros(2, dtype=torch.float32, device=dev)   # [count, kernel ticket]
+        self.step_count = torch.zeros(34, dtype=torch.float32, device=dev)  # [count, kernel tickets...]
 
     def zero_grad(self) -> None:
         self.bucket.zero()

@@ -292,9 +292,10 @@ int dc_tag_pack_weights(const float *const *ws, int nw, float *wcat, int64_t Fo,
 /* ---- optimizer step of the path's training loop -----------------------------
  * torch.optim.Adam(lr) at its defaults (train.py:20: no weight decay, no amsgrad) over ONE
  * flat fp32 bucket of parameters / gradients / moments: a single elementwise pass.  `step` is a
- * zero-initialised 8-byte device buffer: step[0] (float) counts the completed updates and is
- * advanced on the device by the launch itself (step[1] is its internal ticket), so the call is
- * replayable inside a hipGraph.  zero_grad != 0 also clears g (optimizer.zero_grad(), train.py:71). */
+ * zero-initialised device buffer of DC_ADAM_STEP_WORDS 32-bit words: step[0] (float) counts the
+ * completed updates and is advanced on the device by the launch itself (the other words are its
+ * internal tickets), so the call is replayable inside a hipGraph.  zero_grad != 0 also clears g (optimizer.zero_grad(), train.py:71). */
+#define DC_ADAM_STEP_WORDS 34
 int dc_adam_flat(float *p, float *g, float *m, float *v, int64_t n, float *step, float lr,
                  float beta1, float beta2, float eps, int zero_grad, dc_stream_t stream);
 

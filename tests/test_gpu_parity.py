@@ -649,7 +649,7 @@ def test_flat_adam_matches_torch_adam(fused_zero):
             assert not bucket.flat.any()
     for a, b in zip(ref.parameters(), mine.parameters()):
         assert rel_err(_np(b), _np(a)) < 1e-6
-    assert float(o_mine.step_count[0]) == 25.0 and float(o_mine.step_count[1]) == 0.0
+    assert float(o_mine.step_count[0]) == 25.0 and not o_mine.step_count[1:].any()
 
 
 @pytest.mark.parametrize("hidden", [21, 32, 40, 256])
