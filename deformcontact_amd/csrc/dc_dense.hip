@@ -854,6 +854,68 @@ extern "C" int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_fo
     return check_launch("dc_tag_mask_grad");
 }
 
+namespace dc {
+// Everything the h2 dense blocks of one TAGConv layer need from its weights, in ONE launch:
+//   blocks [0, ceil(Fo/4))        : w_rowmax[o]  = max_s,f |W_s[o,f]|            (wave per row o)
+//   blocks [ceil(Fo/4), +ceil(Fi/4)): wt[s][f][:] = W_s[:,f] and wt_rowmax[f] = max_s,o |W_s[o,f]|
+//                                    (wave per column f: strided reads of the L2-resident weights,
+//                                    coalesced writes of the transposed rows)
+struct WPrepParams {
+    const float *w[kMaxSeg];
+    int nseg;
+    int64_t Fo, Fi;
+    float *w_rowmax, *wt, *wt_rowmax;
+};
+__global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rb = (p.Fo + 3) / 4;
+    float m = 0.f;
+    if ((int64_t)blockIdx.x < rb) {
+        const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (o >= p.Fo) return;
+        for (int s = 0; s < p.nseg; ++s) {
+            const float *wr = p.w[s] + o * p.Fi;
+            for (int64_t c = lane; c < p.Fi; c += 64) m = fmaxf(m, fabsf(wr[c]));
+        }
+#pragma unroll
+        for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
+        if (lane == 0) p.w_rowmax[o] = m;
+    } else {
+        const int64_t f = ((int64_t)blockIdx.x - rb) * 4 + (threadIdx.x >> 6);
+        if (f >= p.Fi) return;
+        for (int s = 0; s < p.nseg; ++s) {
+            const float *wc = p.w[s] + f;
+            float *dst = p.wt + ((int64_t)s * p.Fi + f) * p.Fo;
+            for (int64_t o = lane; o < p.Fo; o += 64) {
+                const float v = wc[o * p.Fi];
+                dst[o] = v;
+                m = fmaxf(m, fabsf(v));
+            }
+        }
+#pragma unroll
+        for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
+        if (lane == 0) p.wt_rowmax[f] = m;
+    }
+}
+}  // namespace dc
+
+extern "C" int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,
+                                  float *w_rowmax, float *wt, float *wt_rowmax, dc_stream_t stream) {
+    DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && Fo >= 1 && Fi >= 1 && ws && w_rowmax,
+               "dc_tag_weight_prep: bad arguments");
+    DC_REQUIRE((wt == nullptr) == (wt_rowmax == nullptr),
+               "dc_tag_weight_prep: wt and wt_rowmax go together");
+    WPrepParams p{};
+    for (int s = 0; s < nseg; ++s) {
+        DC_REQUIRE(ws[s], "dc_tag_weight_prep: null segment %d", s);
+        p.w[s] = ws[s];
+    }
+    p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax, p.wt = wt, p.wt_rowmax = wt_rowmax;
+    const int64_t blocks = (Fo + 3) / 4 + (wt ? (Fi + 3) / 4 : 0);
+    hipLaunchKernelGGL(k_weight_prep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dc_tag_weight_prep");
+}
+
 extern "C" int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                                 dc_stream_t stream) {
     DC_REQUIRE(N >= 0 && F >= 1 && F < (1 << 24) && ld >= F, "dc_rowabsmax_f32: bad sizes");

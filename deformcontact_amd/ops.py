@@ -309,9 +309,18 @@ class _TagConvFn(torch.autograd.Function):
         b = bias.contiguous() if bias is not None else None
         args = (_ptr_array(xs), _i64_array(ldxs), _ptr_array(ws), len(xs),
                 b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n, fi_eff, fo)
-        wmax = None
+        wmax = wt = wt_rowmax = None
         if h2:
-            wmax = weight_rowmax(ws)
+            # one launch: row maxima of the weights and, when the input needs a gradient, the
+            # transposed weights + their row maxima for the forward-shaped dX block
+            wmax = torch.empty(fo, dtype=torch.float32, device=dev)
+            if ctx.needs_input_grad[1] and fo % 16 == 0:
+                wt = torch.empty((k + 1, fi, fo), dtype=torch.float32, device=dev)
+                wt_rowmax = torch.empty(fi, dtype=torch.float32, device=dev)
+            _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), k + 1, fo, fi, wmax.data_ptr(),
+                                            wt.data_ptr() if wt is not None else None,
+                                            wt_rowmax.data_ptr() if wt is not None else None, st),
+                       "dc_tag_weight_prep")
             rc = L.dc_tag_linear_fwd_h2(*args, rowmax.data_ptr(), wmax.data_ptr(), st)
         elif DENSE_SPLIT_BF16:
             rc = L.dc_tag_linear_fwd_split(*args, DENSE_PRODUCTS, st)
@@ -322,12 +331,12 @@ class _TagConvFn(torch.autograd.Function):
             g, k, fi, fo, bias is not None, relu, concat
         ctx.params, ctx.bias_param = weights, bias       # the Parameter objects themselves
         ctx.h2 = h2
-        ctx.save_for_backward(slab, out if relu else None, wmax, rowmax, *ws)
+        ctx.save_for_backward(slab, out if relu else None, rowmax, wt, wt_rowmax, *ws)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        slab, out, wmax, xrowmax, *ws = ctx.saved_tensors
+        slab, out, xrowmax, wt, wt_rowmax, *ws = ctx.saved_tensors
         g, k, fi, fo, concat = ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.concat
         L = _lib.lib()
         if gout.stride(1) != 1 or gout.stride(0) % 4 != 0 or gout.data_ptr() % 16 != 0:
@@ -369,11 +378,13 @@ class _TagConvFn(torch.autograd.Function):
             if need_x:
                 chained_hops(g, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
                              rowmax_has_block0=True)
-                wt = torch.empty((k + 1, fi, fo), dtype=torch.float32, device=dev)
-                _lib.check(L.dc_tag_transpose_weights(_ptr_array(ws), k + 1, fo, fi, wt.data_ptr(), st),
-                           "dc_tag_transpose_weights")
+                if wt is None:                       # forward ran without needs_input_grad
+                    wt = torch.empty((k + 1, fi, fo), dtype=torch.float32, device=dev)
+                    wt_rowmax = torch.empty(fi, dtype=torch.float32, device=dev)
+                    _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), k + 1, fo, fi,
+                                                    torch.empty(fo, device=dev).data_ptr(), wt.data_ptr(),
+                                                    wt_rowmax.data_ptr(), st), "dc_tag_weight_prep")
                 wts = [wt[j] for j in range(k + 1)]
-                wt_rowmax = weight_rowmax(wts)
                 gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
                 gblk = [gslab[:, j * fo:(j + 1) * fo] for j in range(k + 1)]
                 rc = L.dc_tag_linear_fwd_h2(_ptr_array(gblk), _i64_array([gwid] * (k + 1)), _ptr_array(wts),

@@ -328,6 +328,12 @@ def test_dense_block_fp16x2_vs_float64(n, fi, fo, nseg, relu, regime):
     rowmax = slab.abs().amax(1).contiguous()
     wmax = ops.weight_rowmax(ws)
     assert torch.equal(wmax, torch.stack([w.abs().amax(1) for w in ws]).amax(0))
+    # the one-launch weight preparation: same row maxima + transposed blocks + their row maxima
+    wm2, wt, wtm = torch.empty(fo, device=DEV), torch.empty(nseg, fi, fo, device=DEV), torch.empty(fi, device=DEV)
+    _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), nseg, fo, fi, wm2.data_ptr(), wt.data_ptr(),
+                                    wtm.data_ptr(), st), "weight_prep")
+    assert torch.equal(wm2, wmax) and torch.equal(wt, torch.stack([w.t() for w in ws]))
+    assert torch.equal(wtm, torch.stack([w.abs().amax(0) for w in ws]).amax(0))
     out = torch.empty(n, fo, device=DEV)
     _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
                                       int(relu), out.data_ptr(), fo, n, fi, fo, rowmax.data_ptr(),
