@@ -158,12 +158,18 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
             g0max = ops.rowabsmax(g)
             keep += [rowmax, wmax, wt, wts, wtmax, pa_wt, gx, growmax, g0max]
 
-            def fwd(n=n, pa_x=pa_x, pa_ld=pa_ld, pa_w=pa_w, bias=bias, out=out, rowmax=rowmax, wmax=wmax):
-                L.dc_tag_linear_fwd_h2(pa_x, pa_ld, pa_w, nseg, bias.data_ptr(), 1, out.data_ptr(), fo, n,
-                                       fi, fo, rowmax.data_ptr(), wmax.data_ptr(), st)
+            wcat = torch.cat(ws, dim=1).contiguous()
+            wtcat = torch.cat(wts, dim=1).contiguous()
+            pa_s, pa_g, pa_c, pa_tc = _ptr_array([slab]), _ptr_array([gslab]), _ptr_array([wcat]), _ptr_array([wtcat])
+            pa_l1 = _i64_array([nseg * fi])
+            keep += [wcat, wtcat, pa_s, pa_g, pa_c, pa_tc, pa_l1]
 
-            def dx(n=n, pa_gx=pa_gx, pa_ld=pa_ld, pa_wt=pa_wt, gx=gx, growmax=growmax, wtmax=wtmax):
-                L.dc_tag_linear_fwd_h2(pa_gx, pa_ld, pa_wt, nseg, None, 0, gx.data_ptr(), fi, n, fo, fi,
+            def fwd(n=n, pa_s=pa_s, pa_l1=pa_l1, pa_c=pa_c, bias=bias, out=out, rowmax=rowmax, wmax=wmax):
+                L.dc_tag_linear_fwd_h2(pa_s, pa_l1, pa_c, 1, bias.data_ptr(), 1, out.data_ptr(), fo, n,
+                                       nseg * fi, fo, rowmax.data_ptr(), wmax.data_ptr(), st)
+
+            def dx(n=n, pa_g=pa_g, pa_l1=pa_l1, pa_tc=pa_tc, gx=gx, growmax=growmax, wtmax=wtmax):
+                L.dc_tag_linear_fwd_h2(pa_g, pa_l1, pa_tc, 1, None, 0, gx.data_ptr(), fi, n, nseg * fo, fi,
                                        growmax.data_ptr(), wtmax.data_ptr(), st)
 
             def dw(n=n, g=g, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb,

@@ -489,6 +489,9 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     DC_REQUIRE(grid < (int64_t)INT32_MAX, "dc_tag_linear_fwd: grid too large");
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
+    static const int h2_tuned = env_int("DC_H2_TUNED", 1);
+    if (products == 2 && vec && h2_tuned && fwd_h2_launch(p, split_mb(N, ntn), hs))
+        return check_launch("dc_tag_linear_fwd_h2");
     if (products && vec && fwd_split_launch(p, split_mb(N, ntn), products, hs))
         return check_launch("dc_tag_linear_fwd_split");
     DC_REQUIRE(products != 2, "dc_tag_linear_fwd_h2: needs Fi %% 16 == 0, 16-byte aligned operands, "
@@ -856,15 +859,17 @@ extern "C" int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_fo
 
 namespace dc {
 // Everything the h2 dense blocks of one TAGConv layer need from its weights, in ONE launch:
-//   blocks [0, ceil(Fo/4))        : w_rowmax[o]  = max_s,f |W_s[o,f]|            (wave per row o)
-//   blocks [ceil(Fo/4), +ceil(Fi/4)): wt[s][f][:] = W_s[:,f] and wt_rowmax[f] = max_s,o |W_s[o,f]|
-//                                    (wave per column f: strided reads of the L2-resident weights,
-//                                    coalesced writes of the transposed rows)
+//   blocks [0, ceil(Fo/4))          : wcat[o][s*Fi + f] = W_s[o,f] (the blocks concatenated along K)
+//                                     and w_rowmax[o] = max_s,f |W_s[o,f]|        (wave per row o)
+//   blocks [ceil(Fo/4), +ceil(Fi/4)): wtcat[f][s*Fo + o] = W_s[o,f] (transposed blocks, concatenated
+//                                     along K of the backward) and wt_rowmax[f] = max_s,o |W_s[o,f]|
+//                                     (wave per column f: strided reads of the L2-resident weights,
+//                                     coalesced writes)
 struct WPrepParams {
     const float *w[kMaxSeg];
     int nseg;
     int64_t Fo, Fi;
-    float *w_rowmax, *wt, *wt_rowmax;
+    float *w_rowmax, *wcat, *wtcat, *wt_rowmax;
 };
 __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
     const int lane = threadIdx.x & 63;
@@ -875,7 +880,12 @@ __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
         if (o >= p.Fo) return;
         for (int s = 0; s < p.nseg; ++s) {
             const float *wr = p.w[s] + o * p.Fi;
-            for (int64_t c = lane; c < p.Fi; c += 64) m = fmaxf(m, fabsf(wr[c]));
+            float *dst = p.wcat ? p.wcat + (o * p.nseg + s) * p.Fi : nullptr;
+            for (int64_t c = lane; c < p.Fi; c += 64) {
+                const float v = wr[c];
+                if (dst) dst[c] = v;
+                m = fmaxf(m, fabsf(v));
+            }
         }
 #pragma unroll
         for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
@@ -885,7 +895,7 @@ __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
         if (f >= p.Fi) return;
         for (int s = 0; s < p.nseg; ++s) {
             const float *wc = p.w[s] + f;
-            float *dst = p.wt + ((int64_t)s * p.Fi + f) * p.Fo;
+            float *dst = p.wtcat + (f * p.nseg + s) * p.Fo;
             for (int64_t o = lane; o < p.Fo; o += 64) {
                 const float v = wc[o * p.Fi];
                 dst[o] = v;
@@ -900,18 +910,20 @@ __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
 }  // namespace dc
 
 extern "C" int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,
-                                  float *w_rowmax, float *wt, float *wt_rowmax, dc_stream_t stream) {
+                                  float *w_rowmax, float *wcat, float *wtcat, float *wt_rowmax,
+                                  dc_stream_t stream) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && Fo >= 1 && Fi >= 1 && ws && w_rowmax,
                "dc_tag_weight_prep: bad arguments");
-    DC_REQUIRE((wt == nullptr) == (wt_rowmax == nullptr),
-               "dc_tag_weight_prep: wt and wt_rowmax go together");
+    DC_REQUIRE((wtcat == nullptr) == (wt_rowmax == nullptr),
+               "dc_tag_weight_prep: wtcat and wt_rowmax go together");
     WPrepParams p{};
     for (int s = 0; s < nseg; ++s) {
         DC_REQUIRE(ws[s], "dc_tag_weight_prep: null segment %d", s);
         p.w[s] = ws[s];
     }
-    p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax, p.wt = wt, p.wt_rowmax = wt_rowmax;
-    const int64_t blocks = (Fo + 3) / 4 + (wt ? (Fi + 3) / 4 : 0);
+    p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax, p.wcat = wcat, p.wtcat = wtcat;
+    p.wt_rowmax = wt_rowmax;
+    const int64_t blocks = (Fo + 3) / 4 + (wtcat ? (Fi + 3) / 4 : 0);
     hipLaunchKernelGGL(k_weight_prep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_tag_weight_prep");
 }

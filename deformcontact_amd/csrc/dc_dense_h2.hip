@@ -1,0 +1,202 @@
+// dc_dense_h2.hip -- the forward-shaped fp16x2 dense block, tuned main loop (gfx950).
+//
+//   out[N,Fo] = act(sum_s xs[s][N,Fi] . ws[s][Fo,Fi]^T + b)      (also the dX block of the backward:
+//   xs = hop slab of the masked gradient, ws = transposed weights, see dc_dense_split.hip)
+//
+// Same arithmetic, LDS layout and epilogue as k_fwd_split<MB, 2> (two power-of-two-scaled fp16
+// planes per operand, products h1*h1 + h1*h2 + h2*h1, 80-byte LDS rows); what differs is the
+// instruction stream of the steady-state loop, which PMC showed to be the limiter (matrix pipe
+// 31 % busy, VALU and MFMA co-executing in only 6 % of the MFMA-busy cycles, ~100 VALU per stage
+// and wave):
+//   * ONE K segment (the host hands over the hop slab whole and the weights concatenated along K by
+//     dc_tag_weight_prep), so operand addresses are a wave-uniform base (SGPR pair, bumped by scalar
+//     adds) plus a constant 32-bit per-thread offset, instead of per-thread 64-bit pointers bumped
+//     with 64-bit VALU adds and re-based at segment switches;
+//   * the steady-state body has no branches (the last two stages are peeled), so the whole stage is
+//     ONE basic block and the split VALU of stage it+1 can be interleaved with the MFMAs of stage
+//     it (__builtin_amdgcn_sched_group_barrier) instead of running before them.
+#include "dc_dense.h"
+
+namespace dc {
+
+using h2_f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using h2_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int kH2Plane = 32;                      // bytes per plane inside an LDS row (16 fp16)
+constexpr int kH2Row = 2 * kH2Plane + 16;         // 80 B: conflict-free b64 stores / b128 reads
+
+__device__ __forceinline__ void h2_split_store(char *dst, float4 x, float s) {
+    x = make_float4(x.x * s, x.y * s, x.z * s, x.w * s);
+    h2_f16x4 h, l;
+    const float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 a = (_Float16)v[i];
+        h[i] = a;
+        l[i] = (_Float16)(v[i] - (float)a);
+    }
+    *reinterpret_cast<h2_f16x4 *>(dst) = h;
+    *reinterpret_cast<h2_f16x4 *>(dst + kH2Plane) = l;
+}
+
+template <int MB>
+__global__ void __launch_bounds__(256)
+k_fwd_h2(FwdParams p) {
+    constexpr int BM = 64 * MB, NVA = BM / 64, NVB = BN / 64;
+    constexpr int kOffB = BM * kH2Row, kStage = (BM + BN) * kH2Row;
+    __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
+    __shared__ float s_inv[BM];
+    const unsigned ntn = (unsigned)((p.Fo + BN - 1) / BN);
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = (int64_t)(lb / ntn) * BM, col0 = (int64_t)(lb % ntn) * BN;
+    const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
+    const int lane = threadIdx.x & 63;
+    const int k4 = threadIdx.x & 3, r = threadIdx.x >> 2;
+    const int64_t lda = p.x[0].ld;
+
+    // per-thread constant offsets (elements) from the block's uniform bases; rows clamped once
+    unsigned offA[NVA], offB[NVB];
+    int ldsA[NVA], ldsB[NVB];
+    float scA[NVA], scB[NVB];
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+        int64_t row = row0 + r + 64 * j;
+        row = row < p.N ? row : p.N - 1;
+        offA[j] = (unsigned)((row - row0) * lda + 4 * k4);
+        ldsA[j] = (r + 64 * j) * kH2Row + 8 * k4;
+        const float m = p.h2.a_rowmax[row];
+        scA[j] = h2_scale(m);
+        if (k4 == 0) s_inv[r + 64 * j] = h2_unscale(m);
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+        int64_t col = col0 + r + 64 * j;
+        col = col < p.Fo ? col : p.Fo - 1;
+        offB[j] = (unsigned)((col - col0) * p.Fi + 4 * k4);
+        ldsB[j] = kOffB + (r + 64 * j) * kH2Row + 8 * k4;
+        scB[j] = h2_scale(p.h2.b_rowmax[col]);
+    }
+
+    f32x16 acc[MB][2];
+    zero_acc<MB>(acc);
+    const int nst = (int)(p.Fi / BK);                 // ONE segment (launcher): plain K loop
+    // wave-uniform running bases (scalar registers)
+    const float *baseA = p.x[0].p + row0 * lda;
+    const float *baseB = p.w[0].p + col0 * p.Fi;
+    float4 va[NVA], vb[NVB];
+
+    auto load = [&]() {
+#pragma unroll
+        for (int j = 0; j < NVA; ++j) va[j] = *reinterpret_cast<const float4 *>(baseA + offA[j]);
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) vb[j] = *reinterpret_cast<const float4 *>(baseB + offB[j]);
+        baseA += BK;                                  // scalar adds
+        baseB += BK;
+    };
+    auto store = [&](char *buf) {
+#pragma unroll
+        for (int j = 0; j < NVA; ++j) h2_split_store(buf + ldsA[j], va[j], scA[j]);
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) h2_split_store(buf + ldsB[j], vb[j], scB[j]);
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fragA = (wm * 32 * MB + fr) * kH2Row + 16 * fh;
+    const int fragB = kOffB + (wn * 64 + fr) * kH2Row + 16 * fh;
+    h2_f16x8 fa[MB][2], fb[2][2];
+    auto frags = [&](const char *buf) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                fa[mb][pl] = *reinterpret_cast<const h2_f16x8 *>(buf + fragA + mb * 32 * kH2Row + pl * kH2Plane);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                fb[nb][pl] = *reinterpret_cast<const h2_f16x8 *>(buf + fragB + nb * 32 * kH2Row + pl * kH2Plane);
+    };
+    auto mma = [&]() {
+        constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};       // smallest terms first
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mb][pa[t]], fb[nb][pb[t]],
+                                                                         acc[mb][nb], 0, 0, 0);
+    };
+
+    if (nst > 0) {
+        load();
+        store(lds);
+        if (nst > 1) load();
+        __syncthreads();
+        int it = 0;
+        for (; it + 2 < nst; ++it) {                 // steady state: one basic block
+            char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
+            frags(cur);
+            store(nxt);
+            load();
+            mma();
+            // issue order: fragment reads first, then the MFMAs with the split VALU / LDS stores of
+            // the next stage in their shadows, the global loads of stage it+2 as soon as their
+            // registers are free
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * MB + 4, 0);                   // DS_READ
+#pragma unroll
+            for (int q = 0; q < 6 * MB; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x2, MB == 2 ? 8 : 10, 0);   // VALU
+                if ((q % 3) == 2) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   // DS_WRITE
+            }
+            __builtin_amdgcn_sched_group_barrier(0x20, NVA + NVB, 0);             // VMEM_READ
+            __syncthreads();
+        }
+        for (; it < nst; ++it) {                     // last two stages
+            char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
+            frags(cur);
+            if (it + 1 < nst) store(nxt);
+            mma();
+            __syncthreads();
+        }
+    }
+
+    float bcol[2], icol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int64_t col = col0 + wn * 64 + nb * 32 + (threadIdx.x & 31);
+        bcol[nb] = (p.bias && col < p.Fo) ? p.bias[col] : 0.f;
+        icol[nb] = h2_unscale(p.h2.b_rowmax[col < p.Fo ? col : p.Fo - 1]);
+    }
+    const bool relu = p.relu != 0;
+    for_each_acc<MB>(acc, wm, wn, [&](int rr, int c, float v) {
+        const int64_t row = row0 + rr, col = col0 + c;
+        if (row < p.N && col < p.Fo) {
+            v = (v * s_inv[rr]) * icol[(c >> 5) & 1];
+            v += bcol[(c >> 5) & 1];
+            if (relu) v = fmaxf(v, 0.f);
+            p.out[row * p.ldo + col] = v;
+        }
+    });
+}
+
+static inline bool h2_al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
+
+bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs) {
+    if (!p.h2.a_rowmax || !p.h2.b_rowmax || p.nseg != 1) return false;
+    if (p.Fi % BK != 0 || p.Fi < BK) return false;
+    // 32-bit per-thread offsets: a block touches 128 rows of each operand
+    if (p.x[0].ld * 128 >= ((int64_t)1 << 30) || p.Fi * 128 >= ((int64_t)1 << 30)) return false;
+    for (int s = 0; s < p.nseg; ++s)
+        if (!h2_al16(p.x[s].p) || !h2_al16(p.w[s].p) || p.x[s].ld % 4 != 0 || p.x[s].ld != p.x[0].ld)
+            return false;
+    const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
+    const dim3 gd((unsigned)grid), bd(256);
+    if (mb == 2)
+        hipLaunchKernelGGL((k_fwd_h2<2>), gd, bd, 0, hs, p);
+    else
+        hipLaunchKernelGGL((k_fwd_h2<1>), gd, bd, 0, hs, p);
+    return true;
+}
+
+}  // namespace dc

@@ -236,11 +236,14 @@ int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_for_mask, int
                      dc_stream_t stream);
 int dc_tag_transpose_weights(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *wt,
                              dc_stream_t stream);
-/* One launch for everything the h2 blocks of a layer need from its weights: w_rowmax [Fo] (as
- * dc_tag_weight_rowmax) and, when wt != NULL, the transposed blocks wt [nseg][Fi][Fo] (as
- * dc_tag_transpose_weights) with wt_rowmax[f] = max_s,o |W_s[o,f]| [Fi] for the backward. */
+/* One launch for everything the h2 blocks of a layer need from its weights W_s [Fo, Fi], s < nseg:
+ *   w_rowmax [Fo]             as dc_tag_weight_rowmax;
+ *   wcat  [Fo, nseg*Fi]       (optional) the blocks concatenated along the forward's reduction, so the
+ *                             forward block runs as ONE segment over the whole hop slab;
+ *   wtcat [Fi, nseg*Fo], wt_rowmax [Fi]  (optional, together) the transposed blocks concatenated along
+ *                             the backward's reduction and wt_rowmax[f] = max_s,o |W_s[o,f]|. */
 int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
-                       float *wt, float *wt_rowmax, dc_stream_t stream);
+                       float *wcat, float *wtcat, float *wt_rowmax, dc_stream_t stream);
 /* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
 int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                      dc_stream_t stream);

@@ -326,18 +326,6 @@ def test_dense_block_fp16x2_vs_float64(n, fi, fo, nseg, relu, regime):
     ws = [torch.from_numpy(hashed_uniform((fo, fi), 40 + s, wscale)).to(DEV) for s in range(nseg)]
     bias = torch.from_numpy(hashed_uniform((fo,), 77, 0.5)).to(DEV) * float(slab.abs().max()) * wscale
     rowmax = slab.abs().amax(1).contiguous()
-    wmax = ops.weight_rowmax(ws)
-    assert torch.equal(wmax, torch.stack([w.abs().amax(1) for w in ws]).amax(0))
-    # the one-launch weight preparation: same row maxima + transposed blocks + their row maxima
-    wm2, wt, wtm = torch.empty(fo, device=DEV), torch.empty(nseg, fi, fo, device=DEV), torch.empty(fi, device=DEV)
-    _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), nseg, fo, fi, wm2.data_ptr(), wt.data_ptr(),
-                                    wtm.data_ptr(), st), "weight_prep")
-    assert torch.equal(wm2, wmax) and torch.equal(wt, torch.stack([w.t() for w in ws]))
-    assert torch.equal(wtm, torch.stack([w.abs().amax(0) for w in ws]).amax(0))
-    out = torch.empty(n, fo, device=DEV)
-    _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
-                                      int(relu), out.data_ptr(), fo, n, fi, fo, rowmax.data_ptr(),
-                                      wmax.data_ptr(), st), "fwd_h2")
     ref = sum(xs[s].double().cpu() @ ws[s].double().cpu().t() for s in range(nseg)) + bias.double().cpu()
     if relu:
         ref = ref.clamp_min(0)
@@ -347,6 +335,27 @@ def test_dense_block_fp16x2_vs_float64(n, fi, fo, nseg, relu, regime):
         den = np.abs(b).max(axis=1, keepdims=True)
         den[den == 0] = 1.0
         return float((np.abs(a - b) / den).max())
+    wmax = ops.weight_rowmax(ws)
+    assert torch.equal(wmax, torch.stack([w.abs().amax(1) for w in ws]).amax(0))
+    # the one-launch weight preparation: same row maxima + transposed blocks + their row maxima
+    wm2, wtm = torch.empty(fo, device=DEV), torch.empty(fi, device=DEV)
+    wcat, wt = torch.empty(fo, nseg * fi, device=DEV), torch.empty(fi, nseg * fo, device=DEV)
+    _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), nseg, fo, fi, wm2.data_ptr(), wcat.data_ptr(),
+                                    wt.data_ptr(), wtm.data_ptr(), st), "weight_prep")
+    assert torch.equal(wm2, wmax) and torch.equal(wcat, torch.cat(ws, dim=1))
+    assert torch.equal(wt, torch.cat([w.t() for w in ws], dim=1))
+    assert torch.equal(wtm, torch.stack([w.abs().amax(0) for w in ws]).amax(0))
+    # the same forward as ONE segment over the whole slab with the concatenated weights (the tuned
+    # single-segment kernel): identical products and order, so identical results
+    out1 = torch.empty(n, fo, device=DEV)
+    _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array([slab]), _i64_array([nseg * fi]), _ptr_array([wcat]), 1,
+                                      bias.data_ptr(), int(relu), out1.data_ptr(), fo, n, nseg * fi, fo,
+                                      rowmax.data_ptr(), wmax.data_ptr(), st), "fwd_h2 one segment")
+    assert row_rel(_np(out1), ref.numpy()) < 2e-6
+    out = torch.empty(n, fo, device=DEV)
+    _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
+                                      int(relu), out.data_ptr(), fo, n, fi, fo, rowmax.data_ptr(),
+                                      wmax.data_ptr(), st), "fwd_h2")
     assert row_rel(_np(out), ref.numpy()) < 2e-6
     # dX: rows of g scaled by their own maxima inside the kernel (also returned)
     mask = out.data_ptr() if relu else None

@@ -90,8 +90,11 @@ def main():
         growmax = torch.empty(n, device=dev)
         wmax = ops.weight_rowmax(ws)
 
+        wcat = torch.cat(ws, dim=1).contiguous()
+        pa_s, pa_c, pa_l1 = _ptr_array([slab]), _ptr_array([wcat]), _i64_array([nseg * fi])
+
         def fwd_h():
-            L.dc_tag_linear_fwd_h2(pa_x, pa_ld, pa_w, nseg, bias.data_ptr(), 1, out.data_ptr(), fo, n, fi, fo,
+            L.dc_tag_linear_fwd_h2(pa_s, pa_l1, pa_c, 1, bias.data_ptr(), 1, out.data_ptr(), fo, n, nseg * fi, fo,
                                    rowmax.data_ptr(), wmax.data_ptr(), st)
 
         def dx_h():
