@@ -102,7 +102,7 @@ def main():
                                       wsx.data_ptr(), wsb, n, fi, fo, growmax.data_ptr(), wmax.data_ptr(), st)
 
         def dw_h():
-            L.dc_tag_linear_bwd_dw_h2(g.data_ptr(), fo, out.data_ptr(), fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
+            L.dc_tag_linear_bwd_dw_h2(g.data_ptr(), fo, None, fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
                                       gb.data_ptr(), 0, scratch.data_ptr(), nbytes, n, fi, fo,
                                       growmax.data_ptr(), rowmax.data_ptr(), st)
 
