@@ -104,6 +104,7 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     }
 }
 
+
 // ---- L lanes per row, 64/L rows per wave (narrow feature rows) -------------
 template <int VEC, int L, int U>
 __global__ void __launch_bounds__(256)
