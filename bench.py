@@ -158,19 +158,19 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
             g0max = ops.rowabsmax(g)
             keep += [rowmax, wmax, wt, wts, wtmax, pa_wt, gx, growmax, g0max]
 
-            wcat = torch.cat(ws, dim=1).contiguous()
-            wtcat = torch.cat(wts, dim=1).contiguous()
-            pa_s, pa_g, pa_c, pa_tc = _ptr_array([slab]), _ptr_array([gslab]), _ptr_array([wcat]), _ptr_array([wtcat])
-            pa_l1 = _i64_array([nseg * fi])
-            keep += [wcat, wtcat, pa_s, pa_g, pa_c, pa_tc, pa_l1]
+            wimg, wtimg = torch.empty(fo, nseg * fi, device=dev), torch.empty(fi, nseg * fo, device=dev)
+            L.dc_tag_weight_prep(pa_w, nseg, fo, fi, wmax.data_ptr(), wimg.data_ptr(), wtimg.data_ptr(),
+                                 wtmax.data_ptr(), st)
+            keep += [wimg, wtimg]
 
-            def fwd(n=n, pa_s=pa_s, pa_l1=pa_l1, pa_c=pa_c, bias=bias, out=out, rowmax=rowmax, wmax=wmax):
-                L.dc_tag_linear_fwd_h2(pa_s, pa_l1, pa_c, 1, bias.data_ptr(), 1, out.data_ptr(), fo, n,
-                                       nseg * fi, fo, rowmax.data_ptr(), wmax.data_ptr(), st)
+            def fwd(n=n, slab=slab, wimg=wimg, bias=bias, out=out, rowmax=rowmax, wmax=wmax):
+                L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), bias.data_ptr(), 1,
+                                        out.data_ptr(), fo, n, nseg * fi, fo, rowmax.data_ptr(),
+                                        wmax.data_ptr(), st)
 
-            def dx(n=n, pa_g=pa_g, pa_l1=pa_l1, pa_tc=pa_tc, gx=gx, growmax=growmax, wtmax=wtmax):
-                L.dc_tag_linear_fwd_h2(pa_g, pa_l1, pa_tc, 1, None, 0, gx.data_ptr(), fi, n, nseg * fo, fi,
-                                       growmax.data_ptr(), wtmax.data_ptr(), st)
+            def dx(n=n, gslab=gslab, wtimg=wtimg, gx=gx, growmax=growmax, wtmax=wtmax):
+                L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), nseg * fo, wtimg.data_ptr(), None, 0, gx.data_ptr(),
+                                        fi, n, nseg * fo, fi, growmax.data_ptr(), wtmax.data_ptr(), st)
 
             def dw(n=n, g=g, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb,
                    g0max=g0max, rowmax=rowmax):

@@ -104,6 +104,7 @@ __device__ __forceinline__ void for_each_acc(const f32x16 (&acc)[MB][2], int wm,
 struct H2Scales {
     const float *a_rowmax;   // fwd: [N] max |x[row, :]| over all segments; dX, dW: [N] max |g[row, :]|
     const float *b_rowmax;   // fwd / dX: [Fo] max_s,f |W_s[o, f]|;  dW: [N] max |x[row, :]|
+    int b_presplit;          // fwd: w[0] is the scaled fp16x2 image written by dc_tag_weight_prep
 };
 
 __device__ __forceinline__ unsigned h2_exp(float m) {

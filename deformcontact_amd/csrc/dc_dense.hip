@@ -492,6 +492,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     static const int h2_tuned = env_int("DC_H2_TUNED", 1);
     if (products == 2 && vec && h2_tuned && fwd_h2_launch(p, split_mb(N, ntn), hs))
         return check_launch("dc_tag_linear_fwd_h2");
+    DC_REQUIRE(!h2.b_presplit, "dc_tag_linear_fwd_h2p: shape not eligible for the pre-split kernel");
     if (products && vec && fwd_split_launch(p, split_mb(N, ntn), products, hs))
         return check_launch("dc_tag_linear_fwd_split");
     DC_REQUIRE(products != 2, "dc_tag_linear_fwd_h2: needs Fi %% 16 == 0, 16-byte aligned operands, "
@@ -727,6 +728,23 @@ extern "C" int dc_tag_linear_fwd_h2(const float *const *xs, const int64_t *ldxs,
     return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, 2, h);
 }
 
+extern "C" int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_image,
+                                     const float *bias, int relu, float *out, int64_t ldo, int64_t N,
+                                     int64_t K, int64_t Fo, const float *x_rowmax,
+                                     const float *w_rowmax, dc_stream_t stream) {
+    DC_REQUIRE(x && w_image && x_rowmax && w_rowmax, "dc_tag_linear_fwd_h2p: null pointer");
+    DC_REQUIRE(K >= 16 && K % 16 == 0 && ldx >= K && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
+                   (((uintptr_t)w_image) & 15) == 0,
+               "dc_tag_linear_fwd_h2p: K %% 16 == 0 and 16-byte aligned operands required (K=%lld)",
+               (long long)K);
+    H2Scales h{};
+    h.a_rowmax = x_rowmax, h.b_rowmax = w_rowmax, h.b_presplit = 1;
+    const float *xs[1] = {x};
+    const float *ws[1] = {(const float *)w_image};   // 4 bytes per element, fp32 addressing
+    const int64_t ld[1] = {ldx};
+    return fwd_impl(xs, ld, ws, 1, bias, relu, out, ldo, N, K, Fo, stream, 2, h);
+}
+
 extern "C" int dc_tag_linear_bwd_dx_h2(const float *g, int64_t ldg, const float *out_for_mask,
                                        int64_t ldo, const float *const *ws, int nseg,
                                        float *const *gxs, const int64_t *ldgxs, void *workspace,
@@ -859,18 +877,29 @@ extern "C" int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_fo
 
 namespace dc {
 // Everything the h2 dense blocks of one TAGConv layer need from its weights, in ONE launch:
-//   blocks [0, ceil(Fo/4))          : wcat[o][s*Fi + f] = W_s[o,f] (the blocks concatenated along K)
-//                                     and w_rowmax[o] = max_s,f |W_s[o,f]|        (wave per row o)
-//   blocks [ceil(Fo/4), +ceil(Fi/4)): wtcat[f][s*Fo + o] = W_s[o,f] (transposed blocks, concatenated
-//                                     along K of the backward) and wt_rowmax[f] = max_s,o |W_s[o,f]|
-//                                     (wave per column f: strided reads of the L2-resident weights,
-//                                     coalesced writes)
+//   blocks [0, ceil(Fo/4))          : w_rowmax[o] = max_s,f |W_s[o,f]| and (optional) the scaled
+//                                     fp16x2 image of row o over the concatenated reduction
+//                                     k = s*Fi + f  (wave per row o, two passes over its 4 KiB)
+//   blocks [ceil(Fo/4), +ceil(Fi/4)): the same for the transposed weights: wt_rowmax[f] =
+//                                     max_s,o |W_s[o,f]| and the image of row f over k = s*Fo + o
+//                                     (wave per column f: strided reads of the L2-resident weights)
+// Image of a row: per 16-wide stage one 64-byte record {h1[16], h2[16]} (fp16), x * 2^e = h1 + h2
+// with the row's power-of-two scale (dc_dense.h) - the bytes k_fwd_h2 wants in LDS, so that kernel
+// stages the weights by LDS-DMA without touching registers or the VALU.
 struct WPrepParams {
     const float *w[kMaxSeg];
     int nseg;
     int64_t Fo, Fi;
-    float *w_rowmax, *wcat, *wtcat, *wt_rowmax;
+    float *w_rowmax, *wt_rowmax;
+    _Float16 *wimg, *wtimg;
 };
+__device__ __forceinline__ void wprep_put(_Float16 *img_row, int64_t k, float v, float scale) {
+    const float x = v * scale;
+    const _Float16 h = (_Float16)x;
+    _Float16 *rec = img_row + (k >> 4) * 32 + (k & 15);
+    rec[0] = h;
+    rec[16] = (_Float16)(x - (float)h);
+}
 __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t rb = (p.Fo + 3) / 4;
@@ -880,50 +909,58 @@ __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
         if (o >= p.Fo) return;
         for (int s = 0; s < p.nseg; ++s) {
             const float *wr = p.w[s] + o * p.Fi;
-            float *dst = p.wcat ? p.wcat + (o * p.nseg + s) * p.Fi : nullptr;
-            for (int64_t c = lane; c < p.Fi; c += 64) {
-                const float v = wr[c];
-                if (dst) dst[c] = v;
-                m = fmaxf(m, fabsf(v));
-            }
+            for (int64_t c = lane; c < p.Fi; c += 64) m = fmaxf(m, fabsf(wr[c]));
         }
 #pragma unroll
         for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
         if (lane == 0) p.w_rowmax[o] = m;
+        if (p.wimg) {
+            const float sc = h2_scale(m);
+            _Float16 *row = p.wimg + o * (2 * p.nseg * p.Fi);
+            for (int s = 0; s < p.nseg; ++s) {
+                const float *wr = p.w[s] + o * p.Fi;
+                for (int64_t c = lane; c < p.Fi; c += 64) wprep_put(row, s * p.Fi + c, wr[c], sc);
+            }
+        }
     } else {
         const int64_t f = ((int64_t)blockIdx.x - rb) * 4 + (threadIdx.x >> 6);
         if (f >= p.Fi) return;
         for (int s = 0; s < p.nseg; ++s) {
             const float *wc = p.w[s] + f;
-            float *dst = p.wtcat + (f * p.nseg + s) * p.Fo;
-            for (int64_t o = lane; o < p.Fo; o += 64) {
-                const float v = wc[o * p.Fi];
-                dst[o] = v;
-                m = fmaxf(m, fabsf(v));
-            }
+            for (int64_t o = lane; o < p.Fo; o += 64) m = fmaxf(m, fabsf(wc[o * p.Fi]));
         }
 #pragma unroll
         for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
         if (lane == 0) p.wt_rowmax[f] = m;
+        const float sc = h2_scale(m);
+        _Float16 *row = p.wtimg + f * (2 * p.nseg * p.Fo);
+        for (int s = 0; s < p.nseg; ++s) {
+            const float *wc = p.w[s] + f;
+            for (int64_t o = lane; o < p.Fo; o += 64) wprep_put(row, s * p.Fo + o, wc[o * p.Fi], sc);
+        }
     }
 }
 }  // namespace dc
 
 extern "C" int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,
-                                  float *w_rowmax, float *wcat, float *wtcat, float *wt_rowmax,
+                                  float *w_rowmax, void *w_image, void *wt_image, float *wt_rowmax,
                                   dc_stream_t stream) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && Fo >= 1 && Fi >= 1 && ws && w_rowmax,
                "dc_tag_weight_prep: bad arguments");
-    DC_REQUIRE((wtcat == nullptr) == (wt_rowmax == nullptr),
-               "dc_tag_weight_prep: wtcat and wt_rowmax go together");
+    DC_REQUIRE((wt_image == nullptr) == (wt_rowmax == nullptr),
+               "dc_tag_weight_prep: wt_image and wt_rowmax go together");
+    DC_REQUIRE((!w_image || (nseg * Fi) % 16 == 0) && (!wt_image || (nseg * Fo) % 16 == 0),
+               "dc_tag_weight_prep: images need a reduction extent that is a multiple of 16");
+    DC_REQUIRE((((uintptr_t)w_image) & 15) == 0 && (((uintptr_t)wt_image) & 15) == 0,
+               "dc_tag_weight_prep: images must be 16-byte aligned");
     WPrepParams p{};
     for (int s = 0; s < nseg; ++s) {
         DC_REQUIRE(ws[s], "dc_tag_weight_prep: null segment %d", s);
         p.w[s] = ws[s];
     }
-    p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax, p.wcat = wcat, p.wtcat = wtcat;
-    p.wt_rowmax = wt_rowmax;
-    const int64_t blocks = (Fo + 3) / 4 + (wtcat ? (Fi + 3) / 4 : 0);
+    p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax, p.wt_rowmax = wt_rowmax;
+    p.wimg = (_Float16 *)w_image, p.wtimg = (_Float16 *)wt_image;
+    const int64_t blocks = (Fo + 3) / 4 + (wt_image ? (Fi + 3) / 4 : 0);
     hipLaunchKernelGGL(k_weight_prep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_tag_weight_prep");
 }

@@ -39,11 +39,18 @@ __device__ __forceinline__ void h2_split_store(char *dst, float4 x, float s) {
     *reinterpret_cast<h2_f16x4 *>(dst + kH2Plane) = l;
 }
 
-template <int MB>
+template <int MB, bool BDMA>
 __global__ void __launch_bounds__(256)
 k_fwd_h2(FwdParams p) {
     constexpr int BM = 64 * MB, NVA = BM / 64, NVB = BN / 64;
-    constexpr int kOffB = BM * kH2Row, kStage = (BM + BN) * kH2Row;
+    // BDMA: the weights arrive already scaled and split (dc_tag_weight_prep: one 64-byte record
+    // {h1[16], h2[16]} per row and stage) and go global -> LDS by LDS-DMA, bypassing registers and
+    // the VALU.  The DMA writes lane i's 16 bytes at base + 16*i, so the B image is dense (64-byte
+    // rows) and the bank spread of the b128 fragment reads comes from an XOR swizzle instead of
+    // padding: piece q of row r sits at position q ^ ((r >> 2) & 3); each lane simply FETCHES the
+    // piece that belongs at its position.
+    constexpr int kRowB = BDMA ? 64 : kH2Row;
+    constexpr int kOffB = BM * kH2Row, kStage = BM * kH2Row + BN * kRowB;
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
     __shared__ float s_inv[BM];
     const unsigned ntn = (unsigned)((p.Fo + BN - 1) / BN);
@@ -74,7 +81,16 @@ k_fwd_h2(FwdParams p) {
         col = col < p.Fo ? col : p.Fo - 1;
         offB[j] = (unsigned)((col - col0) * p.Fi + 4 * k4);
         ldsB[j] = kOffB + (r + 64 * j) * kH2Row + 8 * k4;
-        scB[j] = h2_scale(p.h2.b_rowmax[col]);
+        scB[j] = BDMA ? 1.f : h2_scale(p.h2.b_rowmax[col]);
+    }
+    // BDMA: wave `wid` fills rows [32*wid, 32*wid+32) of the B image with two 1 KiB DMA pieces
+    unsigned dmaOff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rowl = wid * 32 + q * 16 + (lane >> 2);
+        int64_t col = col0 + rowl;
+        col = col < p.Fo ? col : p.Fo - 1;
+        dmaOff[q] = (unsigned)((col - col0) * p.Fi + 4 * ((lane & 3) ^ ((rowl >> 2) & 3)));
     }
 
     f32x16 acc[MB][2];
@@ -88,20 +104,40 @@ k_fwd_h2(FwdParams p) {
     auto load = [&]() {
 #pragma unroll
         for (int j = 0; j < NVA; ++j) va[j] = *reinterpret_cast<const float4 *>(baseA + offA[j]);
-#pragma unroll
-        for (int j = 0; j < NVB; ++j) vb[j] = *reinterpret_cast<const float4 *>(baseB + offB[j]);
         baseA += BK;                                  // scalar adds
+        if (!BDMA) {
+#pragma unroll
+            for (int j = 0; j < NVB; ++j) vb[j] = *reinterpret_cast<const float4 *>(baseB + offB[j]);
+            baseB += BK;
+        }
+    };
+    auto dma_b = [&](char *buf) {                     // B of the NEXT stage straight into `buf`
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds(
+                (const void __attribute__((address_space(1))) *)(baseB + dmaOff[q]),
+                (void __attribute__((address_space(3))) *)(buf + kOffB + (wid * 32 + q * 16) * 64), 16, 0, 0);
         baseB += BK;
     };
     auto store = [&](char *buf) {
 #pragma unroll
         for (int j = 0; j < NVA; ++j) h2_split_store(buf + ldsA[j], va[j], scA[j]);
+        if (!BDMA) {
 #pragma unroll
-        for (int j = 0; j < NVB; ++j) h2_split_store(buf + ldsB[j], vb[j], scB[j]);
+            for (int j = 0; j < NVB; ++j) h2_split_store(buf + ldsB[j], vb[j], scB[j]);
+        }
     };
     const int fr = lane & 31, fh = lane >> 5;
     const int fragA = (wm * 32 * MB + fr) * kH2Row + 16 * fh;
     const int fragB = kOffB + (wn * 64 + fr) * kH2Row + 16 * fh;
+    int fragBd[2][2];                                 // BDMA: swizzled positions of (nb, plane)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const int rowl = wn * 64 + nb * 32 + fr;
+            fragBd[nb][pl] = kOffB + rowl * 64 + 16 * ((2 * pl + fh) ^ ((rowl >> 2) & 3));
+        }
     h2_f16x8 fa[MB][2], fb[2][2];
     auto frags = [&](const char *buf) {
 #pragma unroll
@@ -113,7 +149,9 @@ k_fwd_h2(FwdParams p) {
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                fb[nb][pl] = *reinterpret_cast<const h2_f16x8 *>(buf + fragB + nb * 32 * kH2Row + pl * kH2Plane);
+                fb[nb][pl] = BDMA ? *reinterpret_cast<const h2_f16x8 *>(buf + fragBd[nb][pl])
+                                  : *reinterpret_cast<const h2_f16x8 *>(buf + fragB + nb * 32 * kH2Row +
+                                                                          pl * kH2Plane);
     };
     auto mma = [&]() {
         constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};       // smallest terms first
@@ -128,17 +166,23 @@ k_fwd_h2(FwdParams p) {
     };
 
     if (nst > 0) {
+        if (BDMA) dma_b(lds);
         load();
         store(lds);
         if (nst > 1) load();
+        if (BDMA) __builtin_amdgcn_s_waitcnt(0xF70 | 0);      // vmcnt(0): the DMA piece has landed
         __syncthreads();
         int it = 0;
         for (; it + 2 < nst; ++it) {                 // steady state: one basic block
             char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
             frags(cur);
+            if (BDMA) dma_b(nxt);                     // lands during this stage's MFMAs
             store(nxt);
             load();
             mma();
+            // the DMA pieces (issued before this stage's NVA loads) must be in LDS before the
+            // barrier; the register loads of stage it+2 may stay in flight
+            if (BDMA) __builtin_amdgcn_s_waitcnt(0xF70 | NVA);
             // (explicit sched_group_barrier orders - 1 MFMA : 6-8 VALU, VALU first, early loads, 2 MFMA
             // groups - all measured 1-3 % slower than hipcc's own order of this single block)
             __syncthreads();
@@ -146,8 +190,12 @@ k_fwd_h2(FwdParams p) {
         for (; it < nst; ++it) {                     // last two stages
             char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
             frags(cur);
-            if (it + 1 < nst) store(nxt);
+            if (it + 1 < nst) {
+                if (BDMA) dma_b(nxt);
+                store(nxt);
+            }
             mma();
+            if (BDMA) __builtin_amdgcn_s_waitcnt(0xF70 | 0);
             __syncthreads();
         }
     }
@@ -185,10 +233,13 @@ bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs) {
             return false;
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
     const dim3 gd((unsigned)grid), bd(256);
-    if (mb == 2)
-        hipLaunchKernelGGL((k_fwd_h2<2>), gd, bd, 0, hs, p);
-    else
-        hipLaunchKernelGGL((k_fwd_h2<1>), gd, bd, 0, hs, p);
+    if (p.h2.b_presplit) {
+        if (mb == 2) hipLaunchKernelGGL((k_fwd_h2<2, true>), gd, bd, 0, hs, p);
+        else hipLaunchKernelGGL((k_fwd_h2<1, true>), gd, bd, 0, hs, p);
+    } else {
+        if (mb == 2) hipLaunchKernelGGL((k_fwd_h2<2, false>), gd, bd, 0, hs, p);
+        else hipLaunchKernelGGL((k_fwd_h2<1, false>), gd, bd, 0, hs, p);
+    }
     return true;
 }
 

@@ -311,22 +311,23 @@ class _TagConvFn(torch.autograd.Function):
                 b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n, fi_eff, fo)
         wmax = wt = wt_rowmax = None
         if h2:
-            # one launch: the weights concatenated along K (the dense block then runs as ONE
-            # segment over the whole slab), their row maxima and, when the input needs a gradient,
-            # the transposed-and-concatenated weights + row maxima for the forward-shaped dX block
+            # one launch: the weights scaled and split into their fp16 planes over the concatenated
+            # reduction (the dense block runs as ONE segment over the whole slab and pulls them into
+            # LDS by DMA), their row maxima and, when the input needs a gradient, the same for the
+            # transposed weights (forward-shaped dX block)
             wmax = torch.empty(fo, dtype=torch.float32, device=dev)
-            wcat = torch.empty((fo, width), dtype=torch.float32, device=dev)
+            wimg = torch.empty((fo, width), dtype=torch.float32, device=dev)     # 4 B / element
             if ctx.needs_input_grad[1] and fo % 16 == 0:
                 wt = torch.empty((fi, (k + 1) * fo), dtype=torch.float32, device=dev)
                 wt_rowmax = torch.empty(fi, dtype=torch.float32, device=dev)
-            _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), k + 1, fo, fi, wmax.data_ptr(), wcat.data_ptr(),
+            _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), k + 1, fo, fi, wmax.data_ptr(), wimg.data_ptr(),
                                             wt.data_ptr() if wt is not None else None,
                                             wt_rowmax.data_ptr() if wt is not None else None, st),
                        "dc_tag_weight_prep")
-            rc = L.dc_tag_linear_fwd_h2(_ptr_array([slab]), _i64_array([wpad]), _ptr_array([wcat]), 1,
-                                        b.data_ptr() if b is not None else None, int(relu),
-                                        out.data_ptr(), ldo, n, width, fo,
-                                        rowmax.data_ptr(), wmax.data_ptr(), st)
+            rc = L.dc_tag_linear_fwd_h2p(slab.data_ptr(), wpad, wimg.data_ptr(),
+                                         b.data_ptr() if b is not None else None, int(relu),
+                                         out.data_ptr(), ldo, n, width, fo,
+                                         rowmax.data_ptr(), wmax.data_ptr(), st)
         elif DENSE_SPLIT_BF16:
             rc = L.dc_tag_linear_fwd_split(*args, DENSE_PRODUCTS, st)
         else:
@@ -391,9 +392,9 @@ class _TagConvFn(torch.autograd.Function):
                                                     wt.data_ptr(), wt_rowmax.data_ptr(), st),
                                "dc_tag_weight_prep")
                 gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
-                rc = L.dc_tag_linear_fwd_h2(_ptr_array([gslab]), _i64_array([gwid]), _ptr_array([wt]), 1,
-                                            None, 0, gx.data_ptr(), fi, n, gwid, fi,
-                                            hop_rowmax.data_ptr(), wt_rowmax.data_ptr(), st)
+                rc = L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gwid, wt.data_ptr(), None, 0, gx.data_ptr(),
+                                             fi, n, gwid, fi, hop_rowmax.data_ptr(), wt_rowmax.data_ptr(),
+                                             st)
                 _lib.check(rc, "dc_tag_linear_fwd_h2 (dX)")
                 need_x = False                               # done
 

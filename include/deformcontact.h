@@ -237,13 +237,23 @@ int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_for_mask, int
 int dc_tag_transpose_weights(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *wt,
                              dc_stream_t stream);
 /* One launch for everything the h2 blocks of a layer need from its weights W_s [Fo, Fi], s < nseg:
- *   w_rowmax [Fo]             as dc_tag_weight_rowmax;
- *   wcat  [Fo, nseg*Fi]       (optional) the blocks concatenated along the forward's reduction, so the
- *                             forward block runs as ONE segment over the whole hop slab;
- *   wtcat [Fi, nseg*Fo], wt_rowmax [Fi]  (optional, together) the transposed blocks concatenated along
- *                             the backward's reduction and wt_rowmax[f] = max_s,o |W_s[o,f]|. */
+ *   w_rowmax [Fo]          as dc_tag_weight_rowmax;
+ *   w_image                (optional) the weights ALREADY scaled and split for the forward block: for
+ *                          row o and every 16-wide stage of the concatenated reduction k = s*Fi + f one
+ *                          64-byte record {h1[16], h2[16]} (fp16), W*2^e(o) = h1 + h2 with the row's scale
+ *                          - Fo * nseg*Fi * 4 bytes, 16-byte aligned; consumed by dc_tag_linear_fwd_h2p,
+ *                          which moves it global -> LDS by LDS-DMA instead of re-splitting the weights in
+ *                          every row tile;
+ *   wt_image, wt_rowmax    (optional, together) the same for the transposed weights (row f, reduction
+ *                          k = s*Fo + o, wt_rowmax[f] = max_s,o |W_s[o,f]| [Fi]) for the forward-shaped
+ *                          backward block. */
 int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
-                       float *wcat, float *wtcat, float *wt_rowmax, dc_stream_t stream);
+                       void *w_image, void *wt_image, float *wt_rowmax, dc_stream_t stream);
+/* dc_tag_linear_fwd_h2 for ONE segment x [N, K] (ldx) with pre-split weights (w_image of
+ * dc_tag_weight_prep; K = nseg*Fi of that call): out = act(x . W^T + b). */
+int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_image, const float *bias, int relu,
+                          float *out, int64_t ldo, int64_t N, int64_t K, int64_t Fo,
+                          const float *x_rowmax, const float *w_rowmax, dc_stream_t stream);
 /* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
 int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                      dc_stream_t stream);

@@ -339,19 +339,35 @@ def test_dense_block_fp16x2_vs_float64(n, fi, fo, nseg, relu, regime):
     assert torch.equal(wmax, torch.stack([w.abs().amax(1) for w in ws]).amax(0))
     # the one-launch weight preparation: same row maxima + transposed blocks + their row maxima
     wm2, wtm = torch.empty(fo, device=DEV), torch.empty(fi, device=DEV)
-    wcat, wt = torch.empty(fo, nseg * fi, device=DEV), torch.empty(fi, nseg * fo, device=DEV)
-    _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), nseg, fo, fi, wm2.data_ptr(), wcat.data_ptr(),
-                                    wt.data_ptr(), wtm.data_ptr(), st), "weight_prep")
-    assert torch.equal(wm2, wmax) and torch.equal(wcat, torch.cat(ws, dim=1))
-    assert torch.equal(wt, torch.cat([w.t() for w in ws], dim=1))
+    wimg, wtimg = torch.empty(fo, nseg * fi, device=DEV), torch.empty(fi, nseg * fo, device=DEV)
+    _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), nseg, fo, fi, wm2.data_ptr(), wimg.data_ptr(),
+                                    wtimg.data_ptr(), wtm.data_ptr(), st), "weight_prep")
+    assert torch.equal(wm2, wmax)
     assert torch.equal(wtm, torch.stack([w.abs().amax(0) for w in ws]).amax(0))
-    # the same forward as ONE segment over the whole slab with the concatenated weights (the tuned
-    # single-segment kernel): identical products and order, so identical results
+
+    def unsplit(img, rows, rowmax):          # {h1[16], h2[16]} records -> (h1 + h2) / 2^e per row
+        rec = img.view(torch.float16).view(rows, -1, 2, 16).double()
+        e = torch.frexp(rowmax.double())[1].clamp(min=15 - 126)       # rowmax in [2^(e-1), 2^e)
+        return (rec[:, :, 0] + rec[:, :, 1]).reshape(rows, -1) / torch.pow(2.0, (15 - e).double()).unsqueeze(1)
+    wcat_ref = torch.cat(ws, dim=1).double()
+    wtcat_ref = torch.cat([w.t() for w in ws], dim=1).double()
+    assert float((unsplit(wimg, fo, wmax) - wcat_ref).abs().max()) <= 3e-7 * float(wcat_ref.abs().max())
+    assert float((unsplit(wtimg, fi, wtm) - wtcat_ref).abs().max()) <= 3e-7 * float(wtcat_ref.abs().max())
+    # the same forward as ONE segment over the whole slab with the pre-split weights (k_fwd_h2, weights
+    # by LDS-DMA) ...
     out1 = torch.empty(n, fo, device=DEV)
-    _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array([slab]), _i64_array([nseg * fi]), _ptr_array([wcat]), 1,
-                                      bias.data_ptr(), int(relu), out1.data_ptr(), fo, n, nseg * fi, fo,
-                                      rowmax.data_ptr(), wmax.data_ptr(), st), "fwd_h2 one segment")
+    _lib.check(L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), bias.data_ptr(), int(relu),
+                                       out1.data_ptr(), fo, n, nseg * fi, fo, rowmax.data_ptr(),
+                                       wmax.data_ptr(), st), "fwd_h2p")
     assert row_rel(_np(out1), ref.numpy()) < 2e-6
+    # ... and with the fp32 weights concatenated along K through the generic entry (same kernel,
+    # splitting the weights itself): the same planes, so bit-identical
+    wcat = torch.cat(ws, dim=1).contiguous()
+    out2 = torch.empty(n, fo, device=DEV)
+    _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array([slab]), _i64_array([nseg * fi]), _ptr_array([wcat]), 1,
+                                      bias.data_ptr(), int(relu), out2.data_ptr(), fo, n, nseg * fi, fo,
+                                      rowmax.data_ptr(), wmax.data_ptr(), st), "fwd_h2 one segment")
+    assert torch.equal(out1, out2)
     out = torch.empty(n, fo, device=DEV)
     _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array(xs), _i64_array(ld), _ptr_array(ws), nseg, bias.data_ptr(),
                                       int(relu), out.data_ptr(), fo, n, fi, fo, rowmax.data_ptr(),

@@ -90,12 +90,13 @@ def main():
         growmax = torch.empty(n, device=dev)
         wmax = ops.weight_rowmax(ws)
 
-        wcat = torch.cat(ws, dim=1).contiguous()
-        pa_s, pa_c, pa_l1 = _ptr_array([slab]), _ptr_array([wcat]), _i64_array([nseg * fi])
+        wimg = torch.empty(fo, nseg * fi, device=dev)
+        if (nseg * fi) % 16 == 0:
+            L.dc_tag_weight_prep(pa_w, nseg, fo, fi, wmax.data_ptr(), wimg.data_ptr(), None, None, st)
 
         def fwd_h():
-            L.dc_tag_linear_fwd_h2(pa_s, pa_l1, pa_c, 1, bias.data_ptr(), 1, out.data_ptr(), fo, n, nseg * fi, fo,
-                                   rowmax.data_ptr(), wmax.data_ptr(), st)
+            L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), bias.data_ptr(), 1, out.data_ptr(),
+                                    fo, n, nseg * fi, fo, rowmax.data_ptr(), wmax.data_ptr(), st)
 
         def dx_h():
             L.dc_tag_linear_bwd_dx_h2(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld,
