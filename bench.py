@@ -97,10 +97,11 @@ def cpu_baseline(batch: int, budget_s: float):
 
 
 def dense_roofline(dev, n_s: int, n_r: int, reps: int):
-    """Second roofline object: the dense block (66 % of the step), MFMA-bound.  The six layer-2
-    launches of a step (fwd, dX, dW for the soft and the rigid branch; F = 256, K = 4 x 256)
-    interleaved, HIP events.  `achieved` counts the bf16 MFMA FLOPs actually executed
-    (products x algorithmic); `fp32_equivalent` is algorithmic FLOPs / time."""
+    """Second roofline object: the wide dense blocks (about half of the step), MFMA-bound.  The six
+    layer-2 launches of a step (forward, dX - a second forward-shaped block -, dW for the soft and
+    the rigid branch; F = 256, K = 4 x 256) interleaved on cold buffers, HIP events.  `achieved`
+    counts the MFMA FLOPs actually executed (products x algorithmic); `fp32_equivalent` is
+    algorithmic FLOPs / time."""
     from deformcontact_amd import _lib, ops
     from deformcontact_amd.graph import current_stream_ptr
     from deformcontact_amd.ops import _i64_array, _ptr_array
