@@ -34,7 +34,8 @@ RIGID = dict(n=762, e=4560)
 
 def hop_bytes(n: int, e: int, f: int, addend: bool) -> int:
     """Algorithmic bytes of one hop launch (SURVEY.md 8(d) gather model):
-    E*(4 idx + 4 w + 4F gathered row) + N*(4F written row + 4 ptr) [+ N*4F addend read]."""
+    E*(4 idx + 4 w + 4F gathered row) + N*(4F written row + 4 ptr) [+ N*4F addend read].
+    (The row-maxima side output of the launches a step uses adds 8 bytes per node: not counted.)"""
     return e * (8 + 4 * f) + n * (4 * f + 4) + (n * 4 * f if addend else 0)
 
 
@@ -373,24 +374,25 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: the F=256 hop (k_spmm_wave<4,8>) ----
+        # ---- roofline of the dominant kernel: the F=256 hop as a step launches it
+        # (k_spmm_wave<4,8,true>: the hop + the row maxima the dense block scales by; forward over
+        # the sorted adjacency, backward - on the masked gradient - over the transposed one) ----
         gs, gr = graph_index(rest.edge_index, n_s), graph_index(rig.edge_index, n_r)
         f = 256
         cases = []
         for g, n, e in ((gs, n_s, e_s), (gr, n_r, e_r)):
-            slab = torch.randn(n, 3 * f, device=dev)
-            x = torch.randn(n, f, device=dev)
-            cases.append((g.fwd, x, slab[:, :f], None, hop_bytes(n, e, f, False)))       # fwd hop
-            cases.append((g.bwd, slab[:, f:2 * f], slab[:, 2 * f:], slab[:, 2 * f:],
-                          hop_bytes(n, e, f, True)))                                   # bwd hop
+            slab = torch.randn(n, 4 * f, device=dev)        # a hop slab: K+1 column blocks
+            rm = torch.zeros(n, device=dev)
+            cases.append((g.fwd, slab[:, :f], slab[:, f:2 * f], rm, hop_bytes(n, e, f, False)))      # fwd hop
+            cases.append((g.bwd, slab[:, 2 * f:3 * f], slab[:, 3 * f:], rm, hop_bytes(n, e, f, False)))  # bwd hop
         per_case = []
-        for adj, x, o, add, nbytes in cases:               # isolated, same launch back to back
+        for adj, x, o, rm, nbytes in cases:                # isolated, same launch back to back
             for _ in range(5):
-                ops.hop(adj, x, out=o, addend=add)
+                ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             for _ in range(args.kernel_reps):
-                ops.hop(adj, x, out=o, addend=add)
+                ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2)
             ev1.record()
             torch.cuda.synchronize()
             ms = ev0.elapsed_time(ev1) / args.kernel_reps
@@ -401,8 +403,8 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(args.kernel_reps):
-            for adj, x, o, add, nbytes in cases:
-                ops.hop(adj, x, out=o, addend=add)
+            for adj, x, o, rm, nbytes in cases:
+                ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2)
         ev1.record()
         torch.cuda.synchronize()
         tot_ms = ev0.elapsed_time(ev1) / args.kernel_reps
@@ -416,7 +418,7 @@ def main():
             except Exception:
                 traffic = None
         out["roofline"] = {
-            "bound": "hbm", "kernel": "dc::k_spmm_wave<4,8> (F=256 hop)",
+            "bound": "hbm", "kernel": "dc::k_spmm_wave<4,8,true> (F=256 hop + row maxima, as launched in a step)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(tot_bytes / len(cases)),
