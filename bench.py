@@ -168,11 +168,11 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
             def fwd(n=n, slab=slab, wimg=wimg, bias=bias, out=out, rowmax=rowmax, wmax=wmax):
                 L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), bias.data_ptr(), 1,
                                         out.data_ptr(), fo, n, nseg * fi, fo, rowmax.data_ptr(),
-                                        wmax.data_ptr(), st)
+                                        wmax.data_ptr(), None, 0, st)
 
             def dx(n=n, gslab=gslab, wtimg=wtimg, gx=gx, growmax=growmax, wtmax=wtmax):
                 L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), nseg * fo, wtimg.data_ptr(), None, 0, gx.data_ptr(),
-                                        fi, n, nseg * fo, fi, growmax.data_ptr(), wtmax.data_ptr(), st)
+                                        fi, n, nseg * fo, fi, growmax.data_ptr(), wtmax.data_ptr(), None, 0, st)
 
             def dw(n=n, g=g, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb,
                    g0max=g0max, rowmax=rowmax):

@@ -61,8 +61,9 @@ _SIGNATURES = {
                                         _vp, _vp, _vp]),
     "dc_tag_mask_grad": (c_int, [_vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64, c_int64, _vp, _vp, _vp]),
     "dc_tag_transpose_weights": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp]),
+    "dc_tag_linear_fwd_h2p_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "dc_tag_linear_fwd_h2p": (c_int, [_vp, c_int64, _vp, _vp, c_int, _vp, c_int64, c_int64, c_int64, c_int64,
-                                      _vp, _vp, _vp]),
+                                      _vp, _vp, _vp, c_int64, _vp]),
     "dc_tag_weight_prep": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp, _vp, _vp, _vp]),
     "dc_rowabsmax_f32": (c_int, [_vp, c_int64, c_int64, c_int64, _vp, _vp]),
     "dc_tag_weight_rowmax": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp]),
@@ -70,6 +71,9 @@ _SIGNATURES = {
                                    c_int64, _vp, c_int, _vp]),
     "dc_tag_pack_input": (c_int, [_vp, c_int64, _vp, c_int64, c_int64, c_int64, c_int64, c_int64, _vp]),
     "dc_tag_pack_weights": (c_int, [POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp]),
+    "dc_attn_softmax_rows": (c_int, [_vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp]),
+    "dc_attn_exp_rows": (c_int, [_vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp]),
+    "dc_attn_ds_rows": (c_int, [_vp, _vp, c_int64, c_int64, c_int64, _vp, _vp, _vp]),
     "dc_adam_flat": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_float, c_float, c_float, c_float,
                              c_int, _vp]),
     "dc_compose_perm": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp]),

@@ -1,0 +1,168 @@
+"""Blocked cross-attention on the fp16x2 dense kernels.
+
+The reference's ``MultiHeadAttention`` (``/root/reference/models/model.py:7-21``) computes, per
+head, ``softmax(head(x_soft) @ head(x_rigid).T, dim=-1) @ x_rigid`` - unmasked over the whole
+batch, no ``1/sqrt(d)`` - by materialising the ``[N_s, N_r]`` score matrix and keeping the softmax
+weights for autograd: 2 x 3.2 GB per head at batch 32.  ``attention_core`` computes the same
+function with the score matrix alive only for a block of ``block_rows`` soft rows:
+
+  forward   per block:  S = Q_b K^T  ->  P = softmax(S) (row log-sum-exp kept)  ->  O_b = P V
+  backward  per block:  S, P recomputed;  dP = dO_b V^T;  dS = P * (dP - rowsum(dO_b * O_b));
+                        dQ_b = dS K;  dK += dS^T Q_b;  dV += P^T dO_b
+
+Every GEMM runs on the library's fp16x2 kernels (``dc_tag_linear_fwd_h2p`` with the right-hand
+operand pre-split by ``dc_tag_weight_prep``; ``dc_tag_linear_bwd_dw_h2`` for the two products that
+contract over the soft rows), the row-wise parts on ``dc_attn_*``; fp32 storage throughout, error
+at the level of fp32 accumulation.  Activation memory is ``block_rows x N_r`` floats (x2 in the
+backward) instead of ``N_s x N_r`` per head.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .graph import _require_cuda, current_stream_ptr
+from .ops import _i64_array, _ptr_array
+
+BLOCK_ROWS = 2048
+
+
+def _ceil16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    if t.size(0) == rows and t.is_contiguous():
+        return t
+    out = torch.zeros((rows, t.size(1)), dtype=t.dtype, device=t.device)
+    out[:t.size(0)].copy_(t)
+    return out
+
+
+def _prep(L, mat: torch.Tensor, want_t: bool, st):
+    """``dc_tag_weight_prep`` over one matrix [R, C]: (rowmax [R], image [R, C], timage [C, R] | None,
+    trowmax [C] | None) - the scaled fp16x2 images of its rows and of its columns."""
+    r, c = mat.shape
+    dev = mat.device
+    rowmax = torch.empty(r, dtype=torch.float32, device=dev)
+    img = torch.empty((r, c), dtype=torch.float32, device=dev)
+    timg = torch.empty((c, r), dtype=torch.float32, device=dev) if want_t else None
+    tmax = torch.empty(c, dtype=torch.float32, device=dev) if want_t else None
+    _lib.check(L.dc_tag_weight_prep(_ptr_array([mat]), 1, r, c, rowmax.data_ptr(), img.data_ptr(),
+                                    timg.data_ptr() if want_t else None,
+                                    tmax.data_ptr() if want_t else None, st), "dc_tag_weight_prep")
+    return rowmax, img, timg, tmax
+
+
+def _rowabsmax(L, t: torch.Tensor, st) -> torch.Tensor:
+    out = torch.empty(t.size(0), dtype=torch.float32, device=t.device)
+    _lib.check(L.dc_rowabsmax_f32(t.data_ptr(), t.stride(0), t.size(0), t.size(1), out.data_ptr(), st),
+               "dc_rowabsmax_f32")
+    return out
+
+
+def _gemm(L, x, ldx, rows, k, img, fo, out, ldo, xmax, wmax, st, ws=None):
+    """out[rows, fo] = x[rows, k] . W^T with W given as its pre-split image (fp16x2, LDS-DMA);
+    ``ws``: workspace that lets a long reduction with a small output be cut into ranges."""
+    _lib.check(L.dc_tag_linear_fwd_h2p(x, ldx, img.data_ptr(), None, 0, out, ldo, rows, k, fo, xmax,
+                                       wmax.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                       ws.numel() if ws is not None else 0, st), "dc_tag_linear_fwd_h2p")
+
+
+def _splitk_ws(L, rows, k, fo, dev):
+    nb = L.dc_tag_linear_fwd_h2p_workspace_bytes(rows, k, fo)
+    return torch.empty(nb, dtype=torch.uint8, device=dev) if nb > 0 else None
+
+
+class _AttnCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_rows: int):
+        for name, t in (("q", q), ("k", k), ("v", v)):
+            _require_cuda(t, name)
+            if t.dim() != 2 or t.dtype != torch.float32:
+                raise ValueError(f"attention_core: {name} must be a 2-D float32 tensor")
+        ns, d = q.shape
+        nr = k.size(0)
+        if k.size(1) != d or v.size(0) != nr or d % 16 != 0:
+            raise ValueError("attention_core: q [Ns, d], k [Nr, d], v [Nr, dv] with d % 16 == 0 expected")
+        if nr == 0:
+            raise ValueError("attention_core: softmax over zero keys")
+        dv = v.size(1)
+        dev = q.device
+        L = _lib.lib()
+        st = current_stream_ptr(dev)
+        nsp, nrp = _ceil16(ns), _ceil16(nr)
+        bq = max(16, min(_ceil16(block_rows), nsp))
+        qp, kp, vp = _pad_rows(q, nsp), _pad_rows(k, nrp), _pad_rows(v, nrp)
+        kmax, kimg, _, _ = _prep(L, kp, False, st)                 # rows of K over d
+        _, _, vtimg, vtmax = _prep(L, vp, True, st)                # rows of V^T over the keys
+        qmax = _rowabsmax(L, qp, st)
+        ones = torch.ones(bq, dtype=torch.float32, device=dev)     # softmax weights are <= 1
+        o = torch.empty((nsp, dv), dtype=torch.float32, device=dev)
+        lse = torch.empty(nsp, dtype=torch.float32, device=dev)
+        s = torch.empty((bq, nrp), dtype=torch.float32, device=dev)
+        ws_o = _splitk_ws(L, bq, nrp, dv, dev)
+        for r0 in range(0, nsp, bq):
+            rows = min(bq, nsp - r0)
+            _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, s.data_ptr(), nrp, qmax[r0:].data_ptr(), kmax, st)
+            _lib.check(L.dc_attn_softmax_rows(s.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
+                       "dc_attn_softmax_rows")
+            _gemm(L, s.data_ptr(), nrp, rows, nrp, vtimg, dv, o[r0:].data_ptr(), dv, ones.data_ptr(), vtmax, st,
+                  ws_o)
+        ctx.save_for_backward(qp, kp, vp, o, lse, kimg, kmax, qmax)
+        ctx.dims = (ns, nr, d, dv, bq)
+        return o[:ns]
+
+    @staticmethod
+    def backward(ctx, go: torch.Tensor):
+        qp, kp, vp, o, lse, kimg, kmax, qmax = ctx.saved_tensors
+        ns, nr, d, dv, bq = ctx.dims
+        dev = qp.device
+        L = _lib.lib()
+        st = current_stream_ptr(dev)
+        nsp, nrp = qp.size(0), kp.size(0)
+        gop = _pad_rows(go.contiguous(), nsp)
+        delta = (gop * o).sum(dim=1)
+        gomax = _rowabsmax(L, gop, st)
+        vmax, vimg, _, _ = _prep(L, vp, False, st)                 # rows of V over dv   (dP = dO V^T)
+        _, _, ktimg, ktmax = _prep(L, kp, True, st)                # rows of K^T over keys (dQ = dS K)
+        ones = torch.ones(bq, dtype=torch.float32, device=dev)
+        gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
+        gk = torch.empty((nrp, d), dtype=torch.float32, device=dev)
+        gv = torch.empty((nrp, dv), dtype=torch.float32, device=dev)
+        p = torch.empty((bq, nrp), dtype=torch.float32, device=dev)
+        ds = torch.empty((bq, nrp), dtype=torch.float32, device=dev)
+        dsmax = torch.empty(bq, dtype=torch.float32, device=dev)
+        nb_k = L.dc_tag_linear_bwd_dw_workspace_bytes(bq, d, nrp, 1)
+        nb_v = L.dc_tag_linear_bwd_dw_workspace_bytes(bq, dv, nrp, 1)
+        scratch = torch.empty(max(nb_k, nb_v), dtype=torch.uint8, device=dev)
+        ws_q = _splitk_ws(L, bq, nrp, d, dev)
+        for r0 in range(0, nsp, bq):
+            rows = min(bq, nsp - r0)
+            acc = int(r0 > 0)
+            # recompute the block's weights
+            _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, p.data_ptr(), nrp, qmax[r0:].data_ptr(), kmax, st)
+            _lib.check(L.dc_attn_exp_rows(p.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
+                       "dc_attn_exp_rows")
+            # dP = dO V^T, then dS = P * (dP - delta) in place
+            _gemm(L, gop[r0:].data_ptr(), dv, rows, dv, vimg, nrp, ds.data_ptr(), nrp, gomax[r0:].data_ptr(), vmax, st)
+            _lib.check(L.dc_attn_ds_rows(p.data_ptr(), ds.data_ptr(), nrp, rows, nrp, delta[r0:].data_ptr(),
+                                         dsmax.data_ptr(), st), "dc_attn_ds_rows")
+            # dQ_b = dS K
+            _gemm(L, ds.data_ptr(), nrp, rows, nrp, ktimg, d, gq[r0:].data_ptr(), d, dsmax.data_ptr(), ktmax, st,
+                  ws_q)
+            # dK += dS^T Q_b ; dV += P^T dO_b   (contraction over the block's rows: dW-shaped)
+            for g_t, g_max, x_t, x_ld, x_max, out_t, fi, nb in (
+                    (ds, dsmax, qp[r0:], d, qmax[r0:], gk, d, nb_k),
+                    (p, ones, gop[r0:], dv, gomax[r0:], gv, dv, nb_v)):
+                _lib.check(L.dc_tag_linear_bwd_dw_h2(
+                    g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1,
+                    _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp,
+                    g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
+        return gq[:ns], gk[:nr], gv[:nr], None
+
+
+def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                   block_rows: int = BLOCK_ROWS) -> torch.Tensor:
+    """``softmax(q @ k.T, dim=-1) @ v`` without the ``[Ns, Nr]`` matrix (differentiable)."""
+    return _AttnCoreFn.apply(q.contiguous(), k.contiguous(), v.contiguous(), int(block_rows))

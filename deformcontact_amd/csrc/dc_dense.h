@@ -136,6 +136,8 @@ struct FwdParams {
     int64_t ldo, N, Fi, Fo;
     int nseg, relu;
     H2Scales h2;
+    int ksplit;              // k_fwd_h2: > 1 = the reduction is cut into ksplit ranges, each block
+    float *kpartial;         //   writes its [N, Fo] partial to kpartial[z] (no bias / relu), summed later
 };
 
 struct DxParams {

@@ -468,7 +468,8 @@ using namespace dc;
 
 static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *const *ws, int nseg,
                     const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t Fi,
-                    int64_t Fo, dc_stream_t stream, int products, H2Scales h2 = H2Scales{}) {
+                    int64_t Fo, dc_stream_t stream, int products, H2Scales h2 = H2Scales{},
+                    float *ksplit_ws = nullptr, int64_t ksplit_ws_bytes = 0) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_fwd: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_fwd: bad sizes");
     if (N == 0) return DC_OK;
@@ -490,8 +491,33 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
     static const int h2_tuned = env_int("DC_H2_TUNED", 1);
-    if (products == 2 && vec && h2_tuned && fwd_h2_launch(p, split_mb(N, ntn), hs))
-        return check_launch("dc_tag_linear_fwd_h2");
+    if (products == 2 && vec && h2_tuned) {
+        int smb = split_mb(N, ntn);
+        // a long reduction with a small output (e.g. attention weights x values: [2048, 24384] x
+        // [24384, 256]) has too few tiles for 256 CUs: cut the reduction, sum the partials
+        const int64_t nst = Fi / BK;
+        if (ksplit_ws && !bias && !relu && ldo == Fo && nseg == 1) {
+            smb = 2;
+            int64_t tiles = ((N + 127) / 128) * ntn;
+            if (tiles < 128) smb = 1, tiles = ((N + 63) / 64) * ntn;
+            int64_t ks = tiles < 256 ? (512 + tiles - 1) / tiles : 1;
+            if (ks > nst / 8) ks = nst / 8;
+            if (ks > 32) ks = 32;
+            while (ks > 1 && ks * N * Fo * (int64_t)sizeof(float) > ksplit_ws_bytes) --ks;
+            if (ks > 1) p.ksplit = (int)ks, p.kpartial = ksplit_ws;
+        }
+        if (fwd_h2_launch(p, smb, hs)) {
+            if (p.ksplit > 1) {
+                ReduceParams r{};
+                r.partial = p.kpartial, r.gw[0] = out, r.Fi = Fo, r.Fo = N, r.cols = Fo;
+                r.nseg = 1, r.nchunks = p.ksplit, r.ngw = 1, r.bps = 1, r.accumulate = 0;
+                const int64_t total = N * Fo;
+                hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, r);
+            }
+            return check_launch("dc_tag_linear_fwd_h2");
+        }
+        p.ksplit = 0, p.kpartial = nullptr;
+    }
     DC_REQUIRE(!h2.b_presplit, "dc_tag_linear_fwd_h2p: shape not eligible for the pre-split kernel");
     if (products && vec && fwd_split_launch(p, split_mb(N, ntn), products, hs))
         return check_launch("dc_tag_linear_fwd_split");
@@ -728,10 +754,18 @@ extern "C" int dc_tag_linear_fwd_h2(const float *const *xs, const int64_t *ldxs,
     return fwd_impl(xs, ldxs, ws, nseg, bias, relu, out, ldo, N, Fi, Fo, stream, 2, h);
 }
 
+extern "C" int64_t dc_tag_linear_fwd_h2p_workspace_bytes(int64_t N, int64_t K, int64_t Fo) {
+    if (N < 0 || K < 1 || Fo < 1) return DC_EINVAL;
+    const int64_t tiles = ((N + 63) / 64) * ((Fo + BN - 1) / BN);
+    if (tiles >= 256 || K / BK < 16) return 0;                 // enough tiles / too short to cut
+    return 32 * N * Fo * (int64_t)sizeof(float);
+}
+
 extern "C" int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_image,
                                      const float *bias, int relu, float *out, int64_t ldo, int64_t N,
                                      int64_t K, int64_t Fo, const float *x_rowmax,
-                                     const float *w_rowmax, dc_stream_t stream) {
+                                     const float *w_rowmax, void *workspace,
+                                     int64_t workspace_bytes, dc_stream_t stream) {
     DC_REQUIRE(x && w_image && x_rowmax && w_rowmax, "dc_tag_linear_fwd_h2p: null pointer");
     DC_REQUIRE(K >= 16 && K % 16 == 0 && ldx >= K && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
                    (((uintptr_t)w_image) & 15) == 0,
@@ -742,7 +776,9 @@ extern "C" int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_
     const float *xs[1] = {x};
     const float *ws[1] = {(const float *)w_image};   // 4 bytes per element, fp32 addressing
     const int64_t ld[1] = {ldx};
-    return fwd_impl(xs, ld, ws, 1, bias, relu, out, ldo, N, K, Fo, stream, 2, h);
+    DC_REQUIRE(!workspace || (((uintptr_t)workspace) & 15) == 0, "dc_tag_linear_fwd_h2p: workspace misaligned");
+    return fwd_impl(xs, ld, ws, 1, bias, relu, out, ldo, N, K, Fo, stream, 2, h, (float *)workspace,
+                    workspace ? workspace_bytes : 0);
 }
 
 extern "C" int dc_tag_linear_bwd_dx_h2(const float *g, int64_t ldg, const float *out_for_mask,

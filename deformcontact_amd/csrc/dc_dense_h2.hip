@@ -54,7 +54,9 @@ k_fwd_h2(FwdParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
     __shared__ float s_inv[BM];
     const unsigned ntn = (unsigned)((p.Fo + BN - 1) / BN);
-    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned ks = p.ksplit > 1 ? (unsigned)p.ksplit : 1u, ntiles = gridDim.x / ks;
+    const unsigned lbb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned lb = lbb % ntiles, kz = lbb / ntiles;           // tile, reduction range
     const int64_t row0 = (int64_t)(lb / ntn) * BM, col0 = (int64_t)(lb % ntn) * BN;
     const int wid = threadIdx.x >> 6, wm = wid >> 1, wn = wid & 1;
     const int lane = threadIdx.x & 63;
@@ -95,10 +97,13 @@ k_fwd_h2(FwdParams p) {
 
     f32x16 acc[MB][2];
     zero_acc<MB>(acc);
-    const int nst = (int)(p.Fi / BK);                 // ONE segment (launcher): plain K loop
+    // ONE segment (launcher): plain K loop over this block's range of 16-wide stages
+    const int nst_all = (int)(p.Fi / BK), per = (nst_all + (int)ks - 1) / (int)ks;
+    const int st_beg = (int)kz * per;
+    const int nst = st_beg >= nst_all ? 0 : (nst_all - st_beg < per ? nst_all - st_beg : per);
     // wave-uniform running bases (scalar registers)
-    const float *baseA = p.x[0].p + row0 * lda;
-    const float *baseB = p.w[0].p + col0 * p.Fi;
+    const float *baseA = p.x[0].p + row0 * lda + (int64_t)st_beg * BK;
+    const float *baseB = p.w[0].p + col0 * p.Fi + (int64_t)st_beg * BK;
     float4 va[NVA], vb[NVB];
 
     auto load = [&]() {
@@ -208,6 +213,14 @@ k_fwd_h2(FwdParams p) {
         icol[nb] = h2_unscale(p.h2.b_rowmax[col < p.Fo ? col : p.Fo - 1]);
     }
     const bool relu = p.relu != 0;
+    if (ks > 1) {                                     // split reduction: plain partial, summed later
+        float *part = p.kpartial + (int64_t)kz * p.N * p.Fo;
+        for_each_acc<MB>(acc, wm, wn, [&](int rr, int c, float v) {
+            const int64_t row = row0 + rr, col = col0 + c;
+            if (row < p.N && col < p.Fo) part[row * p.Fo + col] = (v * s_inv[rr]) * icol[(c >> 5) & 1];
+        });
+        return;
+    }
     for_each_acc<MB>(acc, wm, wn, [&](int rr, int c, float v) {
         const int64_t row = row0 + rr, col = col0 + c;
         if (row < p.N && col < p.Fo) {
@@ -231,7 +244,8 @@ bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs) {
     for (int s = 0; s < p.nseg; ++s)
         if (!h2_al16(p.x[s].p) || !h2_al16(p.w[s].p) || p.x[s].ld % 4 != 0 || p.x[s].ld != p.x[0].ld)
             return false;
-    const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
+    const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN) *
+                         (p.ksplit > 1 ? p.ksplit : 1);
     const dim3 gd((unsigned)grid), bd(256);
     if (p.h2.b_presplit) {
         if (mb == 2) hipLaunchKernelGGL((k_fwd_h2<2, true>), gd, bd, 0, hs, p);

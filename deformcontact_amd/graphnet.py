@@ -15,6 +15,8 @@ bench / tests / training on the GPU box need no file from ``/root/reference``.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -105,11 +107,22 @@ class CrossAttention(nn.Module):
         self.attention_heads = nn.ModuleList(
             nn.Linear(feature_dim, feature_dim) for _ in range(num_heads))
 
+    #: blocked attention on the library's dense kernels (``attention.attention_core``): the
+    #: ``[N_s, N_r]`` score / weight matrices of the reference exist only per block of soft rows
+    #: (``DC_FUSED_ATTN=0``: the reference's materialising formula on stock PyTorch)
+    fused = os.environ.get("DC_FUSED_ATTN", "1") != "0"
+
     def forward(self, x_resting, x_rigid):
         pooled = []
+        use_fused = (self.fused and x_resting.is_cuda and x_resting.dtype == torch.float32
+                     and x_resting.size(1) % 16 == 0 and x_rigid.size(0) > 0)
         for head in self.attention_heads:
-            scores = head(x_resting) @ head(x_rigid).t()
-            pooled.append(torch.softmax(scores, dim=-1) @ x_rigid)
+            if use_fused:
+                from .attention import attention_core
+                pooled.append(attention_core(head(x_resting), head(x_rigid), x_rigid))
+            else:
+                scores = head(x_resting) @ head(x_rigid).t()
+                pooled.append(torch.softmax(scores, dim=-1) @ x_rigid)
         return torch.cat(pooled, dim=-1)
 
 

@@ -327,7 +327,7 @@ class _TagConvFn(torch.autograd.Function):
             rc = L.dc_tag_linear_fwd_h2p(slab.data_ptr(), wpad, wimg.data_ptr(),
                                          b.data_ptr() if b is not None else None, int(relu),
                                          out.data_ptr(), ldo, n, width, fo,
-                                         rowmax.data_ptr(), wmax.data_ptr(), st)
+                                         rowmax.data_ptr(), wmax.data_ptr(), None, 0, st)
         elif DENSE_SPLIT_BF16:
             rc = L.dc_tag_linear_fwd_split(*args, DENSE_PRODUCTS, st)
         else:
@@ -394,7 +394,7 @@ class _TagConvFn(torch.autograd.Function):
                 gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
                 rc = L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gwid, wt.data_ptr(), None, 0, gx.data_ptr(),
                                              fi, n, gwid, fi, hop_rowmax.data_ptr(), wt_rowmax.data_ptr(),
-                                             st)
+                                             None, 0, st)
                 _lib.check(rc, "dc_tag_linear_fwd_h2 (dX)")
                 need_x = False                               # done
 

@@ -250,10 +250,15 @@ int dc_tag_transpose_weights(const float *const *ws, int nseg, int64_t Fo, int64
 int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
                        void *w_image, void *wt_image, float *wt_rowmax, dc_stream_t stream);
 /* dc_tag_linear_fwd_h2 for ONE segment x [N, K] (ldx) with pre-split weights (w_image of
- * dc_tag_weight_prep; K = nseg*Fi of that call): out = act(x . W^T + b). */
+ * dc_tag_weight_prep; K = nseg*Fi of that call): out = act(x . W^T + b).  With a workspace of
+ * dc_tag_linear_fwd_h2p_workspace_bytes (may be NULL / 0) a long reduction with too few output
+ * tiles for the chip (no bias, no relu, ldo == Fo) is cut into ranges whose partials are summed in
+ * range order by a second launch (deterministic). */
+int64_t dc_tag_linear_fwd_h2p_workspace_bytes(int64_t N, int64_t K, int64_t Fo);
 int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_image, const float *bias, int relu,
                           float *out, int64_t ldo, int64_t N, int64_t K, int64_t Fo,
-                          const float *x_rowmax, const float *w_rowmax, dc_stream_t stream);
+                          const float *x_rowmax, const float *w_rowmax, void *workspace,
+                          int64_t workspace_bytes, dc_stream_t stream);
 /* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
 int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                      dc_stream_t stream);
@@ -306,6 +311,20 @@ int dc_tag_pack_input(const float *x, int64_t ldx, float *slab, int64_t ld_slab,
                       int64_t F, int64_t width, int64_t wpad, dc_stream_t stream);
 int dc_tag_pack_weights(const float *const *ws, int nw, float *wcat, int64_t Fo, int64_t fi,
                         int64_t wpad, dc_stream_t stream);
+
+/* ---- row kernels of the blocked cross-attention -------------------
+ * models/model.py:7-21: per head  softmax(head(x_soft) . head(x_rigid)^T, dim=-1) . x_rigid, unmasked,
+ * no 1/sqrt(d).  The score matrix exists only for a block of soft rows s [rows, ld]; its three
+ * GEMMs run on the h2 dense entries above and these kernels do the row-wise parts in place:
+ *   softmax_rows: s[i,0:n] <- softmax(s[i,0:n]), s[i,n:npad] <- 0, lse[i] = log sum_j exp(s[i,j])
+ *   exp_rows    : s[i,0:n] <- exp(s[i,0:n] - lse[i]), s[i,n:npad] <- 0   (backward recompute)
+ *   ds_rows     : dp[i,j] <- p[i,j] * (dp[i,j] - delta[i]) for j < npad; rowmax[i] = max_j |.| */
+int dc_attn_softmax_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, float *lse,
+                         dc_stream_t stream);
+int dc_attn_exp_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, const float *lse,
+                     dc_stream_t stream);
+int dc_attn_ds_rows(const float *p, float *dp, int64_t ld, int64_t rows, int64_t npad,
+                    const float *delta, float *rowmax, dc_stream_t stream);
 
 /* ---- optimizer step of the path's training loop -----------------------------
  * torch.optim.Adam(lr) at its defaults (train.py:20: no weight decay, no amsgrad) over ONE

@@ -358,7 +358,17 @@ def test_dense_block_fp16x2_vs_float64(n, fi, fo, nseg, relu, regime):
     out1 = torch.empty(n, fo, device=DEV)
     _lib.check(L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), bias.data_ptr(), int(relu),
                                        out1.data_ptr(), fo, n, nseg * fi, fo, rowmax.data_ptr(),
-                                       wmax.data_ptr(), st), "fwd_h2p")
+                                       wmax.data_ptr(), None, 0, st), "fwd_h2p")
+    # cut reduction (forced by a workspace; no bias / relu): sum of range partials, same 2e-6 bound
+    wsb = L.dc_tag_linear_fwd_h2p_workspace_bytes(n, nseg * fi, fo)
+    if wsb > 0:
+        wsk = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        out3 = torch.empty(n, fo, device=DEV)
+        _lib.check(L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), None, 0,
+                                           out3.data_ptr(), fo, n, nseg * fi, fo, rowmax.data_ptr(),
+                                           wmax.data_ptr(), wsk.data_ptr(), wsb, st), "fwd_h2p split-K")
+        ref3 = sum(xs[s].double().cpu() @ ws[s].double().cpu().t() for s in range(nseg))
+        assert row_rel(_np(out3), ref3.numpy()) < 2e-6
     assert row_rel(_np(out1), ref.numpy()) < 2e-6
     # ... and with the fp32 weights concatenated along K through the generic entry (same kernel,
     # splitting the weights itself): the same planes, so bit-identical
@@ -746,3 +756,25 @@ def test_multihop_falls_back_on_large_components():
     conv = dc.nn.TAGConv(16, 16).to(DEV)
     x = torch.randn(3000, 16, device=DEV)
     assert torch.isfinite(conv(x, torch.from_numpy(ei).to(DEV))).all()
+
+
+# --------------------------------------------------------------------------- #
+# blocked cross-attention vs the reference's formula in float64
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("ns,nr,d,dv,block", [(300, 130, 256, 256, 128), (64, 48, 32, 64, 2048),
+                                              (1000, 777, 256, 256, 512), (17, 5, 16, 16, 16)])
+def test_blocked_attention_core_vs_float64(ns, nr, d, dv, block):
+    from deformcontact_amd.attention import attention_core
+    torch.manual_seed(ns + nr)
+    q = (torch.randn(ns, d, device=DEV) * 0.5).requires_grad_()
+    k = (torch.randn(nr, d, device=DEV) * 0.5).requires_grad_()
+    v = torch.randn(nr, dv, device=DEV).requires_grad_()
+    go = torch.randn(ns, dv, device=DEV)
+    out = attention_core(q, k, v, block_rows=block)
+    out.backward(go)
+    qd, kd, vd = (t.detach().double().cpu().requires_grad_() for t in (q, k, v))
+    ref = torch.softmax(qd @ kd.t(), dim=-1) @ vd            # models/model.py:16-18
+    ref.backward(go.double().cpu())
+    assert rel_err(_np(out), ref.detach().numpy()) < 5e-6
+    for name, got, want in (("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
+        assert rel_err(_np(got), want.numpy()) < 1e-5, name

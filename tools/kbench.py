@@ -96,7 +96,7 @@ def main():
 
         def fwd_h():
             L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), bias.data_ptr(), 1, out.data_ptr(),
-                                    fo, n, nseg * fi, fo, rowmax.data_ptr(), wmax.data_ptr(), st)
+                                    fo, n, nseg * fi, fo, rowmax.data_ptr(), wmax.data_ptr(), None, 0, st)
 
         def dx_h():
             L.dc_tag_linear_bwd_dx_h2(g.data_ptr(), fo, out.data_ptr(), fo, pa_w, nseg, pa_gx, pa_ld,
