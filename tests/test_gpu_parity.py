@@ -464,13 +464,15 @@ def test_conv_forward_backward_vs_oracle(kind, n, e, fi, fo):
 @pytest.mark.parametrize("backbone,fname", [("TAGConv", "graphnet_tag_h32.npz"),
                                              ("GCNConv", "graphnet_gcn_h32.npz"),
                                              ("GATConv", "graphnet_gat_h32.npz")])
-def test_full_model_golden(backbone, fname):
+@pytest.mark.parametrize("fused_attn", [False, True])
+def test_full_model_golden(backbone, fname, fused_attn):
     """Fixtures produced by the reference's GraphNet + losses (oracle/make_golden.py)."""
     from deformcontact_amd.graphnet import EVERYDAY_NETWORK, gradient_consistency_loss, load_model
     z = load_golden(fname)
     m = load_model(dict(EVERYDAY_NETWORK, hidden_dim=int(z["hidden"]), backbone=backbone))
     fill_state_dict_(m)
     m = m.to(DEV).train()
+    m.multihead_attention.fused = "1" if fused_attn else "0"
     rest, rig = golden_graphs(z, DEV)
     acts = {}
     for br in ("resting", "rigid"):
@@ -500,7 +502,11 @@ def test_full_model_golden(backbone, fname):
             scale = np.abs(z["grad." + name.replace("att_dst", "att_src")]).max()
             assert np.abs(_np(p.grad) - ref).max() < 3 * TOL * scale, name
             continue
-        assert rel_err(_np(p.grad), ref) < 3 * TOL, name
+        # blocked attention: the softmax backward dS = P * (dP - delta) cancels the common part of
+        # dP in fp32 in BOTH computations (fixture: the reference's own formula on CPU), so two
+        # correct fp32 evaluations of the attention-weight gradients differ by a few 1e-5
+        tol = 1e-4 if (fused_attn and "multihead_attention" in name) else 3 * TOL
+        assert rel_err(_np(p.grad), ref) < tol, name
 
 
 def test_encoder_golden_hidden256():
