@@ -24,7 +24,11 @@ from . import _lib
 from .graph import _require_cuda, current_stream_ptr
 from .ops import _i64_array, _ptr_array
 
-BLOCK_ROWS = 2048
+import os
+
+#: soft rows per block: the block's score matrix (x2 in the backward) should stay in the 256 MiB
+#: Infinity Cache between the GEMM that writes it and the row kernel / GEMM that reads it
+BLOCK_ROWS = int(os.environ.get("DC_ATTN_BLOCK", "2048"))
 
 
 def _ceil16(n: int) -> int:
