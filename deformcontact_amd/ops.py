@@ -274,6 +274,8 @@ class _TagConvFn(torch.autograd.Function):
         # narrow layers: one K segment over the whole slab, zero-padded to a multiple of 16 so
         # the lean MFMA path (aligned float4 loads, no K tail) applies (84 -> 96, 100 -> 112)
         slab = _as_slab_block0(x, n, fi, wpad)
+        if (slab is None and k == 0 and wpad == fi and x.is_contiguous() and x.data_ptr() % 16 == 0):
+            slab = x                                 # no hops: the input itself is the (1-block) slab
         L = _lib.lib()
         st = current_stream_ptr(dev)
         if slab is None:
@@ -442,6 +444,13 @@ class _TagConvFn(torch.autograd.Function):
             chained_hops(g, gslab, fi, k, backward=True)  # g_{j-1} = G_{j-1} + A^T g_j
             gx = gblocks[0]
         return (None, gx, gb, None, None, *gws)
+
+
+def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 relu: bool = False) -> torch.Tensor:
+    """``act(x @ weight.T + bias)`` on the library's dense block (a TAGConv layer with K = 0: no hops):
+    the ``lin`` of ``GCNConv`` / ``GATConv`` (PyG ``nn/dense/linear.py``), forward and backward."""
+    return _TagConvFn.apply(None, x, bias, bool(relu), None, weight)
 
 
 def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
