@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import nn as dc_nn
+from . import ops
 
 
 def _conv_class(backbone: str, conv_module):
@@ -124,13 +125,22 @@ class CrossAttention(nn.Module):
         use_fused = eligible and (mode in ("1", "true", "on") or (
             mode == "auto" and x_resting.size(0) * x_rigid.size(0) >= self.fused_min_scores))
         for head in self.attention_heads:
+            q, k = _linear(head, x_resting), _linear(head, x_rigid)
             if use_fused:
                 from .attention import attention_core
-                pooled.append(attention_core(head(x_resting), head(x_rigid), x_rigid))
+                pooled.append(attention_core(q, k, x_rigid))
             else:
-                scores = head(x_resting) @ head(x_rigid).t()
-                pooled.append(torch.softmax(scores, dim=-1) @ x_rigid)
+                pooled.append(torch.softmax(q @ k.t(), dim=-1) @ x_rigid)
         return torch.cat(pooled, dim=-1)
+
+
+def _linear(lin: nn.Linear, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """``act(lin(x))`` on the library's dense block (bias + ReLU in the MFMA epilogue, dX / dW on the
+    same kernels) for float32 CUDA inputs; the parameters stay those of the ``nn.Linear``."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+        return ops.dense_linear(x, lin.weight, lin.bias, relu=relu)
+    y = lin(x)
+    return F.relu(y) if relu else y
 
 
 class GraphNet(ContactEncoder):
@@ -151,13 +161,33 @@ class GraphNet(ContactEncoder):
     def forward(self, graph_resting, graph_rigid):
         x_rest, x_rig = self.encode(graph_resting, graph_rigid)
         pooled = self.multihead_attention(x_rest, x_rig)     # always applied (reference quirk)
-        delta = self.decoder(torch.cat([x_rest, pooled], dim=-1))
+        delta = self._decode(torch.cat([x_rest, pooled], dim=-1))
         out = graph_resting.clone()
         if self.mode == "res":
             out.pos = out.pos + delta
         elif self.mode == "rec":
             out.pos = delta
         return out
+
+
+def _decode_impl(decoder: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """``self.decoder(x)`` (``models/model.py:52-64``: Linear -> ReLU -> Dropout blocks + Linear) with
+    every Linear (+ its ReLU) as one launch of the library's dense block."""
+    mods = list(decoder)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = _linear(m, x, relu=fuse)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+GraphNet._decode = lambda self, x: _decode_impl(self.decoder, x)
 
 
 def gradient_consistency_loss(pred, target) -> torch.Tensor:
