@@ -18,20 +18,54 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture losses + backward + FlatAdam in one hipGraph (flat-bucket Adam kernel)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rest, deff, rig = (b.to(dev) for b in synth.make_batch(a.batch))
     torch.manual_seed(0)
     model = load_model(EVERYDAY_NETWORK).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=4e-4)
+    if a.graph:
+        from deformcontact_amd import dp
+        from deformcontact_amd.train import losses
+        bucket = dp.GradBucket(model.parameters())
+        opt = dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=True)
+        bucket.zero()
+        out = {}
+
+        def one():
+            o = losses(model, rest, deff, rig, 1.0)
+            o["loss"].backward()
+            opt.step()
+            return o["loss"].detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                one()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss_t = one()
+        run = g.replay
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=4e-4)
+
+        def run():
+            out.update(train_step(model, opt, rest, deff, rig))
+        out = {}
     for _ in range(2):
-        train_step(model, opt, rest, deff, rig)
+        run()
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = train_step(model, opt, rest, deff, rig)
+        run()
     torch.cuda.synchronize()
+    if a.graph:
+        out = {"loss": loss_t}
     ms = (time.perf_counter() - t0) / a.steps * 1e3
     e = rest.edge_index.shape[1] + rig.edge_index.shape[1]
     ns, nr = rest.x.shape[0], rig.x.shape[0]
