@@ -69,3 +69,81 @@ def to_batches(collated, device=None) -> Tuple[Batch, Batch, Batch]:
     if device is not None:
         out = tuple(b.to(device) for b in out)
     return out
+
+
+class PrefetchLoader:
+    """Background batch assembly + overlapped upload.
+
+    The reference loads with ``DataLoader(num_workers=0)`` and builds the three PyG batches and
+    their ``.to(device)`` copies on the training thread (``train.py:25-44``), so every step waits
+    for the per-sample Python work (mesh reading, ``mesh_to_graph``, collate).  Here a worker
+    thread runs ``iterate_batches`` + ``Batch.from_data_list`` ``depth`` batches ahead, pins the
+    host tensors, and the consumer uploads batch i+1 on a side HIP stream while batch i trains;
+    ``__iter__`` yields ``(collated, (rest, deff, rig))`` with the batches already on ``device``.
+    Order and contents equal ``iterate_batches`` + ``to_batches``.
+    """
+
+    def __init__(self, dataset, batch_size: int, device=None, shuffle: bool = False, seed: int = 0,
+                 drop_last: bool = False, depth: int = 2):
+        self.dataset, self.batch_size, self.device = dataset, batch_size, device
+        self.shuffle, self.seed, self.drop_last, self.depth = shuffle, seed, drop_last, max(1, depth)
+
+    def _produce(self, q):
+        try:
+            pin = self.device is not None and torch.device(self.device).type == "cuda"
+            for collated in iterate_batches(self.dataset, self.batch_size, self.shuffle, self.seed,
+                                            self.drop_last):
+                host = to_batches(collated, None)
+                if pin:
+                    for b in host:
+                        for k in ("x", "pos", "edge_index", "batch", "ptr"):
+                            t = getattr(b, k, None)
+                            if isinstance(t, torch.Tensor):
+                                setattr(b, k, t.pin_memory())
+                q.put((collated, host))
+            q.put(None)
+        except BaseException as e:          # surface worker errors in the consumer
+            q.put(e)
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        worker = threading.Thread(target=self._produce, args=(q,), daemon=True)
+        worker.start()
+        cuda = self.device is not None and torch.device(self.device).type == "cuda"
+        side = torch.cuda.Stream(device=self.device) if cuda else None
+
+        def upload(item):
+            collated, host = item
+            if self.device is None:
+                return collated, host, None
+            if not cuda:
+                return collated, tuple(b.to(self.device) for b in host), None
+            with torch.cuda.stream(side):
+                dev = tuple(b.to(self.device, non_blocking=True) for b in host)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return collated, dev, ev
+
+        def get():
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            return item
+
+        nxt = get()
+        pending = upload(nxt) if nxt is not None else None
+        while pending is not None:
+            collated, dev, ev = pending
+            nxt = get()
+            pending = upload(nxt) if nxt is not None else None      # next upload overlaps this step
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for b in dev:
+                    for k in ("x", "pos", "edge_index", "batch", "ptr"):
+                        t = getattr(b, k, None)
+                        if isinstance(t, torch.Tensor) and t.is_cuda:
+                            t.record_stream(torch.cuda.current_stream(self.device))
+            yield collated, dev
+        worker.join()

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import dp
 from .graphnet import EVERYDAY_NETWORK, gradient_consistency_loss, load_model
-from .loaders import SyntheticEverydayDataset, iterate_batches, to_batches
+from .loaders import PrefetchLoader, SyntheticEverydayDataset, iterate_batches, to_batches
 
 
 def losses(model, rest, deff, rig, lambda_gradient: float = 1.0) -> Dict[str, torch.Tensor]:
@@ -67,8 +67,9 @@ def train(network_cfg=None, *, device="cuda", epochs: int = 2, num_train: int = 
     best, step = float("inf"), 0
     for epoch in range(epochs):
         model.train()
-        for collated in iterate_batches(train_ds, batch_size, shuffle=True, seed=seed + epoch):
-            rest, deff, rig = to_batches(collated, device)
+        # worker thread assembles + pins the next batches, uploads overlap the current step
+        for collated, (rest, deff, rig) in PrefetchLoader(train_ds, batch_size, device, shuffle=True,
+                                                          seed=seed + epoch):
             out = train_step(model, opt, rest, deff, rig, lambda_gradient, bucket)
             if step % log_every == 0:
                 log.write(json.dumps({"step": step, "epoch": epoch, "t": time.time(),

@@ -784,3 +784,16 @@ def test_blocked_attention_core_vs_float64(ns, nr, d, dv, block):
     assert rel_err(_np(out), ref.detach().numpy()) < 5e-6
     for name, got, want in (("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
         assert rel_err(_np(got), want.numpy()) < 1e-5, name
+
+
+def test_prefetch_loader_uploads_equal_plain_batches():
+    from deformcontact_amd.loaders import (PrefetchLoader, SyntheticEverydayDataset, iterate_batches,
+                                           to_batches)
+    ds = SyntheticEverydayDataset(5, first_idx=1, soft_vertices=128, sphere_resolution=6)
+    plain = [to_batches(c, DEV) for c in iterate_batches(ds, 2)]
+    got = [b for _, b in PrefetchLoader(ds, 2, DEV)]
+    assert len(got) == len(plain)
+    for b0, b1 in zip(plain, got):
+        for x, y in zip(b0, b1):
+            assert y.x.is_cuda and torch.equal(x.x, y.x) and torch.equal(x.edge_index, y.edge_index)
+            assert torch.equal(x.pos, y.pos)

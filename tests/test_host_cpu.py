@@ -169,3 +169,30 @@ def test_synth_everyday_shape():
     deg = np.bincount(rig.edge_index.numpy()[1][:4560], minlength=762)
     assert sorted(np.unique(deg).tolist()) == [5, 6, 40]
     assert deff.pos.shape == rest.pos.shape
+
+
+def test_prefetch_loader_matches_plain_iteration_cpu():
+    """PrefetchLoader (worker thread, depth-2 queue) yields the batches of iterate_batches + to_batches
+    in the same order with the same contents; worker exceptions surface in the consumer."""
+    import torch
+    from deformcontact_amd.loaders import (PrefetchLoader, SyntheticEverydayDataset, iterate_batches,
+                                           to_batches)
+    ds = SyntheticEverydayDataset(5, first_idx=3, soft_vertices=64, sphere_resolution=4)
+    plain = [(c, to_batches(c, None)) for c in iterate_batches(ds, 2, shuffle=True, seed=7)]
+    for dev in (None, "cpu"):
+        got = list(PrefetchLoader(ds, 2, dev, shuffle=True, seed=7))
+        assert len(got) == len(plain) == 3
+        for (c0, b0), (c1, b1) in zip(plain, got):
+            assert c0[0] == c1[0]
+            for x, y in zip(b0, b1):
+                assert torch.equal(x.x, y.x) and torch.equal(x.edge_index, y.edge_index)
+                assert torch.equal(x.pos, y.pos) and torch.equal(x.batch, y.batch)
+
+    class Broken(SyntheticEverydayDataset):
+        def __getitem__(self, i):
+            if i == 3:
+                raise RuntimeError("boom")
+            return super().__getitem__(i)
+    import pytest
+    with pytest.raises(RuntimeError, match="boom"):
+        list(PrefetchLoader(Broken(5, soft_vertices=64, sphere_resolution=4), 2, None))
