@@ -450,7 +450,7 @@ k_dw_split(DwParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
     const unsigned ntm = (unsigned)((p.Fo + BM - 1) / BM), ntn = (unsigned)((p.Fi + BN - 1) / BN);
     const unsigned tiles = ntm * ntn, per_chunk = tiles * p.nseg;
-    const unsigned lb = blockIdx.x;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);   // a chunk's tiles share one L2
     const unsigned chunk = lb / per_chunk, rem = lb % per_chunk;
     const int s = (int)(rem / tiles);
     const int64_t o0 = (int64_t)((rem % tiles) / ntn) * BM, f0 = (int64_t)((rem % tiles) % ntn) * BN;
