@@ -185,9 +185,11 @@ k_fwd_h2(FwdParams p) {
             store(nxt);
             load();
             mma();
-            // the DMA pieces (issued before this stage's NVA loads) must be in LDS before the
-            // barrier; the register loads of stage it+2 may stay in flight
-            if (BDMA) __builtin_amdgcn_s_waitcnt(0xF70 | NVA);
+            // the DMA pieces must be in LDS before the barrier.  vmcnt(0) also drains the register
+            // loads of stage it+2 (issued at the top of this stage, a whole MFMA phase ago): a counted
+            // vmcnt(NVA) would let them stay in flight but relies on hipcc keeping the DMAs ahead of
+            // those loads in program order - measured no faster (61.4 vs 61.3 us), so the robust form
+            if (BDMA) __builtin_amdgcn_s_waitcnt(0xF70 | 0);
             // (explicit sched_group_barrier orders - 1 MFMA : 6-8 VALU, VALU first, early loads, 2 MFMA
             // groups - all measured 1-3 % slower than hipcc's own order of this single block)
             __syncthreads();
