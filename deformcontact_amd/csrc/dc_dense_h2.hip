@@ -50,8 +50,13 @@ k_fwd_h2(FwdParams p) {
     // padding: piece q of row r sits at position q ^ ((r >> 2) & 3); each lane simply FETCHES the
     // piece that belongs at its position.
     constexpr int kRowB = BDMA ? 64 : kH2Row;
-    constexpr int kOffB = BM * kH2Row, kStage = BM * kH2Row + BN * kRowB;
-    __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
+    // A and B live in SEPARATE LDS objects: hipcc guards every DS access that may alias an
+    // outstanding LDS-DMA with s_waitcnt vmcnt(0); with one array the ds_writes of the A tile
+    // (issued right after the DMA of the B tile) waited for that DMA - a global-memory latency in
+    // the middle of every stage
+    constexpr int kSzA = BM * kH2Row, kSzB = BN * kRowB, kOffB = 0;
+    __shared__ __attribute__((aligned(16))) char sA[2 * kSzA];
+    __shared__ __attribute__((aligned(16))) char sB[2 * kSzB];
     __shared__ float s_inv[BM];
     const unsigned ntn = (unsigned)((p.Fo + BN - 1) / BN);
     const unsigned ks = p.ksplit > 1 ? (unsigned)p.ksplit : 1u, ntiles = gridDim.x / ks;
@@ -116,20 +121,20 @@ k_fwd_h2(FwdParams p) {
             baseB += BK;
         }
     };
-    auto dma_b = [&](char *buf) {                     // B of the NEXT stage straight into `buf`
+    auto dma_b = [&](int b) {                         // B of the NEXT stage straight into buffer b
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             __builtin_amdgcn_global_load_lds(
                 (const void __attribute__((address_space(1))) *)(baseB + dmaOff[q]),
-                (void __attribute__((address_space(3))) *)(buf + kOffB + (wid * 32 + q * 16) * 64), 16, 0, 0);
+                (void __attribute__((address_space(3))) *)(sB + b * kSzB + (wid * 32 + q * 16) * 64), 16, 0, 0);
         baseB += BK;
     };
-    auto store = [&](char *buf) {
+    auto store = [&](int b) {
 #pragma unroll
-        for (int j = 0; j < NVA; ++j) h2_split_store(buf + ldsA[j], va[j], scA[j]);
+        for (int j = 0; j < NVA; ++j) h2_split_store(sA + b * kSzA + ldsA[j], va[j], scA[j]);
         if (!BDMA) {
 #pragma unroll
-            for (int j = 0; j < NVB; ++j) h2_split_store(buf + ldsB[j], vb[j], scB[j]);
+            for (int j = 0; j < NVB; ++j) h2_split_store(sB + b * kSzB + ldsB[j], vb[j], scB[j]);
         }
     };
     const int fr = lane & 31, fh = lane >> 5;
@@ -144,12 +149,14 @@ k_fwd_h2(FwdParams p) {
             fragBd[nb][pl] = kOffB + rowl * 64 + 16 * ((2 * pl + fh) ^ ((rowl >> 2) & 3));
         }
     h2_f16x8 fa[MB][2], fb[2][2];
-    auto frags = [&](const char *buf) {
+    auto frags = [&](int b) {
+        const char *buf = sB + b * kSzB;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-                fa[mb][pl] = *reinterpret_cast<const h2_f16x8 *>(buf + fragA + mb * 32 * kH2Row + pl * kH2Plane);
+                fa[mb][pl] = *reinterpret_cast<const h2_f16x8 *>(sA + b * kSzA + fragA + mb * 32 * kH2Row +
+                                                                 pl * kH2Plane);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -171,15 +178,15 @@ k_fwd_h2(FwdParams p) {
     };
 
     if (nst > 0) {
-        if (BDMA) dma_b(lds);
+        if (BDMA) dma_b(0);
         load();
-        store(lds);
+        store(0);
         if (nst > 1) load();
         if (BDMA) __builtin_amdgcn_s_waitcnt(0xF70 | 0);      // vmcnt(0): the DMA piece has landed
         __syncthreads();
         int it = 0;
         for (; it + 2 < nst; ++it) {                 // steady state: one basic block
-            char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
+            const int cur = it & 1, nxt = cur ^ 1;
             frags(cur);
             if (BDMA) dma_b(nxt);                     // lands during this stage's MFMAs
             store(nxt);
@@ -195,7 +202,7 @@ k_fwd_h2(FwdParams p) {
             __syncthreads();
         }
         for (; it < nst; ++it) {                     // last two stages
-            char *cur = lds + (it & 1) * kStage, *nxt = lds + ((it + 1) & 1) * kStage;
+            const int cur = it & 1, nxt = cur ^ 1;
             frags(cur);
             if (it + 1 < nst) {
                 if (BDMA) dma_b(nxt);
