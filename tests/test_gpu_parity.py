@@ -461,6 +461,20 @@ def test_conv_forward_backward_vs_oracle(kind, n, e, fi, fo):
         assert rel_err(_np(p.grad), _np(gc[name].grad)) < 2 * TOL, name
 
 
+@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x3", "bf16x3_multihop"])
+def test_tagconv_alternative_dense_paths_vs_oracle(path):
+    """The dense-block implementations the default (scaled fp16x2) replaces stay selectable
+    (DC_DENSE_SPLIT=0, DC_DENSE_F16X2=0, DC_MULTIHOP=1): same parity bar on a wide layer."""
+    saved = (ops.DENSE_SPLIT_BF16, ops.DENSE_F16X2, ops.MULTIHOP)
+    try:
+        ops.DENSE_SPLIT_BF16 = path != "fp32_mfma"
+        ops.DENSE_F16X2 = False
+        ops.MULTIHOP = path.endswith("multihop")
+        test_conv_forward_backward_vs_oracle("TAGConv", 150, 1100, 256, 256)
+    finally:
+        ops.DENSE_SPLIT_BF16, ops.DENSE_F16X2, ops.MULTIHOP = saved
+
+
 @pytest.mark.parametrize("backbone,fname", [("TAGConv", "graphnet_tag_h32.npz"),
                                              ("GCNConv", "graphnet_gcn_h32.npz"),
                                              ("GATConv", "graphnet_gat_h32.npz")])
