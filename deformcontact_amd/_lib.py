@@ -19,9 +19,14 @@ _vp = c_void_p
 _SIGNATURES = {
     "dc_version": (c_int, []),
     "dc_last_error": (c_char_p, []),
+    "dc_stream_capture_id": (c_int64, [_vp]),
     "dc_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "dc_csr_build": (c_int, [_vp, c_int64, c_int64, c_int, c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, c_int64, _vp]),
+    "dc_graph_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "dc_graph_build": (c_int, [_vp, c_int64, c_int64, c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, c_int64, _vp]),
+    "dc_hash_i64": (c_int, [_vp, c_int64, _vp, _vp]),
     "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
     "dc_spmm_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                             c_int64, _vp]),

@@ -14,5 +14,15 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace dc
 
-extern "C" int dc_version(void) { return 100; }   // 0.1.0
+extern "C" int dc_version(void) { return 200; }   // 0.2.0
 extern "C" const char *dc_last_error(void) { return dc::g_err; }
+
+extern "C" int64_t dc_stream_capture_id(dc_stream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo((hipStream_t)stream, &st, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return st == hipStreamCaptureStatusActive ? (int64_t)id : 0;
+}

@@ -2,46 +2,81 @@
 //
 // Replaces the implicit destination ordering of PyG's scatter_add_ and the
 // gcn_norm call TAGConv/GCNConv.forward repeats on every invocation
-// (/root/reference/models/model.py:71,77).  Integer work, HBM/L2-bound, built
-// once per batched edge_index and cached by the host.
+// (/root/reference/models/model.py:71,77).  Integer work, L2/HBM-bound, once per
+// batched edge_index.
 //
-// Pipeline (all on one stream, no host sync):
+// One pipeline builds ONE side (dc_csr_build: edges grouped by edge_index[key_row])
+// or BOTH sides (dc_graph_build: by destination for the forward hop and by source
+// for the transposed hop of the backward pass) -- the two sides share every launch
+// (gridDim.y = side), so a whole GraphIndex costs 5 launches for the batch sizes of
+// the reference (2N <= kScanSmall) and 7 beyond, on one stream, no host sync:
+//
+//   k_init       counters = 0 (1 with self loops), status = 0, big-group count = 0
 //   k_count      histogram of the key endpoint (int atomics; order-free)
-//   k_scan_*     exclusive scan -> ptr[N+1]               (3 small kernels)
+//   k_scan_*     exclusive scan -> ptr[N+1] (one block per side when small, else
+//                reduce / tile scan / apply); groups longer than kRankLoop are listed
 //   k_fill       bucket every edge id into its group in ARBITRARY order
-//   k_rank_emit  rank each id inside its group (count of smaller ids) and
-//                write perm/other/w at ptr[key]+rank -> the order is the
-//                stable sort no matter how the atomics in k_fill interleaved.
+//   k_emit       small groups: rank each id inside its group (count of smaller ids);
+//                listed (big) groups: one workgroup sorts the group's ids (bitonic
+//                network with ascending comparators only, in LDS up to 4096 ids,
+//                in place in global memory beyond) -- O(S log^2 S), no O(deg^2) walk
+//                on hubs; then perm/other/w are written at ptr[key]+rank, so the
+//                result is the stable sort no matter how the atomics interleaved.
 #include "dc_common.h"
 
 namespace dc {
 
-constexpr int kScanTile = 1024;   // elements per scan block (256 threads x 4)
+constexpr int kScanTile = 1024;      // elements per scan block (256 threads x 4)
+constexpr int kScanSmall = 1 << 16;  // per-side N up to which ONE block scans a side
+constexpr int kRankLoop = 48;        // groups up to this length rank by counting
+constexpr int kBigBlocks = 64;       // extra workgroups of k_emit that sort listed groups
+constexpr int kSortLds = 4096;       // ids sorted in LDS (16 KiB); longer groups in place
 
-struct EdgeView {
-    const int64_t *key;
-    const int64_t *oth;
+struct Side {
+    const int64_t *key;    // edge_index row that groups this side
+    const int64_t *oth;    // the other row
+    int32_t *cnt;          // [N]   counters, then fill cursors (workspace)
+    int32_t *tmp;          // [E+N] edge ids bucketed per group (workspace)
+    int32_t *tiles;        // [ntiles+2] scan tile sums (workspace)
+    int32_t *big;          // [1 + N] count + list of groups longer than kRankLoop (workspace)
+    int32_t *ptr;          // [N+1] out
+    int32_t *other;        // [E'] out
+    int32_t *perm;         // [E'] out
+    float *w;              // [E'] out or null
+    const int32_t *deg_ptr;  // offsets whose differences are the in-degrees gcn_norm uses
+    int key_is_dst;
+};
+
+struct Build {
+    Side s[2];
     int64_t E, N;
     int self_loops;
+    int32_t *status;
 };
 
 __global__ void __launch_bounds__(256)
-k_fill_i32(int32_t *p, int64_t n, int32_t v) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+k_init(Build b) {
+    const Side &sd = b.s[blockIdx.y];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b.N) sd.cnt[i] = b.self_loops ? 1 : 0;
+    if (i == 0) {
+        sd.big[0] = 0;
+        if (blockIdx.y == 0) *b.status = 0;
+    }
 }
 
 __global__ void __launch_bounds__(256)
-k_count(EdgeView ev, int32_t *cnt, int32_t *status) {
+k_count(Build b, int nsides) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ev.E) return;
-    const int64_t k = ev.key[e], o = ev.oth[e];
-    if (k < 0 || k >= ev.N || o < 0 || o >= ev.N) {
-        atomicOr(status, 1);
+    if (e >= b.E) return;
+    const int64_t k = b.s[0].key[e], o = b.s[0].oth[e];
+    if (k < 0 || k >= b.N || o < 0 || o >= b.N) {
+        atomicOr(b.status, 1);
         return;
     }
-    if (ev.self_loops && k == o) return;
-    atomicAdd(&cnt[k], 1);
+    if (b.self_loops && k == o) return;
+    atomicAdd(&b.s[0].cnt[k], 1);
+    if (nsides == 2) atomicAdd(&b.s[1].cnt[o], 1);   // side 1 groups by side 0's other row
 }
 
 // ---- exclusive scan of cnt[0..N) into ptr[0..N], ptr[N] = total -----------
@@ -54,83 +89,124 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-// inclusive scan across a 256-thread block; returns this thread's inclusive
+// inclusive scan across a block of NW waves; returns this thread's inclusive
 // value, *total = block sum
-__device__ __forceinline__ int block_incl_scan256(int v, int *total) {
-    __shared__ int wsum[4];
+template <int NW>
+__device__ __forceinline__ int block_incl_scan(int v, int *total) {
+    __shared__ int wsum[NW];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int inc = wave_incl_scan(v);
     if (lane == 63) wsum[wid] = inc;
     __syncthreads();
-    int off = 0;
+    int off = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < NW; ++w) {
         if (w < wid) off += wsum[w];
-    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        tot += wsum[w];
+    }
+    *total = tot;
     __syncthreads();
     return inc + off;
 }
 
+__device__ __forceinline__ void note_big(const Side &sd, int64_t node, int len) {
+    if (len > kRankLoop) sd.big[1 + atomicAdd(&sd.big[0], 1)] = (int32_t)node;
+}
+
+// one 1024-thread block per side: counts -> ptr, cursors, big-group list
+__global__ void __launch_bounds__(1024)
+k_scan_small(Build b) {
+    const Side &sd = b.s[blockIdx.x];
+    int carry = 0;
+    for (int64_t base = 0; base < b.N; base += 4096) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 4;
+        int v[4], s = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = i0 + j < b.N ? sd.cnt[i0 + j] : 0;
+            s += v[j];
+        }
+        int total;
+        int run = carry + block_incl_scan<16>(s, &total) - s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < b.N) {
+                sd.ptr[i0 + j] = run;
+                sd.cnt[i0 + j] = run;   // becomes the fill cursor
+                note_big(sd, i0 + j, v[j]);
+            }
+            run += v[j];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) sd.ptr[b.N] = carry;
+}
+
 __global__ void __launch_bounds__(256)
-k_scan_reduce(const int32_t *cnt, int64_t N, int32_t *tile_sums) {
+k_scan_reduce(Build b) {
+    const Side &sd = b.s[blockIdx.y];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 4;
     int s = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (base + j < N) s += cnt[base + j];
+        if (base + j < b.N) s += sd.cnt[base + j];
     int total;
-    block_incl_scan256(s, &total);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+    block_incl_scan<4>(s, &total);
+    if (threadIdx.x == 0) sd.tiles[blockIdx.x] = total;
 }
 
 __global__ void __launch_bounds__(256)
-k_scan_tiles(int32_t *tile_sums, int64_t ntiles) {   // single block, in place -> exclusive
+k_scan_tiles(Build b, int64_t ntiles) {   // one block per side, in place -> exclusive
+    const Side &sd = b.s[blockIdx.x];
     int carry = 0;
     for (int64_t base = 0; base < ntiles; base += 256) {
         const int64_t i = base + threadIdx.x;
-        const int v = i < ntiles ? tile_sums[i] : 0;
+        const int v = i < ntiles ? sd.tiles[i] : 0;
         int total;
-        const int inc = block_incl_scan256(v, &total);
-        if (i < ntiles) tile_sums[i] = carry + inc - v;
+        const int inc = block_incl_scan<4>(v, &total);
+        if (i < ntiles) sd.tiles[i] = carry + inc - v;
         carry += total;
     }
-    if (threadIdx.x == 0) tile_sums[ntiles] = carry;
+    if (threadIdx.x == 0) sd.tiles[ntiles] = carry;
 }
 
 __global__ void __launch_bounds__(256)
-k_scan_apply(int32_t *cnt /* in: counts, out: cursor = ptr */, int64_t N,
-             const int32_t *tile_sums, int64_t ntiles, int32_t *ptr) {
+k_scan_apply(Build b, int64_t ntiles) {
+    const Side &sd = b.s[blockIdx.y];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 4;
     int v[4], s = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        v[j] = base + j < N ? cnt[base + j] : 0;
+        v[j] = base + j < b.N ? sd.cnt[base + j] : 0;
         s += v[j];
     }
     int total;
-    int run = block_incl_scan256(s, &total) - s + tile_sums[blockIdx.x];
+    int run = block_incl_scan<4>(s, &total) - s + sd.tiles[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (base + j < N) {
-            ptr[base + j] = run;
-            cnt[base + j] = run;   // becomes the fill cursor
+        if (base + j < b.N) {
+            sd.ptr[base + j] = run;
+            sd.cnt[base + j] = run;   // becomes the fill cursor
+            note_big(sd, base + j, v[j]);
         }
         run += v[j];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) ptr[N] = tile_sums[ntiles];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sd.ptr[b.N] = sd.tiles[ntiles];
 }
 
 __global__ void __launch_bounds__(256)
-k_fill(EdgeView ev, int32_t *cursor, int32_t *tmp) {
+k_fill(Build b, int nsides) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ev.E) {
-        const int64_t k = ev.key[t], o = ev.oth[t];
-        if (k < 0 || k >= ev.N || o < 0 || o >= ev.N) return;
-        if (ev.self_loops && k == o) return;
-        tmp[atomicAdd(&cursor[k], 1)] = (int32_t)t;
-    } else if (ev.self_loops && t < ev.E + ev.N) {
-        const int64_t k = t - ev.E;
-        tmp[atomicAdd(&cursor[k], 1)] = (int32_t)t;
+    if (t < b.E) {
+        const int64_t k = b.s[0].key[t], o = b.s[0].oth[t];
+        if (k < 0 || k >= b.N || o < 0 || o >= b.N) return;
+        if (b.self_loops && k == o) return;
+        b.s[0].tmp[atomicAdd(&b.s[0].cnt[k], 1)] = (int32_t)t;
+        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cnt[o], 1)] = (int32_t)t;
+    } else if (b.self_loops && t < b.E + b.N) {
+        const int64_t k = t - b.E;
+        b.s[0].tmp[atomicAdd(&b.s[0].cnt[k], 1)] = (int32_t)t;
+        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cnt[k], 1)] = (int32_t)t;
     }
 }
 
@@ -139,30 +215,87 @@ __device__ __forceinline__ float inv_sqrt_deg(const int32_t *deg_ptr, int64_t v)
     return d > 0 ? 1.0f / sqrtf((float)d) : 0.0f;   // deg.pow(-0.5), inf -> 0
 }
 
-__global__ void __launch_bounds__(256)
-k_rank_emit(EdgeView ev, const int32_t *ptr, const int32_t *tmp, int32_t *other,
-            int32_t *perm, const int32_t *deg_ptr, float *w, int key_is_dst) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= ptr[ev.N]) return;
-    const int32_t eid = tmp[p];
-    int64_t k, o;
-    if (eid < ev.E) {
-        k = ev.key[eid];
-        o = ev.oth[eid];
-    } else {
-        k = o = eid - ev.E;
-    }
-    const int32_t beg = ptr[k], end = ptr[k + 1];
-    int rank = 0;
-    for (int32_t q = beg; q < end; ++q) rank += tmp[q] < eid;
-    const int32_t out = beg + rank;
-    perm[out] = eid;
-    other[out] = (int32_t)o;
-    if (w) {
+__device__ __forceinline__ void emit_one(const Build &b, const Side &sd, int32_t eid, int64_t k,
+                                         int32_t out) {
+    const int64_t o = eid < b.E ? sd.oth[eid] : k;
+    sd.perm[out] = eid;
+    sd.other[out] = (int32_t)o;
+    if (sd.w) {
         // gcn_norm: dis[row] * 1 * dis[col]  (row = source, col = destination)
-        const int64_t src = key_is_dst ? o : k, dst = key_is_dst ? k : o;
-        w[out] = inv_sqrt_deg(deg_ptr, src) * 1.0f * inv_sqrt_deg(deg_ptr, dst);
+        const int64_t src = sd.key_is_dst ? o : k, dst = sd.key_is_dst ? k : o;
+        sd.w[out] = inv_sqrt_deg(sd.deg_ptr, src) * 1.0f * inv_sqrt_deg(sd.deg_ptr, dst);
     }
+}
+
+// Sort a[0..S) ascending with the bitonic network in its all-ascending-comparator form (the
+// first step of every merge compares mirrored positions), so positions >= S can be treated as
+// +infinity without ever being stored.  Ids are distinct: no stability question.
+template <typename Get, typename Put>
+__device__ __forceinline__ void bitonic_sort(int S, Get get, Put put) {
+    int P = 2;
+    while (P < S) P <<= 1;
+    for (int size = 2; size <= P; size <<= 1) {
+        const int half = size >> 1;
+        for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+            const int blk = t / half, off = t - blk * half;
+            const int i = blk * size + off, j = blk * size + size - 1 - off;
+            if (j < S) {
+                const int32_t a = get(i), c = get(j);
+                if (a > c) { put(i, c); put(j, a); }
+            }
+        }
+        __syncthreads();
+        for (int stride = half >> 1; stride >= 1; stride >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const int i = 2 * stride * (t / stride) + (t % stride), j = i + stride;
+                if (j < S) {
+                    const int32_t a = get(i), c = get(j);
+                    if (a > c) { put(i, c); put(j, a); }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_emit(Build b, unsigned slot_blocks) {
+    const Side &sd = b.s[blockIdx.y];
+    if (blockIdx.x >= slot_blocks) {
+        // ---- listed groups: sort the ids of the whole group, then emit in order ----
+        __shared__ int32_t lds[kSortLds];
+        const int nbig = sd.big[0];
+        for (int g = blockIdx.x - slot_blocks; g < nbig; g += kBigBlocks) {
+            const int64_t k = sd.big[1 + g];
+            const int32_t beg = sd.ptr[k], S = sd.ptr[k + 1] - beg;
+            int32_t *seg = sd.tmp + beg;
+            if (S <= kSortLds) {
+                for (int q = threadIdx.x; q < S; q += blockDim.x) lds[q] = seg[q];
+                __syncthreads();
+                bitonic_sort(S, [&](int i) { return lds[i]; }, [&](int i, int32_t v) { lds[i] = v; });
+                for (int q = threadIdx.x; q < S; q += blockDim.x) emit_one(b, sd, lds[q], k, beg + q);
+                __syncthreads();
+            } else {
+                // in place in global memory; one workgroup owns the segment: its own stores are
+                // visible to its own later loads once the barrier has drained them (volatile
+                // accesses keep them out of registers / the non-coherent path)
+                volatile int32_t *vs = seg;
+                bitonic_sort(S, [&](int i) { return vs[i]; }, [&](int i, int32_t v) { vs[i] = v; });
+                for (int q = threadIdx.x; q < S; q += blockDim.x) emit_one(b, sd, vs[q], k, beg + q);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= sd.ptr[b.N]) return;
+    const int32_t eid = sd.tmp[p];
+    const int64_t k = eid < b.E ? sd.key[eid] : eid - b.E;
+    const int32_t beg = sd.ptr[k], end = sd.ptr[k + 1];
+    if (end - beg > kRankLoop) return;          // a listed group: the sorting workgroups emit it
+    int rank = 0;
+    for (int32_t q = beg; q < end; ++q) rank += sd.tmp[q] < eid;
+    emit_one(b, sd, eid, k, beg + rank);
 }
 
 __global__ void __launch_bounds__(256)
@@ -171,7 +304,71 @@ k_invert_perm(const int32_t *perm, const int32_t *n_ptr, int32_t *pos_of, int64_
     if (p < max_edges && p < *n_ptr) pos_of[perm[p]] = (int32_t)p;
 }
 
+// order-independent 64-bit content hash of an int64 array (sum of mixed (value, position) words)
+__global__ void __launch_bounds__(256)
+k_hash_i64(const int64_t *v, int64_t n, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (unsigned long long)v[i] * 0x9E3779B97F4A7C15ull +
+                               ((unsigned long long)i + 1) * 0xC2B2AE3D27D4EB4Full;
+        z ^= z >> 29;
+        z *= 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 32;
+        acc += z;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 static inline int64_t align16(int64_t b) { return (b + 15) & ~int64_t(15); }
+
+static inline int64_t side_bytes(int64_t E, int64_t N) {
+    const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
+    return align16(4 * (N + 1)) + align16(4 * (E + N + 1)) + align16(4 * (ntiles + 2)) +
+           align16(4 * (N + 2));
+}
+
+static char *carve_side(Side &sd, char *ws, int64_t E, int64_t N) {
+    const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
+    sd.cnt = (int32_t *)ws;
+    ws += align16(4 * (N + 1));
+    sd.tmp = (int32_t *)ws;
+    ws += align16(4 * (E + N + 1));
+    sd.tiles = (int32_t *)ws;
+    ws += align16(4 * (ntiles + 2));
+    sd.big = (int32_t *)ws;
+    ws += align16(4 * (N + 2));
+    return ws;
+}
+
+static int run_build(Build &b, int nsides, hipStream_t stream, const char *what) {
+    const int64_t E = b.E, N = b.N;
+    if (N == 0) {
+        for (int s = 0; s < nsides; ++s) hipMemsetAsync(b.s[s].ptr, 0, sizeof(int32_t), stream);
+        hipMemsetAsync(b.status, 0, sizeof(int32_t), stream);
+        return check_launch(what);
+    }
+    const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
+    const int64_t slots = E + (b.self_loops ? N : 0);
+    hipLaunchKernelGGL(k_init, dim3((unsigned)((N + 255) / 256), nsides), dim3(256), 0, stream, b);
+    if (E > 0)
+        hipLaunchKernelGGL(k_count, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, b, nsides);
+    if (N <= kScanSmall) {
+        hipLaunchKernelGGL(k_scan_small, dim3(nsides), dim3(1024), 0, stream, b);
+    } else {
+        hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ntiles, nsides), dim3(256), 0, stream, b);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(nsides), dim3(256), 0, stream, b, ntiles);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntiles, nsides), dim3(256), 0, stream, b, ntiles);
+    }
+    if (slots > 0) {
+        const unsigned sb = (unsigned)((slots + 255) / 256);
+        hipLaunchKernelGGL(k_fill, dim3(sb), dim3(256), 0, stream, b, nsides);
+        hipLaunchKernelGGL(k_emit, dim3(sb + kBigBlocks, nsides), dim3(256), 0, stream, b, sb);
+    }
+    return check_launch(what);
+}
 
 }  // namespace dc
 
@@ -179,8 +376,12 @@ using namespace dc;
 
 extern "C" int64_t dc_csr_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return DC_EINVAL;
-    const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
-    return align16(4 * (N + 1)) + align16(4 * (E + N + 1)) + align16(4 * (ntiles + 2));
+    return side_bytes(E, N);
+}
+
+extern "C" int64_t dc_graph_workspace_bytes(int64_t E, int64_t N) {
+    if (E < 0 || N < 0) return DC_EINVAL;
+    return 2 * side_bytes(E, N);
 }
 
 extern "C" int dc_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int key_row,
@@ -202,37 +403,48 @@ extern "C" int dc_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int
                (long long)dc_csr_workspace_bytes(E, N));
     DC_REQUIRE(((uintptr_t)workspace & 15) == 0, "dc_csr_build: workspace not 16-byte aligned");
 
-    const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
+    Build b{};
+    b.E = E, b.N = N, b.self_loops = self_loops, b.status = status;
+    Side &sd = b.s[0];
+    sd.key = edge_index + (key_row ? E : 0);
+    sd.oth = edge_index + (key_row ? 0 : E);
+    carve_side(sd, (char *)workspace, E, N);
+    sd.ptr = ptr, sd.other = other, sd.perm = perm, sd.w = w;
+    sd.deg_ptr = deg_ptr ? deg_ptr : ptr;
+    sd.key_is_dst = key_row;
+    return run_build(b, 1, stream, "dc_csr_build");
+}
+
+extern "C" int dc_graph_build(const int64_t *edge_index, int64_t E, int64_t N, int self_loops,
+                              int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
+                              int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
+                              int32_t *status, void *workspace, int64_t workspace_bytes,
+                              dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(E >= 0 && N >= 0, "dc_graph_build: negative size E=%lld N=%lld", (long long)E,
+               (long long)N);
+    DC_REQUIRE(E + N < (int64_t)INT32_MAX, "dc_graph_build: E+N=%lld exceeds int32 indexing",
+               (long long)(E + N));
+    DC_REQUIRE(ptr_f && ptr_b && status && workspace, "dc_graph_build: null ptr/status/workspace");
+    DC_REQUIRE(E == 0 || (edge_index && other_f && perm_f && other_b && perm_b),
+               "dc_graph_build: null edge arrays");
+    DC_REQUIRE((w_f == nullptr) == (w_b == nullptr), "dc_graph_build: w_f and w_b go together");
+    DC_REQUIRE(workspace_bytes >= dc_graph_workspace_bytes(E, N),
+               "dc_graph_build: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+               (long long)dc_graph_workspace_bytes(E, N));
+    DC_REQUIRE(((uintptr_t)workspace & 15) == 0, "dc_graph_build: workspace not 16-byte aligned");
+
+    Build b{};
+    b.E = E, b.N = N, b.self_loops = self_loops, b.status = status;
     char *ws = (char *)workspace;
-    int32_t *cnt = (int32_t *)ws;
-    ws += align16(4 * (N + 1));
-    int32_t *tmp = (int32_t *)ws;
-    ws += align16(4 * (E + N + 1));
-    int32_t *tile_sums = (int32_t *)ws;
-
-    EdgeView ev{edge_index + (key_row ? E : 0), edge_index + (key_row ? 0 : E), E, N, self_loops};
-    const int64_t slots = E + (self_loops ? N : 0);
-
-    if (N == 0) {
-        hipMemsetAsync(ptr, 0, sizeof(int32_t), stream);
-        return check_launch("dc_csr_build(memset)");
-    }
-    if (self_loops)
-        hipLaunchKernelGGL(k_fill_i32, dim3((N + 255) / 256), dim3(256), 0, stream, cnt, N, 1);
-    else
-        hipMemsetAsync(cnt, 0, sizeof(int32_t) * N, stream);
-    if (E > 0)
-        hipLaunchKernelGGL(k_count, dim3((E + 255) / 256), dim3(256), 0, stream, ev, cnt, status);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(ntiles), dim3(256), 0, stream, cnt, N, tile_sums);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, stream, tile_sums, ntiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, stream, cnt, N, tile_sums, ntiles,
-                       ptr);
-    if (slots > 0) {
-        hipLaunchKernelGGL(k_fill, dim3((slots + 255) / 256), dim3(256), 0, stream, ev, cnt, tmp);
-        hipLaunchKernelGGL(k_rank_emit, dim3((slots + 255) / 256), dim3(256), 0, stream, ev, ptr,
-                           tmp, other, perm, deg_ptr ? deg_ptr : ptr, w, key_row);
-    }
-    return check_launch("dc_csr_build");
+    Side &f = b.s[0], &t = b.s[1];
+    f.key = edge_index + E, f.oth = edge_index;          // by destination
+    t.key = edge_index, t.oth = edge_index + E;          // by source
+    ws = carve_side(f, ws, E, N);
+    carve_side(t, ws, E, N);
+    f.ptr = ptr_f, f.other = other_f, f.perm = perm_f, f.w = w_f, f.deg_ptr = ptr_f, f.key_is_dst = 1;
+    t.ptr = ptr_b, t.other = other_b, t.perm = perm_b, t.w = w_b, t.deg_ptr = ptr_f, t.key_is_dst = 0;
+    return run_build(b, 2, stream, "dc_graph_build");
 }
 
 extern "C" int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last, int32_t *pos_of,
@@ -243,4 +455,16 @@ extern "C" int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last, int3
     hipLaunchKernelGGL(k_invert_perm, dim3((max_edges + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, perm, ptr_last, pos_of, max_edges);
     return check_launch("dc_invert_perm");
+}
+
+extern "C" int dc_hash_i64(const int64_t *v, int64_t n, uint64_t *out, dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(n >= 0 && out, "dc_hash_i64: negative size or null out");
+    hipMemsetAsync(out, 0, sizeof(uint64_t), stream);
+    if (n == 0) return check_launch("dc_hash_i64");
+    DC_REQUIRE(v, "dc_hash_i64: null input");
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_hash_i64, dim3(grid), dim3(256), 0, stream, v, n,
+                       (unsigned long long *)out);
+    return check_launch("dc_hash_i64");
 }

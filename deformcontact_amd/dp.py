@@ -35,7 +35,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
 
 
 class GradBucket:
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
+    """``direct=True`` opts the parameters into direct gradient writes by the library's dW
+    kernels (``ops.DIRECT_PARAM_GRAD``): those kernels then accumulate into this bucket's views
+    on whatever stream the backward node runs on, and report each write here; the bucket's
+    consumers wait for those streams before they read the flat buffer."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, direct: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradBucket: no trainable parameters")
@@ -52,6 +57,36 @@ class GradBucket:
             p.grad = v
             self._views.append(v)
             off += p.numel()
+        self.direct = bool(direct)
+        self._view_of = {id(p): v for p, v in zip(self.params, self._views)}
+        self._pending = []          # (event, recorded under stream capture?) of direct writes
+        if self.direct:
+            import weakref
+            ref = weakref.ref(self)
+            for p in self.params:
+                p._dc_grad_sink = ref
+
+    def owns(self, p, g) -> bool:
+        return self._view_of.get(id(p)) is g
+
+    def note_direct_write(self, stream) -> None:
+        """A library kernel on ``stream`` has just accumulated into this bucket."""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._pending.append((ev, torch.cuda.is_current_stream_capturing()))
+
+    def wait_direct_writes(self) -> None:
+        """Order every reported direct write before later work on the current stream.  Events
+        recorded under a stream capture that has ended are dropped: ending the capture already
+        required their streams to be joined."""
+        if not self._pending:
+            return
+        pending, self._pending = self._pending, []
+        capturing = torch.cuda.is_current_stream_capturing()
+        cur = torch.cuda.current_stream(self.flat.device)
+        for ev, cap in pending:
+            if cap == capturing:
+                cur.wait_event(ev)
 
     def zero(self) -> None:
         """Zero all gradients in one memset and re-attach the views if something replaced them."""
@@ -69,6 +104,7 @@ class GradBucket:
 
     def all_reduce_mean(self) -> None:
         """Average gradients over ranks: one collective on the flat bucket."""
+        self.wait_direct_writes()
         self._repack()
         ws = world_size(self.group)
         if ws == 1:
@@ -116,6 +152,7 @@ class FlatAdam:
     def step(self) -> None:
         from .graph import current_stream_ptr
         b = self.bucket
+        b.wait_direct_writes()
         rc = self._lib.lib().dc_adam_flat(
             self.flat_param.data_ptr(), b.flat.data_ptr(), self.exp_avg.data_ptr(),
             self.exp_avg_sq.data_ptr(), b.numel, self.step_count.data_ptr(), self.lr,

@@ -23,7 +23,14 @@ from typing import Optional
 
 import torch
 
+import os
+
 from . import _lib
+
+#: ``DC_VALIDATE=1``: every new ``GraphIndex`` checks its node ids on the host (one device sync per
+#: new ``edge_index``) and raises ``IndexError`` as PyG / ATen would; off by default because the
+#: check would serialise the training stream (out-of-range edges are skipped and flagged either way).
+VALIDATE = os.environ.get("DC_VALIDATE", "0") == "1"
 
 
 def _require_cuda(t: torch.Tensor, what: str) -> None:
@@ -35,6 +42,13 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
 
 def current_stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def capture_id(device) -> int:
+    """Sequence id of the hipGraph capture the current stream takes part in (0 = not capturing)."""
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    return int(_lib.lib().dc_stream_capture_id(current_stream_ptr(device)))
 
 
 @dataclass
@@ -59,15 +73,49 @@ class GraphIndex:
         self.self_loops = bool(self_loops)
         self.normalize = bool(normalize)
         self.device = edge_index.device
+        #: set by callers that guarantee the topology is constant for the life of a captured graph
+        #: (bench.py's cached-topology mode): lets ``graph_index`` reuse this entry under capture
+        self._static_ok = False
+        self._capture_id = capture_id(self.device)
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.fwd = self._build(key_row=1, deg_ptr=None)
-        self.bwd = self._build(key_row=0, deg_ptr=self.fwd.ptr)
+        dev, n, cap = self.device, self.num_nodes, max(self.capacity, 1)
+
+        def side():
+            return SortedAdjacency(
+                torch.empty(n + 1, dtype=torch.int32, device=dev),
+                torch.empty(cap, dtype=torch.int32, device=dev),
+                torch.empty(cap, dtype=torch.int32, device=dev),
+                torch.empty(cap, dtype=torch.float32, device=dev) if self.normalize else None)
+
+        self.fwd, self.bwd = side(), side()
+        nbytes = _lib.lib().dc_graph_workspace_bytes(self.num_input_edges, n)
+        self._workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         self._pos_fwd = None
         self._segments = False          # not computed yet
         self._bwd_to_fwd = None
         self._num_edges = None if self_loops else self.num_input_edges
-        if validate:
+        self.rebuild()
+        if validate or VALIDATE:
             self.validate()
+
+    def rebuild(self) -> None:
+        """(Re)run the build pipeline (``dc_graph_build``: both sides, 5-7 launches, no host sync)
+        on the current stream into this object's buffers - e.g. after the ``edge_index`` buffer
+        has been refilled with a new batch of the same shape.  Legal under hipGraph capture."""
+        f, t = self.fwd, self.bwd
+        rc = _lib.lib().dc_graph_build(
+            self.edge_index.data_ptr(), self.num_input_edges, self.num_nodes, int(self.self_loops),
+            f.ptr.data_ptr(), f.other.data_ptr(), f.perm.data_ptr(),
+            f.w.data_ptr() if f.w is not None else None,
+            t.ptr.data_ptr(), t.other.data_ptr(), t.perm.data_ptr(),
+            t.w.data_ptr() if t.w is not None else None,
+            self._status.data_ptr(), self._workspace.data_ptr(), self._workspace.numel(),
+            current_stream_ptr(self.device))
+        _lib.check(rc, "dc_graph_build")
+        self._pos_fwd = self._bwd_to_fwd = None
+        self._segments = False
+        if self.self_loops:
+            self._num_edges = None
 
     # capacity of the per-edge arrays (upper bound on E' when loops are appended)
     @property
@@ -88,24 +136,19 @@ class GraphIndex:
                 f"edge_index contains node ids outside [0, {self.num_nodes}) "
                 "(PyG/ATen would raise an index error here)")
 
-    def _build(self, key_row: int, deg_ptr) -> SortedAdjacency:
-        L = _lib.lib()
-        dev, n, e = self.device, self.num_nodes, self.num_input_edges
-        cap = max(self.capacity, 1)
-        ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        other = torch.empty(cap, dtype=torch.int32, device=dev)
-        perm = torch.empty(cap, dtype=torch.int32, device=dev)
-        w = torch.empty(cap, dtype=torch.float32, device=dev) if self.normalize else None
-        ws_bytes = L.dc_csr_workspace_bytes(e, n)
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-        rc = L.dc_csr_build(self.edge_index.data_ptr(), e, n, key_row, int(self.self_loops),
-                            ptr.data_ptr(), other.data_ptr(), perm.data_ptr(),
-                            deg_ptr.data_ptr() if deg_ptr is not None else None,
-                            w.data_ptr() if w is not None else None,
-                            self._status.data_ptr(), ws.data_ptr(), ws.numel(),
-                            current_stream_ptr(dev))
-        _lib.check(rc, "dc_csr_build")
-        return SortedAdjacency(ptr, other, perm, w)
+    def tensors(self):
+        """Every device buffer this object owns (for ``record_stream`` when it is built on one
+        stream and consumed on another)."""
+        out = [self._status, self._workspace]
+        for adj in (self.fwd, self.bwd):
+            out += [t for t in (adj.ptr, adj.other, adj.perm, adj.w) if t is not None]
+        for entry in getattr(self, "_hop_cache", {}).values():
+            out += [t for t in entry[:2] if t is not None]
+        return out
+
+    def record_stream(self, stream) -> None:
+        for t in self.tensors():
+            t.record_stream(stream)
 
     def segments(self):
         """Node ranges no edge leaves (one or more whole meshes of the batch each), merged greedily
@@ -176,13 +219,28 @@ _CACHE: "OrderedDict[tuple, GraphIndex]" = OrderedDict()
 _CACHE_MAX = 32
 
 
+def _key(edge_index, num_nodes, self_loops, normalize):
+    return (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
+            tuple(edge_index.stride()), int(num_nodes), bool(self_loops), bool(normalize),
+            edge_index.device.index)
+
+
 def graph_index(edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = False,
                 normalize: bool = True) -> GraphIndex:
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
-           tuple(edge_index.stride()), int(num_nodes), bool(self_loops), bool(normalize),
-           edge_index.device.index)
+    """The sorted adjacency of ``edge_index``, built on first use and cached on the tensor's
+    address + version + shape.
+
+    The key cannot see writes that bypass PyTorch's version counter (raw kernels, hipGraph replay
+    into a static buffer), so an entry is only reused by the stream capture that built it (or, for
+    eagerly built entries, outside any capture): a captured step always contains the build of the
+    ``edge_index`` buffers it reads, and replays it on whatever those buffers then hold.  Callers
+    that guarantee a constant topology for the life of a captured graph may set
+    ``GraphIndex._static_ok`` on an eagerly built entry to keep the build out of the capture.
+    """
+    key = _key(edge_index, num_nodes, self_loops, normalize)
     g = _CACHE.get(key)
-    if g is not None:
+    cid = capture_id(edge_index.device) if edge_index.is_cuda else 0
+    if g is not None and (g._capture_id == cid or (cid != 0 and g._static_ok)):
         _CACHE.move_to_end(key)
         return g
     g = GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize)
@@ -191,6 +249,29 @@ def graph_index(edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = 
     while len(_CACHE) > _CACHE_MAX:
         _CACHE.popitem(last=False)
     return g
+
+
+def content_hash(t: torch.Tensor) -> int:
+    """64-bit content hash of an int64 device tensor (``dc_hash_i64``; synchronises on the
+    current stream): the key of ``loaders.TopologyCache``."""
+    _require_cuda(t, "tensor")
+    if t.dtype != torch.int64:
+        raise ValueError("content_hash: int64 tensor expected")
+    t = t.contiguous()
+    out = torch.empty(1, dtype=torch.int64, device=t.device)
+    rc = _lib.lib().dc_hash_i64(t.data_ptr(), t.numel(), out.data_ptr(), current_stream_ptr(t.device))
+    _lib.check(rc, "dc_hash_i64")
+    return int(out.item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def register(edge_index: torch.Tensor, g: GraphIndex) -> None:
+    """Make ``g`` (built elsewhere, e.g. by ``loaders.TopologyCache`` on the loader's stream) the
+    cached adjacency of ``edge_index``."""
+    g._src_ref = edge_index
+    g._capture_id = 0
+    _CACHE[_key(edge_index, g.num_nodes, g.self_loops, g.normalize)] = g
+    while len(_CACHE) > _CACHE_MAX:
+        _CACHE.popitem(last=False)
 
 
 def clear_cache() -> None:

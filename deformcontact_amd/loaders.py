@@ -71,6 +71,69 @@ def to_batches(collated, device=None) -> Tuple[Batch, Batch, Batch]:
     return out
 
 
+class TopologyCache:
+    """Per-topology cache of sorted adjacencies.
+
+    The reference keeps one rest mesh per object (``loaders/everyday_deform.py:29-30``), so the
+    same ``edge_index`` CONTENT comes back in fresh tensors batch after batch.  ``get`` hashes the
+    tensor's content on the device (``dc_hash_i64``, one small kernel + an 8-byte read-back on the
+    CURRENT stream - meant for the loader's side stream, not the training stream), returns the
+    ``GraphIndex`` built for an earlier tensor with the same (content hash, shape, N, flags) or
+    builds one, and registers it as the adjacency of THIS tensor so that the conv layers
+    (``graph.graph_index``, keyed on the tensor's address) find it.  64-bit hash: a collision
+    between two different topologies of identical shape is possible in principle (2^-64 per pair).
+    """
+
+    def __init__(self, max_entries: int = 64):
+        from collections import OrderedDict
+        self._d = OrderedDict()
+        self.max_entries = max_entries
+        self.hits = self.misses = 0
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = False,
+            normalize: bool = True):
+        from . import graph
+        key = (graph.content_hash(edge_index), tuple(edge_index.shape), int(num_nodes),
+               bool(self_loops), bool(normalize), edge_index.device.index)
+        g = self._d.get(key)
+        if g is None:
+            self.misses += 1
+            g = graph.GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize)
+            self._d[key] = g
+            while len(self._d) > self.max_entries:
+                self._d.popitem(last=False)
+        else:
+            self.hits += 1
+            self._d.move_to_end(key)
+        graph.register(edge_index, g)
+        return g
+
+
+def prepare_for(model, cache: "TopologyCache | None" = None):
+    """``prepare`` callback for ``PrefetchLoader``: for the freshly uploaded ``(rest, deff, rig)``
+    batches build (or fetch from ``cache``) the sorted adjacency each branch's first conv layer
+    will ask for and, for TAGConv, the hop slab of its no-grad input (``ops.precompute_input_hops``)
+    - on the loader's stream, while the previous batch trains."""
+    from . import ops
+
+    def prepare(batches):
+        rest, _, rig = batches
+        built = []
+        for convs, b in ((getattr(model, "conv_layers_resting", []), rest),
+                         (getattr(model, "conv_layers_rigid", []), rig)):
+            if not len(convs) or not hasattr(convs[0], "graph_flags"):
+                continue
+            conv, n = convs[0], b.x.size(0)
+            g = cache.get(b.edge_index, n, **conv.graph_flags()) if cache is not None \
+                else conv.graph(b.edge_index, n)
+            if hasattr(conv, "K") and getattr(conv, "supports_fused_relu", False):
+                ops.precompute_input_hops(g, b.x, conv.K)
+            built.append(g)
+        return built
+
+    return prepare
+
+
 class PrefetchLoader:
     """Background batch assembly + overlapped upload.
 
@@ -84,9 +147,13 @@ class PrefetchLoader:
     """
 
     def __init__(self, dataset, batch_size: int, device=None, shuffle: bool = False, seed: int = 0,
-                 drop_last: bool = False, depth: int = 2):
+                 drop_last: bool = False, depth: int = 2, prepare=None):
         self.dataset, self.batch_size, self.device = dataset, batch_size, device
         self.shuffle, self.seed, self.drop_last, self.depth = shuffle, seed, drop_last, max(1, depth)
+        #: optional ``prepare((rest, deff, rig)) -> [GraphIndex]`` run on the upload stream right
+        #: after the copies (``prepare_for(model, TopologyCache())``): the per-batch topology work
+        #: (sorted adjacency, gcn_norm, first-layer hop slabs) leaves the training stream
+        self.prepare = prepare
 
     def _produce(self, q):
         try:
@@ -122,9 +189,10 @@ class PrefetchLoader:
                 return collated, tuple(b.to(self.device) for b in host), None
             with torch.cuda.stream(side):
                 dev = tuple(b.to(self.device, non_blocking=True) for b in host)
+                built = self.prepare(dev) if self.prepare is not None else []
                 ev = torch.cuda.Event()
                 ev.record(side)
-            return collated, dev, ev
+            return collated, dev, (ev, built)
 
         def get():
             item = q.get()
@@ -139,7 +207,10 @@ class PrefetchLoader:
             nxt = get()
             pending = upload(nxt) if nxt is not None else None      # next upload overlaps this step
             if ev is not None:
+                ev, built = ev
                 torch.cuda.current_stream(self.device).wait_event(ev)
+                for g in built or []:
+                    g.record_stream(torch.cuda.current_stream(self.device))
                 for b in dev:
                     for k in ("x", "pos", "edge_index", "batch", "ptr"):
                         t = getattr(b, k, None)

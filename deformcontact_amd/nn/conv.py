@@ -78,8 +78,11 @@ class TAGConv(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
+    def graph_flags(self) -> dict:
+        return dict(self_loops=False, normalize=self.normalize)
+
     def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
-        return graph_index(edge_index, num_nodes, self_loops=False, normalize=self.normalize)
+        return graph_index(edge_index, num_nodes, **self.graph_flags())
 
     supports_fused_relu = True
 
@@ -119,8 +122,11 @@ class GCNConv(nn.Module):
         if self.bias is not None:
             nn.init.zeros_(self.bias)
 
+    def graph_flags(self) -> dict:
+        return dict(self_loops=True, normalize=True)
+
     def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
-        return graph_index(edge_index, num_nodes, self_loops=True, normalize=True)
+        return graph_index(edge_index, num_nodes, **self.graph_flags())
 
     def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
         _check_inputs(x, edge_index, self.in_channels)
@@ -157,8 +163,11 @@ class GATConv(nn.Module):
             if self.bias is not None:
                 self.bias.zero_()
 
+    def graph_flags(self) -> dict:
+        return dict(self_loops=True, normalize=False)
+
     def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
-        return graph_index(edge_index, num_nodes, self_loops=True, normalize=False)
+        return graph_index(edge_index, num_nodes, **self.graph_flags())
 
     def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
         _check_inputs(x, edge_index, self.in_channels)

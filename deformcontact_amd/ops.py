@@ -159,11 +159,15 @@ def _i64_array(vals):
 
 MAX_SEG = 4   # DC_MAX_SEG in include/deformcontact.h
 
-#: Accumulate weight / bias gradients straight into ``param.grad`` inside the dW slab-reduce
-#: kernel when every parameter of the layer already has a dense fp32 ``.grad`` (e.g. the views of
-#: ``dp.GradBucket``), instead of returning them to autograd (which would run one elementwise
-#: ``add`` kernel per parameter).  Tensor hooks on those parameters do not fire in that mode;
-#: set to False to get stock autograd behaviour.
+#: Direct parameter-gradient mode (opt-in, ``dp.GradBucket(params, direct=True)``): the dW
+#: slab-reduce kernel accumulates weight / bias gradients straight into the bucket's views instead
+#: of returning them to autograd (which would run one elementwise ``add`` kernel per parameter).
+#: Only parameters the bucket has marked are written that way (``requires_grad`` ones whose
+#: ``.grad`` still is the bucket's view); every such write is reported to the bucket
+#: (``GradBucket.note_direct_write``), which makes its consumers (``all_reduce_mean``,
+#: ``FlatAdam.step``) wait for the writing stream.  Tensor hooks on those parameters do not fire
+#: and ``torch.autograd.grad`` gets ``None`` for them - hence opt-in.  Setting this to False
+#: disables the mode globally.
 DIRECT_PARAM_GRAD = True
 
 
@@ -226,10 +230,89 @@ def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bo
                 rowmax_mode=1 if (j == 0 and not rowmax_has_block0) else 2)
 
 
-def _grad_sink(p) -> bool:
-    g = getattr(p, "grad", None)
-    return (g is not None and g.dtype == torch.float32 and g.is_contiguous()
-            and g.device == p.device and g.shape == p.shape)
+#: Cache the hop slab ``[x | A x | ... | A^K x]`` (+ row maxima) of TAGConv layers whose input
+#: needs no gradient - the FIRST layer of each branch (``models/model.py:71,77`` with the raw
+#: ``graph.x``): it is a parameter-free function of (x, edge_index), so it is computed once per
+#: batch (by the first forward, or ahead of time by ``precompute_input_hops`` on the loader's
+#: stream) instead of once per step.  Keyed on the input tensor's address + version and stored on
+#: the ``GraphIndex`` (i.e. dropped with the topology); under stream capture the same rule as for
+#: the adjacency applies (``graph.graph_index``).  ``DC_HOP_CACHE=0`` disables.
+HOP_CACHE = os.environ.get("DC_HOP_CACHE", "1") != "0"
+_HOP_CACHE_ENTRIES = 2
+
+
+def _hop_cache_key(x: torch.Tensor, k: int, wpad: int, want_rowmax: bool):
+    return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), int(k), int(wpad),
+            bool(want_rowmax))
+
+
+def _hop_cache_get(g, key, dev):
+    cache = getattr(g, "_hop_cache", None)
+    if not cache or key not in cache:
+        return None
+    from .graph import capture_id
+    cid = capture_id(dev)
+    slab, rowmax, ecid, _ref = cache[key]
+    if ecid == cid or (cid != 0 and g._static_ok):
+        return slab, rowmax
+    return None
+
+
+def _hop_cache_put(g, key, x, slab, rowmax, dev):
+    from .graph import capture_id
+    cache = g.__dict__.setdefault("_hop_cache", {})
+    while len(cache) >= _HOP_CACHE_ENTRIES:
+        cache.pop(next(iter(cache)))
+    cache[key] = (slab, rowmax, capture_id(dev), x)      # x kept alive: its address is the key
+
+
+def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool):
+    """Pack ``x`` into block 0 of a fresh ``[N, wpad]`` slab and run the K hops (+ row maxima)."""
+    n, fi = x.shape
+    concat, width, wpad = tag_slab_geometry(fi, k)
+    dev = x.device
+    slab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
+    xin = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
+    _lib.check(_lib.lib().dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), wpad, n,
+                                            fi, width, wpad, current_stream_ptr(dev)),
+               "dc_tag_pack_input")
+    rowmax = torch.empty(n, dtype=torch.float32, device=dev) if want_rowmax else None
+    chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax)
+    return slab, rowmax
+
+
+def _tag_uses_h2(fi: int, k: int) -> bool:
+    concat, _, wpad = tag_slab_geometry(fi, k)
+    return (DENSE_F16X2 and DENSE_SPLIT_BF16 and DENSE_PRODUCTS == 6 and not concat and k >= 1
+            and fi % 16 == 0 and wpad % 4 == 0)
+
+
+def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3) -> None:
+    """Compute and cache, on the current stream, the hop slab a ``TAGConv(in, out, K=k)`` layer
+    will need for the no-grad input ``x`` over topology ``g`` (what ``loaders.PrefetchLoader`` does
+    for the next batch while the current one trains)."""
+    _require_cuda(x, "x")
+    if not HOP_CACHE or k < 1 or x.dtype != torch.float32 or x.dim() != 2:
+        return
+    fi = x.size(1)
+    want = _tag_uses_h2(fi, k)
+    key = _hop_cache_key(x, k, tag_slab_geometry(fi, k)[2], want)
+    if _hop_cache_get(g, key, x.device) is None:
+        slab, rowmax = _build_input_slab(g, x, k, want)
+        _hop_cache_put(g, key, x, slab, rowmax, x.device)
+
+
+def _grad_sink(p):
+    """The ``dp.GradBucket`` that owns ``p.grad`` in direct mode, or None."""
+    ref = getattr(p, "_dc_grad_sink", None)
+    bucket = ref() if ref is not None else None
+    if bucket is None or not p.requires_grad:
+        return None
+    g = p.grad
+    if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device
+            or g.shape != p.shape or not bucket.owns(p, g)):
+        return None
+    return bucket
 
 
 def tag_slab_geometry(fi: int, k: int):
@@ -240,11 +323,17 @@ def tag_slab_geometry(fi: int, k: int):
     return concat, width, wpad
 
 
+_SLAB_TAG = "_dc_hop_slab"
+
+
 def _as_slab_block0(x: torch.Tensor, n: int, fi: int, wpad: int):
-    """If ``x`` already is column block 0 of a ``[n, wpad]`` buffer (the previous layer wrote
-    its output there), return that buffer; else None."""
+    """If ``x`` is column block 0 of a ``[n, wpad]`` hop slab THIS LIBRARY allocated for it (the
+    previous layer's forward wrote its output there and tagged the buffer), return that buffer;
+    else None.  Shape and stride alone are not enough: a caller's own ``feat[:, :fi]`` view of a
+    wider tensor looks the same, and the hops would overwrite its other columns."""
     base = x._base
-    if (base is not None and base.dim() == 2 and tuple(base.shape) == (n, wpad)
+    if (base is not None and getattr(base, _SLAB_TAG, None) == (n, fi, wpad)
+            and base.dim() == 2 and tuple(base.shape) == (n, wpad)
             and base.is_contiguous() and x.stride() == (wpad, 1) and x.shape == (n, fi)
             and x.data_ptr() == base.data_ptr() and base.dtype == torch.float32):
         return base
@@ -278,16 +367,24 @@ class _TagConvFn(torch.autograd.Function):
             slab = x                                 # no hops: the input itself is the (1-block) slab
         L = _lib.lib()
         st = current_stream_ptr(dev)
+        h2 = _tag_uses_h2(fi, k)
+        rowmax = None
         if slab is None:
-            slab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
-            xin = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
-            _lib.check(L.dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), wpad, n,
-                                           fi, width, wpad, st), "dc_tag_pack_input")
+            # the layer's own input: pack + K hops, or the cached slab when x needs no gradient
+            key = None
+            if HOP_CACHE and g is not None and k >= 1 and not ctx.needs_input_grad[1]:
+                key = _hop_cache_key(x, k, wpad, h2)
+                hit = _hop_cache_get(g, key, dev)
+                if hit is not None:
+                    slab, rowmax = hit
+            if slab is None:
+                slab, rowmax = _build_input_slab(g, x, k, h2)
+                if key is not None:
+                    _hop_cache_put(g, key, x, slab, rowmax, dev)
+        else:
+            rowmax = torch.empty(n, dtype=torch.float32, device=dev) if h2 else None
+            chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax)
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-        h2 = (DENSE_F16X2 and DENSE_SPLIT_BF16 and DENSE_PRODUCTS == 6 and not concat and k >= 1
-              and fi % 16 == 0 and wpad % 4 == 0)
-        rowmax = torch.empty(n, dtype=torch.float32, device=dev) if h2 else None
-        chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax)
         if concat:
             wc = [w.contiguous() for w in weights]
             wcat = torch.empty((fo, wpad), dtype=torch.float32, device=dev)
@@ -302,6 +399,7 @@ class _TagConvFn(torch.autograd.Function):
             # the output IS column block 0 of the next TAGConv layer's hop slab (no copy there)
             next_width, next_wpad = next_geom
             nxt = torch.empty((n, next_wpad), dtype=torch.float32, device=dev)
+            setattr(nxt, _SLAB_TAG, (n, fo, next_wpad))      # recognised by _as_slab_block0
             if next_wpad > next_width:
                 nxt[:, next_width:].zero_()          # K padding of a narrow next layer
             out = nxt[:, :fo]
@@ -402,9 +500,11 @@ class _TagConvFn(torch.autograd.Function):
 
         if need_w or need_b:
             # one output block per lins[k].weight, in either layout of the dense block
+            sinks = [_grad_sink(p) for p in ctx.params] + \
+                ([_grad_sink(ctx.bias_param)] if ctx.has_bias else [])
             direct = (DIRECT_PARAM_GRAD and not torch.is_grad_enabled()
-                      and all(_grad_sink(p) for p in ctx.params)
-                      and (not ctx.has_bias or _grad_sink(ctx.bias_param)))
+                      and all(ctx.needs_input_grad[5:]) and (need_b or not ctx.has_bias)
+                      and sinks[0] is not None and all(b is sinks[0] for b in sinks))
             if direct:
                 outs = [p.grad for p in ctx.params]
                 gb_out = ctx.bias_param.grad if ctx.has_bias else None
@@ -423,7 +523,9 @@ class _TagConvFn(torch.autograd.Function):
             else:
                 rc = L.dc_tag_linear_bwd_dw(*args, st)
             _lib.check(rc, "dc_tag_linear_bwd_dw")
-            if not direct:
+            if direct:
+                sinks[0].note_direct_write(torch.cuda.current_stream(dev))
+            else:
                 gws = [outs[j] if ctx.needs_input_grad[5 + j] else None for j in range(k + 1)]
                 gb = gb_out
 

@@ -37,7 +37,9 @@ def losses(model, rest, deff, rig, lambda_gradient: float = 1.0) -> Dict[str, to
 def train_step(model, optimizer, rest, deff, rig, lambda_gradient: float = 1.0,
                bucket: Optional[dp.GradBucket] = None) -> Dict[str, torch.Tensor]:
     out = losses(model, rest, deff, rig, lambda_gradient)
-    if bucket is not None:
+    if getattr(optimizer, "zero_grad_in_step", False):
+        pass                                   # FlatAdam cleared the gradients it consumed
+    elif bucket is not None:
         bucket.zero()
     else:
         optimizer.zero_grad(set_to_none=True)
@@ -48,32 +50,120 @@ def train_step(model, optimizer, rest, deff, rig, lambda_gradient: float = 1.0,
     return {k: v.detach() for k, v in out.items()}
 
 
+_BATCH_TENSORS = ("x", "pos", "edge_index", "batch", "ptr")
+
+
+class GraphedTrainStep:
+    """The reference's whole train step (``train.py:46-58,71-73``: forward, both losses, backward,
+    Adam) as ONE hipGraph over static input buffers.  Every call copies the new batches into the
+    buffers and replays; the graph CONTAINS the per-batch topology work (sorted adjacency +
+    gcn_norm build, first-layer hops), so any batch of the captured shape is handled correctly.
+    The first ``eager_steps`` calls (and any call whose shapes differ from the captured ones) run
+    eagerly - they are real training steps, nothing is replayed twice.  With ``world_size > 1``
+    the gradient all-reduce and Adam stay outside the graph.  Returned loss tensors are the
+    graph's static outputs: read them before the next call."""
+
+    def __init__(self, model, optimizer: "dp.FlatAdam", bucket: dp.GradBucket,
+                 lambda_gradient: float = 1.0, eager_steps: int = 2):
+        self.model, self.opt, self.bucket, self.lam = model, optimizer, bucket, float(lambda_gradient)
+        self.eager_steps, self._seen = int(eager_steps), 0
+        self._sig = self._graph = self._static = self._out = None
+        self._tail_in_graph = dp.world_size() == 1
+        self.replays = 0
+
+    @staticmethod
+    def _signature(batches):
+        return tuple((k, tuple(getattr(b, k).shape)) for b in batches for k in _BATCH_TENSORS
+                     if isinstance(getattr(b, k, None), torch.Tensor))
+
+    def _fwd_bwd(self, rest, deff, rig):
+        out = losses(self.model, rest, deff, rig, self.lam)
+        out["loss"].backward()
+        return {k: v.detach() for k, v in out.items()}
+
+    def _tail(self):
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+
+    def __call__(self, rest, deff, rig) -> Dict[str, torch.Tensor]:
+        sig = self._signature((rest, deff, rig))
+        if sig != self._sig:
+            self._sig, self._seen, self._graph = sig, 0, None
+        if self._graph is None and self._seen < self.eager_steps:
+            self._seen += 1
+            out = self._fwd_bwd(rest, deff, rig)
+            self._tail()
+            return out
+        if self._graph is None:
+            self._static = tuple(b.clone() for b in (rest, deff, rig))
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._out = self._fwd_bwd(*self._static)
+                if self._tail_in_graph:
+                    self._tail()
+            self._graph = graph
+        for dst, src in zip(self._static, (rest, deff, rig)):
+            for k in _BATCH_TENSORS:
+                t = getattr(dst, k, None)
+                if isinstance(t, torch.Tensor):
+                    t.copy_(getattr(src, k), non_blocking=True)
+        self._graph.replay()
+        self.replays += 1
+        if not self._tail_in_graph:
+            self._tail()
+        return self._out
+
+
 def train(network_cfg=None, *, device="cuda", epochs: int = 2, num_train: int = 64, num_val: int = 16,
           batch_size: int = 4, lr: float = 4e-4, lambda_gradient: float = 1.0, out_dir: str = "runs/dc",
           soft_vertices: int = 1024, sphere_resolution: int = 20, log_every: int = 1, seed: int = 0,
-          conv_module=None):
-    """Synthetic-data counterpart of ``train.py:15-135`` (best-val checkpoint + config dump)."""
+          conv_module=None, capture: bool = True, stats: Optional[dict] = None):
+    """Synthetic-data counterpart of ``train.py:15-135`` (best-val checkpoint + config dump).
+
+    On a HIP device with the library's conv layers: Adam is ``dp.FlatAdam`` (one kernel over the
+    flat bucket, ``train.py:20`` defaults), gradients are accumulated straight into the bucket
+    (``GradBucket(direct=True)``), the loader prepares each batch's topology on its own stream
+    (``loaders.prepare_for`` + ``TopologyCache``) and, with ``capture``, steps of a repeating shape
+    are hipGraph replays (``GraphedTrainStep``).  ``stats`` (optional dict) receives step timings."""
     cfg = dict(EVERYDAY_NETWORK if network_cfg is None else network_cfg)
     torch.manual_seed(seed)
     model = load_model(cfg, conv_module=conv_module).to(device)
     dp.broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
-    bucket = dp.GradBucket(model.parameters()) if dp.world_size() > 1 else None
+    on_gpu = torch.device(device).type == "cuda" and conv_module is None
+    if on_gpu:
+        bucket = dp.GradBucket(model.parameters(), direct=True)
+        opt = dp.FlatAdam(bucket, lr=lr, zero_grad_in_step=True)
+        bucket.zero()
+        graphed = GraphedTrainStep(model, opt, bucket, lambda_gradient) if capture else None
+    else:                                       # CPU oracle convs (tests): stock optimizer
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        bucket = dp.GradBucket(model.parameters()) if dp.world_size() > 1 else None
+        graphed = None
     rank = torch.distributed.get_rank() if dp.world_size() > 1 else 0
     train_ds = SyntheticEverydayDataset(num_train, rank * num_train, soft_vertices, sphere_resolution)
     val_ds = SyntheticEverydayDataset(num_val, 10_000_000, soft_vertices, sphere_resolution)
     os.makedirs(out_dir, exist_ok=True)
     log = open(os.path.join(out_dir, f"log_rank{rank}.jsonl"), "a")
     best, step = float("inf"), 0
+    # with capture the graph holds the topology work; otherwise the loader prepares it off-stream
+    from .loaders import TopologyCache, prepare_for
+    prepare = prepare_for(model, TopologyCache()) if (on_gpu and graphed is None) else None
+    t_steps = []
     for epoch in range(epochs):
         model.train()
         # worker thread assembles + pins the next batches, uploads overlap the current step
         for collated, (rest, deff, rig) in PrefetchLoader(train_ds, batch_size, device, shuffle=True,
-                                                          seed=seed + epoch):
-            out = train_step(model, opt, rest, deff, rig, lambda_gradient, bucket)
+                                                          seed=seed + epoch, prepare=prepare):
+            t0 = time.perf_counter()
+            if graphed is not None:
+                out = graphed(rest, deff, rig)
+            else:
+                out = train_step(model, opt, rest, deff, rig, lambda_gradient, bucket)
             if step % log_every == 0:
                 log.write(json.dumps({"step": step, "epoch": epoch, "t": time.time(),
                                       **{k: float(v) for k, v in out.items()}}) + "\n")
+            t_steps.append(time.perf_counter() - t0)
             step += 1
         model.eval()
         tot, nb = 0.0, 0
@@ -93,6 +183,9 @@ def train(network_cfg=None, *, device="cuda", epochs: int = 2, num_train: int = 
                 json.dump({"network": cfg, "training": {"learning_rate": lr,
                                                         "lambda_gradient": lambda_gradient}}, f, indent=4)
     log.close()
+    if stats is not None:
+        stats.update(steps=step, step_seconds=t_steps,
+                     graph_replays=graphed.replays if graphed is not None else 0)
     return model, best
 
 

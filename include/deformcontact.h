@@ -39,6 +39,10 @@ typedef void *dc_stream_t; /* hipStream_t */
 
 int dc_version(void);
 const char *dc_last_error(void);
+/* Sequence id of the hipGraph capture `stream` currently takes part in, 0 when it is not
+ * capturing.  The host's adjacency cache uses it: a sorted adjacency is only reused by the
+ * capture that enqueued its build (the build has not RUN while a capture is open). */
+int64_t dc_stream_capture_id(dc_stream_t stream);
 
 /* ---- topology: edge_index -> sorted adjacency ("CSR") ---------------------
  * Replaces the implicit ordering of PyG's scatter_add_ (utils/_scatter.py) and,
@@ -65,16 +69,35 @@ const char *dc_last_error(void);
  *                differences give that in-degree: NULL = this call's own `ptr`
  *                (valid for key_row = 1), else the key_row=1 ptr of the same
  *                edge set.
- *   status[1]    device int32, OR-ed with 1 if any endpoint is outside [0,N)
- *                (such edges are skipped).  Caller zeroes it and may read it
- *                back after synchronising.
+ *   status[1]    device int32, SET by the call: 1 if any endpoint is outside [0,N)
+ *                (such edges are skipped), else 0.  Read it back after synchronising.
  *   workspace    dc_csr_workspace_bytes(E, N) bytes, 16-byte aligned.
+ *
+ * Groups of any length are handled in O(S log^2 S) (hubs are sorted by one workgroup, short
+ * groups ranked by counting): no quadratic walk on high-degree nodes.
  */
 int64_t dc_csr_workspace_bytes(int64_t E, int64_t N);
 int dc_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int key_row,
                  int self_loops, int32_t *ptr, int32_t *other, int32_t *perm,
                  const int32_t *deg_ptr, float *w, int32_t *status, void *workspace,
                  int64_t workspace_bytes, dc_stream_t stream);
+
+/* Both sides of one edge set in ONE pipeline (5 launches for N <= 65,536, 7 beyond): the
+ * key_row = 1 set (`*_f`: by destination, the forward hop) and the key_row = 0 set (`*_b`: by
+ * source, the transposed hop of the backward pass), identical to two dc_csr_build calls with
+ * deg_ptr = ptr_f for the second.  w_f / w_b both NULL or both set.  This is what one
+ * `conv(x, edge_index)` of the reference needs per NEW edge_index (model.py:71,77); it is cheap
+ * enough (tens of microseconds at the batch-32 shape) to sit inside a captured training step. */
+int64_t dc_graph_workspace_bytes(int64_t E, int64_t N);
+int dc_graph_build(const int64_t *edge_index, int64_t E, int64_t N, int self_loops,
+                   int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
+                   int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
+                   int32_t *status, void *workspace, int64_t workspace_bytes, dc_stream_t stream);
+
+/* Order-dependent 64-bit content hash of an int64 device array (e.g. edge_index) into
+ * out[1] (device): the key of the host's per-topology cache (loaders.TopologyCache), so a batch
+ * whose edge_index has been seen before reuses its sorted adjacency. */
+int dc_hash_i64(const int64_t *v, int64_t n, uint64_t *out, dc_stream_t stream);
 
 /* ---- the hop: fused gather - scale - segment-sum --------------------------
  * Replaces MessagePassing.propagate for aggr="add" with message = w_e * x_j:

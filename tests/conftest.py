@@ -26,7 +26,9 @@ def golden_dir():
 
 def pytest_collection_modifyitems(config, items):
     import torch
-    if torch.cuda.is_available():
+    # device_count() does not initialise the HIP runtime in this process (is_available() does):
+    # tests/test_a_bench_launch.py starts child processes and must do so from a clean process
+    if torch.cuda.device_count() > 0:
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:

@@ -67,6 +67,119 @@ def test_csr_hub_node_long_segment():
     _check_csr(ei, n)
 
 
+@pytest.mark.parametrize("hub", [48, 49, 300, 4096, 4097, 9000, 70000])
+def test_csr_hub_lengths_around_every_threshold(hub):
+    """Groups up to 48 ids rank by counting, longer ones are sorted by one workgroup (LDS up to
+    4096 ids, in place beyond): lengths on both sides of each switch, as destination AND as
+    source hub, plus a second long group so several listed groups share the sorting blocks."""
+    n = 500
+    e = hub + 3000
+    ei = random_multigraph(n, e, 100 + hub % 97)
+    rng = np.random.default_rng(hub)
+    pos = rng.permutation(e)[:hub]
+    ei[1, pos] = 7                                        # hub as destination
+    ei[1, (ei[1] == 7) & ~np.isin(np.arange(e), pos)] = 8
+    pos2 = rng.permutation(e)[:hub]
+    ei[0, pos2] = 11                                      # hub as source
+    ei[0, (ei[0] == 11) & ~np.isin(np.arange(e), pos2)] = 12
+    ei[1, rng.permutation(e)[:77]] = 5                    # a second listed group
+    g = _check_csr(ei, n)
+    deg = np.bincount(ei[1], minlength=n)
+    assert deg[7] >= hub and _np(g.fwd.ptr)[8] - _np(g.fwd.ptr)[7] == deg[7]
+
+
+def test_csr_single_side_entry_equals_pair_build():
+    """dc_csr_build (one side per call, the round-1 entry point) against dc_graph_build."""
+    from deformcontact_amd import _lib
+    from deformcontact_amd.graph import current_stream_ptr
+    L = _lib.lib()
+    n, e = 700, 9000
+    ei_np = random_multigraph(n, e, 21)
+    ei_np[1, :200] = 3
+    ei = torch.from_numpy(ei_np).to(DEV)
+    g = GraphIndex(ei, n)
+    st = current_stream_ptr(torch.device(DEV))
+    status = torch.ones(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(L.dc_csr_workspace_bytes(e, n), dtype=torch.uint8, device=DEV)
+    outs = {}
+    for key_row, deg in ((1, None), (0, "f")):
+        ptr = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+        other, perm = (torch.empty(e, dtype=torch.int32, device=DEV) for _ in range(2))
+        w = torch.empty(e, dtype=torch.float32, device=DEV)
+        rc = L.dc_csr_build(ei.data_ptr(), e, n, key_row, 0, ptr.data_ptr(), other.data_ptr(),
+                            perm.data_ptr(), outs["f"][0].data_ptr() if deg else None, w.data_ptr(),
+                            status.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        assert rc == 0
+        outs["f" if key_row else "b"] = (ptr, other, perm, w)
+    assert int(status) == 0                                  # SET by the call
+    for name, adj in (("f", g.fwd), ("b", g.bwd)):
+        ptr, other, perm, w = outs[name]
+        assert torch.equal(ptr, adj.ptr) and torch.equal(other, adj.other)
+        assert torch.equal(perm, adj.perm) and torch.equal(w, adj.w)
+
+
+def test_graph_rebuild_in_place_and_inside_a_captured_graph():
+    """A captured step contains the build of the edge_index buffer it reads: refill the buffer,
+    replay, and the adjacency (and a hop through it) follow the new topology."""
+    from deformcontact_amd.graph import graph_index
+    n, e, f = 400, 3000, 32
+    eis = [random_multigraph(n, e, 31 + i) for i in range(3)]
+    buf = torch.from_numpy(eis[0]).to(DEV)
+    x = torch.from_numpy(hashed_uniform((n, f), 1, 1.0)).to(DEV)
+    clear_cache()
+    g_eager = graph_index(buf, n)
+    assert graph_index(buf, n) is g_eager                    # eager reuse
+    # in-place rebuild (eager)
+    buf.copy_(torch.from_numpy(eis[1]))
+    g_eager.rebuild()
+    ptr, other, perm = hop_c.csr_build(eis[1], n, 1)
+    assert np.array_equal(_np(g_eager.fwd.ptr), ptr) and np.array_equal(_np(g_eager.fwd.other), other)
+    # capture: the eagerly built entry must NOT be reused
+    y = torch.empty(n, f, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.hop(graph_index(buf, n).fwd, x, out=y)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_cap = graph_index(buf, n)
+        assert g_cap is not g_eager
+        assert graph_index(buf, n) is g_cap                  # reused inside the same capture
+        ops.hop(g_cap.fwd, x, out=y)
+    assert graph_index(buf, n) is not g_cap                  # and not outside it
+    for i in (2, 0, 1):
+        buf.copy_(torch.from_numpy(eis[i]))
+        graph.replay()
+        torch.cuda.synchronize()
+        w_edge = hop_c.gcn_norm(eis[i], n)
+        assert np.array_equal(_np(y), hop_c.hop(eis[i], w_edge, _np(x))), i
+    # opt-out for a topology the caller guarantees constant
+    g2 = graph_index(buf, n)
+    g2._static_ok = True
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        assert graph_index(buf, n) is g2
+        ops.hop(g2.fwd, x, out=y)
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(y), hop_c.hop(eis[1], hop_c.gcn_norm(eis[1], n), _np(x)))
+
+
+def test_content_hash_distinguishes_order_and_values():
+    from deformcontact_amd.graph import content_hash
+    a = torch.from_numpy(random_multigraph(300, 5000, 41)).to(DEV)
+    b = a.clone()
+    assert content_hash(a) == content_hash(b)
+    b[0, 17], b[0, 18] = a[0, 18].item(), a[0, 17].item()   # swap two entries
+    assert (a[0, 17] != a[0, 18]) and content_hash(a) != content_hash(b)
+    c = a.clone()
+    c[1, 4999] += 1
+    assert content_hash(a) != content_hash(c)
+    assert content_hash(a[:, :0].contiguous()) == 0
+
+
 def test_csr_self_loop_rewrite_matches_pyg_loop_utils():
     n = 50
     ei = random_multigraph(n, 400, 12, self_loops=True)
@@ -622,6 +735,69 @@ def test_graph_cache_reuse_and_invalidation():
     assert conv.graph(ei, n) is not g1
 
 
+def test_input_hop_slab_cache_hits_and_invalidates():
+    """First-layer hop slab (a function of x and edge_index only) is computed once per
+    (x, topology): bit-identical output on a hit, recomputed when x or edge_index change, never
+    used when x needs a gradient."""
+    from deformcontact_amd.graph import graph_index
+    clear_cache()
+    n, fi, fo = 150, 21, 64
+    ei = torch.from_numpy(random_multigraph(n, 1200, 19)).to(DEV)
+    x = torch.from_numpy(hashed_uniform((n, fi), 3, 2.0)).to(DEV)
+    conv = dc.nn.TAGConv(fi, fo).to(DEV)
+    calls = []
+    real = ops._build_input_slab
+    ops._build_input_slab = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        y0 = conv(x, ei)
+        y1 = conv(x, ei)
+        assert len(calls) == 1 and torch.equal(y0, y1)
+        old, ops.HOP_CACHE = ops.HOP_CACHE, False
+        y_nc = conv(x, ei)
+        ops.HOP_CACHE = old
+        assert len(calls) == 2 and torch.equal(y_nc, y0)
+        x[3, 2] += 1.0                                        # in-place edit bumps the version
+        y2 = conv(x, ei)
+        assert len(calls) == 3 and not torch.equal(y2, y0)
+        ei2 = ei.clone()
+        ei2[0, 5] = (ei2[0, 5] + 1) % n
+        y3 = conv(x, ei2)
+        assert len(calls) == 4
+        xg = x.clone().requires_grad_(True)
+        conv(xg, ei).sum().backward()                         # needs grad: no cache, grads flow
+        conv(xg, ei)
+        assert len(calls) == 6 and xg.grad is not None
+        # ahead-of-time (what the loader does): the layer then builds nothing
+        x4 = x.clone()
+        ops.precompute_input_hops(graph_index(ei, n), x4, 3)
+        assert len(calls) == 7
+        y4 = conv(x4, ei)
+        assert len(calls) == 7 and torch.equal(y4, y2)
+    finally:
+        ops._build_input_slab = real
+    ref = pyg_ref.TAGConv(fi, fo)
+    ref.load_state_dict(conv.state_dict())
+    assert rel_err(_np(y2), ref(x.cpu(), ei.cpu()).detach().numpy()) < TOL
+    assert rel_err(_np(y3), ref(x.cpu(), ei2.cpu()).detach().numpy()) < TOL
+
+
+def test_topology_cache_reuses_adjacency_for_equal_content_in_new_tensors():
+    from deformcontact_amd.graph import graph_index
+    from deformcontact_amd.loaders import TopologyCache
+    clear_cache()
+    n = 200
+    a = torch.from_numpy(random_multigraph(n, 1500, 23)).to(DEV)
+    b = a.clone()                                             # same topology, fresh tensor
+    c = torch.from_numpy(random_multigraph(n, 1500, 24)).to(DEV)
+    cache = TopologyCache()
+    ga, gb, gc = cache.get(a, n), cache.get(b, n), cache.get(c, n)
+    assert ga is gb and gc is not ga and (cache.hits, cache.misses) == (1, 2)
+    assert graph_index(b, n) is ga                            # registered for the new tensor
+    assert cache.get(a, n, self_loops=True) is not ga         # flags are part of the key
+    x = torch.randn(n, 8, device=DEV)
+    assert torch.equal(ops.hop(graph_index(b, n).fwd, x), ops.hop(GraphIndex(b, n).fwd, x))
+
+
 def test_reference_style_usage_through_alias():
     """`from torch_geometric.nn import TAGConv` code path (models/model.py:2) on the GPU."""
     import sys
@@ -643,8 +819,10 @@ def test_reference_style_usage_through_alias():
 
 @pytest.mark.parametrize("fi,fo", [(21, 256), (256, 256)])
 def test_direct_param_grad_accumulation_equals_autograd(fi, fo):
-    """ops.DIRECT_PARAM_GRAD: dW / bias gradients accumulated into existing .grad buffers by the
-    slab-reduce kernel must equal what autograd's AccumulateGrad produces."""
+    """Direct mode (opt-in through ``dp.GradBucket(direct=True)``): dW / bias gradients accumulated
+    into the bucket's views by the slab-reduce kernel must equal what autograd's AccumulateGrad
+    produces; parameters that merely HAVE a dense ``.grad`` (no bucket) keep stock autograd."""
+    from deformcontact_amd import dp
     n, e = 150, 1100
     ei = torch.from_numpy(random_multigraph(n, e, 17)).to(DEV)
     x = torch.from_numpy(hashed_uniform((n, fi), 3, 2.0)).to(DEV).requires_grad_(True)
@@ -660,28 +838,89 @@ def test_direct_param_grad_accumulation_equals_autograd(fi, fo):
     run()                                                   # .grad is None -> autograd path
     ref = {k: p.grad.clone() for k, p in conv.named_parameters()}
     gx_ref = x.grad.clone()
-    for p in conv.parameters():
-        p.grad = torch.zeros_like(p)                        # dense buffers -> direct path
+    # a plain dense .grad is NOT a sink: hooks fire, autograd accumulates (2x)
+    fired = []
+    h = conv.lins[0].weight.register_hook(lambda g: fired.append(1))
+    x.grad = None
+    run()
+    h.remove()
+    assert fired, "without a direct bucket tensor hooks must fire"
+    for k, p in conv.named_parameters():
+        assert rel_err(_np(p.grad), 2 * _np(ref[k])) < 1e-6, k
+    # opt in
+    bucket = dp.GradBucket(conv.parameters(), direct=True)   # zeroed views
     ptrs = {k: p.grad.data_ptr() for k, p in conv.named_parameters()}
     x.grad = None
     run()
+    assert bucket._pending, "direct writes must be reported to the bucket"
+    bucket.wait_direct_writes()
     for k, p in conv.named_parameters():
         assert p.grad.data_ptr() == ptrs[k], "direct mode must write in place"
         assert rel_err(_np(p.grad), _np(ref[k])) < 1e-6, k
     assert torch.equal(x.grad, gx_ref)
     x.grad = None
     run()                                                   # accumulates: 2x
+    bucket.wait_direct_writes()
     for k, p in conv.named_parameters():
         assert rel_err(_np(p.grad), 2 * _np(ref[k])) < 1e-6, k
+    # a frozen parameter takes the layer out of direct mode (nothing may be accumulated into it)
+    conv.lins[2].weight.requires_grad_(False)
+    frozen = conv.lins[2].weight.grad.clone()
+    x.grad = None
+    run()
+    bucket.wait_direct_writes()
+    assert torch.equal(conv.lins[2].weight.grad, frozen)
+    assert rel_err(_np(conv.lins[1].weight.grad), 3 * _np(ref["lins.1.weight"])) < 1e-6
+    conv.lins[2].weight.requires_grad_(True)
     old = ops.DIRECT_PARAM_GRAD
     try:
         ops.DIRECT_PARAM_GRAD = False
         x.grad = None
-        run()                                               # stock autograd accumulate: 3x
-        for k, p in conv.named_parameters():
-            assert rel_err(_np(p.grad), 3 * _np(ref[k])) < 1e-6, k
+        run()                                               # stock autograd accumulate
+        assert rel_err(_np(conv.lins[1].weight.grad), 4 * _np(ref["lins.1.weight"])) < 1e-6
     finally:
         ops.DIRECT_PARAM_GRAD = old
+
+
+def test_direct_param_grad_two_stream_encoder_with_bucket():
+    """Direct gradient writes of the rigid branch land on the encoder's side stream: the bucket's
+    consumers must be ordered behind them.  Two-stream encoder + GradBucket(direct=True) + FlatAdam
+    against the same step with stock autograd accumulation, several steps."""
+    from deformcontact_amd import dp, synth
+    from deformcontact_amd.graphnet import ContactEncoder
+    rest, _, rig = (b.to(DEV) for b in synth.make_batch(3, soft_vertices=200, sphere_resolution=7))
+    g_s = torch.randn(rest.x.shape[0], 256, device=DEV)
+    g_r = torch.randn(rig.x.shape[0], 256, device=DEV)
+    finals = []
+    for direct in (False, True):
+        torch.manual_seed(0)
+        enc = ContactEncoder([21, 25], 256).to(DEV)
+        enc.overlap_branches = True
+        bucket = dp.GradBucket(enc.parameters(), direct=direct)
+        opt = dp.FlatAdam(bucket, lr=1e-3, zero_grad_in_step=True)
+        for _ in range(4):
+            a, b = enc(rest, rig)
+            torch.autograd.backward([a, b], [g_s, g_r])
+            bucket.all_reduce_mean()
+            opt.step()
+        torch.cuda.synchronize()
+        assert not bucket._pending
+        finals.append(opt.flat_param.clone())
+    assert rel_err(_np(finals[1]), _np(finals[0])) < 1e-6
+
+
+def test_foreign_column_view_is_not_taken_for_a_hop_slab():
+    """A caller's own ``feat[:, :F]`` view of a wider buffer has the shape and strides of column
+    block 0 of a hop slab; the layer must not run its hops in place there."""
+    n, fi, fo = 96, 32, 16
+    ei = torch.from_numpy(random_multigraph(n, 500, 5)).to(DEV)
+    conv = dc.nn.TAGConv(fi, fo).to(DEV)
+    wide = torch.from_numpy(hashed_uniform((n, 4 * fi), 9, 1.0)).to(DEV)
+    keep = wide.clone()
+    out_view = conv(wide[:, :fi], ei)
+    assert torch.equal(wide, keep), "the caller's buffer was overwritten"
+    out_copy = conv(keep[:, :fi].contiguous(), ei)
+    assert torch.equal(out_view, out_copy)
 
 
 @pytest.mark.parametrize("fused_zero", [False, True])

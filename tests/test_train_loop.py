@@ -68,3 +68,42 @@ def test_loss_curve_matches_oracle_on_gpu():
         curve_gpu.append(float(train_step(gpu, o_gpu, *b_gpu)["loss"]))
     assert np.allclose(curve_gpu, curve_ref, rtol=2e-4), (curve_gpu, curve_ref)
     assert np.allclose(curve_gpu[:2], curve_ref[:2], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_graphed_train_loop_follows_oracle_curve_with_changing_batches(tmp_path):
+    """BASELINE.json configs[2]: the real loop - a NEW batch every step (new edge_index, new
+    features), FlatAdam over the direct-gradient bucket, steps replayed from one hipGraph that
+    contains the adjacency build - against the CPU oracle with torch.optim.Adam on the same
+    batches.  Also: train() on the GPU writes its log / checkpoint and replays graphs."""
+    from deformcontact_amd import dp
+    from deformcontact_amd.train import GraphedTrainStep
+    torch.set_num_threads(1)
+    torch.manual_seed(0)
+    ref = load_model(SMALL, conv_module=pyg_ref)
+    gpu = load_model(SMALL)
+    gpu.load_state_dict(ref.state_dict())
+    gpu = gpu.to("cuda:0")
+    o_ref = torch.optim.Adam(ref.parameters(), lr=4e-4)
+    bucket = dp.GradBucket(gpu.parameters(), direct=True)
+    o_gpu = dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=True)
+    step = GraphedTrainStep(gpu, o_gpu, bucket, 1.0, eager_steps=2)
+    curve_ref, curve_gpu = [], []
+    for collated in _batches(20, 2):
+        curve_ref.append(float(train_step(ref, o_ref, *loaders.to_batches(collated))["loss"]))
+        curve_gpu.append(float(step(*loaders.to_batches(collated, "cuda:0"))["loss"]))
+    assert step.replays == 8
+    assert np.allclose(curve_gpu, curve_ref, rtol=2e-4), (curve_gpu, curve_ref)
+    assert np.allclose(curve_gpu[:2], curve_ref[:2], rtol=1e-5)
+    for a, b in zip(ref.parameters(), gpu.parameters()):
+        assert np.allclose(b.detach().cpu().numpy(), a.detach().numpy(), rtol=0, atol=2e-5)
+    stats = {}
+    train(SMALL, device="cuda:0", epochs=1, num_train=12, num_val=2, batch_size=2, out_dir=str(tmp_path),
+          soft_vertices=64, sphere_resolution=4, stats=stats)
+    assert stats["steps"] == 6 and stats["graph_replays"] == 4
+    lines = [json.loads(l) for l in open(tmp_path / "log_rank0.jsonl")]
+    assert sum("loss" in l for l in lines) == 6 and all(np.isfinite(l["loss"]) for l in lines if "loss" in l)
+    stats = {}
+    train(SMALL, device="cuda:0", epochs=1, num_train=6, num_val=2, batch_size=2, out_dir=str(tmp_path),
+          soft_vertices=64, sphere_resolution=4, capture=False, stats=stats)   # loader-prepared topology
+    assert stats["steps"] == 3 and stats["graph_replays"] == 0

@@ -1,0 +1,151 @@
+// tools/exp/hop_exp.hip -- experimental variants of the F=256 fp32 hop (NOT part of the product
+// library): built into tools/exp/libhopexp.so and driven by tools/exp/hop_exp.py to decide what
+// goes into csrc/dc_spmm.hip.  All variants compute y[i,:] = sum_p w[p] * x[other[p],:] with the
+// product's rounding (separate mul / add, p order), F = 256, 16-byte aligned rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+static __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk / 8, r = nblk % 8;
+    const unsigned xcd = bid % 8, idx = bid / 8;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static __device__ __forceinline__ void axpy(float4 &a, float w, const float4 &v) {
+    const float mx = w * v.x, my = w * v.y, mz = w * v.z, mw = w * v.w;
+    a.x = a.x + mx; a.y = a.y + my; a.z = a.z + mz; a.w = a.w + mw;
+}
+
+template <bool NT>
+static __device__ __forceinline__ void store4(float *p, const float4 &v) {
+    if (NT) {
+        __builtin_nontemporal_store(v.x, p);
+        __builtin_nontemporal_store(v.y, p + 1);
+        __builtin_nontemporal_store(v.z, p + 2);
+        __builtin_nontemporal_store(v.w, p + 3);
+    } else {
+        *reinterpret_cast<float4 *>(p) = v;
+    }
+}
+
+// ---- copy floor: same geometry as the product kernel, y[row] = x[row] ----
+__global__ void __launch_bounds__(256)
+k_copy_rows(const float *__restrict__ x, int64_t ldx, float *y, int64_t ldy, int64_t N) {
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = lb * 4u + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int c = (threadIdx.x & 63) * 4;
+    *reinterpret_cast<float4 *>(y + row * ldy + c) = *reinterpret_cast<const float4 *>(x + row * ldx + c);
+}
+
+// ---- chunked: each wave walks RW consecutive rows, WPB waves per block; the index loads of the
+// next row are issued before the current row's gathers are consumed ----
+template <int RW, int WPB, bool NT, int U>
+__global__ void __launch_bounds__(WPB * 64)
+k_hop_chunk(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
+            const float *__restrict__ w, const float *__restrict__ x, int64_t ldx, float *y,
+            int64_t ldy, int64_t N) {
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t row0 = ((int64_t)lb * WPB + wave) * RW;
+    if (row0 >= N) return;
+    const int c = (threadIdx.x & 63) * 4;
+    const int nrow = (int)((N - row0) < RW ? (N - row0) : RW);
+    int beg = ptr[row0], end = ptr[row0 + 1];
+    for (int r = 0; r < nrow; ++r) {
+        const int64_t row = row0 + r;
+        int nbeg = 0, nend = 0;
+        if (r + 1 < nrow) { nbeg = end; nend = ptr[row + 2]; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = beg; p < end; p += U) {
+            const int n = end - p;
+            int s[U]; float ww[U]; float4 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) if (j < n) { s[j] = other[p + j]; ww[j] = w[p + j]; }
+#pragma unroll
+            for (int j = 0; j < U; ++j) if (j < n) v[j] = *reinterpret_cast<const float4 *>(x + (int64_t)s[j] * ldx + c);
+#pragma unroll
+            for (int j = 0; j < U; ++j) if (j < n) axpy(acc, ww[j], v[j]);
+        }
+        store4<NT>(y + row * ldy + c, acc);
+        beg = nbeg; end = nend;
+    }
+}
+
+// ---- pipelined: the gathers of row r+1 are issued BEFORE row r is reduced and stored (two
+// register sets); rows with more than U neighbours fall back to the plain loop for the rest ----
+template <int RW, int WPB, bool NT, int U>
+__global__ void __launch_bounds__(WPB * 64)
+k_hop_pipe(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
+           const float *__restrict__ w, const float *__restrict__ x, int64_t ldx, float *y,
+           int64_t ldy, int64_t N) {
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t row0 = ((int64_t)lb * WPB + wave) * RW;
+    if (row0 >= N) return;
+    const int c = (threadIdx.x & 63) * 4;
+    const int nrow = (int)((N - row0) < RW ? (N - row0) : RW);
+    float4 va[U], vb[U];
+    float wa[U], wb[U];
+    int bega, enda, begb = 0, endb = 0;
+    auto issue = [&](int beg, int end, float4 (&v)[U], float (&ww)[U]) {
+        const int n = end - beg;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool ok = j < n;
+            const int s = ok ? other[beg + j] : 0;
+            ww[j] = ok ? w[beg + j] : 0.0f;
+            if (ok) v[j] = *reinterpret_cast<const float4 *>(x + (int64_t)s * ldx + c);
+        }
+    };
+    auto finish = [&](int64_t row, int beg, int end, float4 (&v)[U], float (&ww)[U]) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int n = end - beg;
+#pragma unroll
+        for (int j = 0; j < U; ++j) if (j < n) axpy(acc, ww[j], v[j]);
+        for (int p = beg + U; p < end; ++p) {          // long rows: the tail, one at a time
+            const float4 t = *reinterpret_cast<const float4 *>(x + (int64_t)other[p] * ldx + c);
+            axpy(acc, w[p], t);
+        }
+        store4<NT>(y + row * ldy + c, acc);
+    };
+    bega = ptr[row0]; enda = ptr[row0 + 1];
+    issue(bega, enda, va, wa);
+    for (int r = 0; r < nrow; r += 2) {
+        if (r + 1 < nrow) { begb = enda; endb = ptr[row0 + r + 2]; issue(begb, endb, vb, wb); }
+        finish(row0 + r, bega, enda, va, wa);
+        if (r + 1 >= nrow) break;
+        if (r + 2 < nrow) { bega = endb; enda = ptr[row0 + r + 3]; issue(bega, enda, va, wa); }
+        finish(row0 + r + 1, begb, endb, vb, wb);
+    }
+}
+
+#define LAUNCH(K, grid, threads) hipLaunchKernelGGL(K, dim3(grid), dim3(threads), 0, (hipStream_t)stream, ptr, other, w, x, ldx, y, ldy, N)
+
+extern "C" int hopexp_run(int variant, const int32_t *ptr, const int32_t *other, const float *w,
+                          const float *x, int64_t ldx, float *y, int64_t ldy, int64_t N, void *stream) {
+    auto blocks = [&](int rw, int wpb) { return (unsigned)((N + (int64_t)rw * wpb - 1) / ((int64_t)rw * wpb)); };
+    switch (variant) {
+    case 0: hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, N); break;
+    case 1: LAUNCH((k_hop_chunk<1, 4, false, 8>), blocks(1, 4), 256); break;
+    case 2: LAUNCH((k_hop_chunk<1, 4, true, 8>), blocks(1, 4), 256); break;
+    case 3: LAUNCH((k_hop_chunk<2, 4, false, 8>), blocks(2, 4), 256); break;
+    case 4: LAUNCH((k_hop_chunk<4, 4, false, 8>), blocks(4, 4), 256); break;
+    case 5: LAUNCH((k_hop_chunk<8, 4, false, 8>), blocks(8, 4), 256); break;
+    case 6: LAUNCH((k_hop_chunk<4, 8, false, 8>), blocks(4, 8), 512); break;
+    case 7: LAUNCH((k_hop_chunk<1, 16, false, 8>), blocks(1, 16), 1024); break;
+    case 8: LAUNCH((k_hop_pipe<4, 4, false, 8>), blocks(4, 4), 256); break;
+    case 9: LAUNCH((k_hop_pipe<8, 4, false, 8>), blocks(8, 4), 256); break;
+    case 10: LAUNCH((k_hop_pipe<16, 4, false, 8>), blocks(16, 4), 256); break;
+    case 11: LAUNCH((k_hop_pipe<8, 4, true, 8>), blocks(8, 4), 256); break;
+    case 12: LAUNCH((k_hop_pipe<4, 8, false, 8>), blocks(4, 8), 512); break;
+    case 13: LAUNCH((k_hop_pipe<8, 2, false, 8>), blocks(8, 2), 128); break;
+    case 14: LAUNCH((k_hop_chunk<1, 4, false, 4>), blocks(1, 4), 256); break;
+    case 15: LAUNCH((k_hop_pipe<4, 4, false, 6>), blocks(4, 4), 256); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Drive tools/exp/libhopexp.so (experimental hop variants) on the B=32 everyday graphs.
+
+    python tools/exp/hop_exp.py [--reps 200]
+
+Prints us per launch and the compulsory-bytes fraction of 8 TB/s for every variant, on the slab
+column-block layout a step uses (ld = 1024) and on contiguous [N,256] buffers, checks each
+variant bit-for-bit against the product kernel, and times the sorted-adjacency build."""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import torch  # noqa: E402
+
+from deformcontact_amd import ops, synth  # noqa: E402
+from deformcontact_amd.graph import GraphIndex, current_stream_ptr  # noqa: E402
+
+NAMES = {0: "copy rows (floor)", 1: "chunk RW1 WPB4 (= product)", 2: "chunk RW1 nt-store", 3: "chunk RW2",
+         4: "chunk RW4", 5: "chunk RW8", 6: "chunk RW4 WPB8", 7: "chunk RW1 WPB16", 8: "pipe RW4",
+         9: "pipe RW8", 10: "pipe RW16", 11: "pipe RW8 nt", 12: "pipe RW4 WPB8", 13: "pipe RW8 WPB2",
+         14: "chunk RW1 U4", 15: "pipe RW4 U6"}
+
+
+def timeit(fn, reps):
+    for _ in range(5):
+        fn()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / reps)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=200)
+    args = ap.parse_args()
+    so = os.path.join(HERE, "libhopexp.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+                               "-ffp-contract=off", os.path.join(HERE, "hop_exp.hip"), "-o", so])
+    L = ctypes.CDLL(so)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    L.hopexp_run.argtypes = [ctypes.c_int, vp, vp, vp, vp, i64, vp, i64, i64, vp]
+    dev = torch.device("cuda:0")
+    st = current_stream_ptr(dev)
+    rest, _, rig = synth.make_batch(32)
+    f = 256
+    for name, b in (("soft", rest), ("rigid", rig)):
+        n, e = b.x.shape[0], b.edge_index.shape[1]
+        g = GraphIndex(b.edge_index.to(dev), n)
+        comp = e * 8 + n * (8 * f + 4)
+        slab = torch.randn(n, 4 * f, device=dev)
+        xc, yc = slab[:, :f].contiguous(), torch.empty(n, f, device=dev)
+        for lay, x, y in (("slab ld=1024", slab[:, :f], slab[:, f:2 * f]), ("contiguous", xc, yc)):
+            ref = ops.hop(g.fwd, x).clone()
+            rm = torch.zeros(n, device=dev)
+            t = timeit(lambda: ops.hop(g.fwd, x, out=y), args.reps)
+            print(f"{name:5s} {lay:13s} product dc_spmm_f32        : {t * 1e3:7.2f} us  frac {comp / t / 1e6 / 8000:.3f}")
+            t = timeit(lambda: ops.hop(g.fwd, x, out=y, rowmax=rm, rowmax_mode=2), args.reps)
+            print(f"{name:5s} {lay:13s} product dc_spmm_f32_rowmax : {t * 1e3:7.2f} us  frac {comp / t / 1e6 / 8000:.3f}")
+            for v in sorted(NAMES):
+                def run(v=v):
+                    rc = L.hopexp_run(v, g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(),
+                                      x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), n, st)
+                    assert rc == 0, rc
+                y.zero_()
+                run()
+                torch.cuda.synchronize()
+                ok = "exact" if (v == 0 or torch.equal(y, ref)) else "MISMATCH"
+                t = timeit(run, args.reps)
+                print(f"{name:5s} {lay:13s} v{v:02d} {NAMES[v]:26s}: {t * 1e3:7.2f} us  frac {comp / t / 1e6 / 8000:.3f}  {ok}")
+        t = timeit(g.rebuild, 50)
+        print(f"{name:5s} dc_graph_build (both sides, N={n} E={e}): {t * 1e3:7.2f} us")
+
+
+if __name__ == "__main__":
+    main()

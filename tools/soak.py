@@ -22,7 +22,7 @@ def run(steps, dev):
     gen = torch.Generator(device=dev).manual_seed(1)
     g_rest = torch.randn(rest.x.shape[0], 256, device=dev, generator=gen) * 1e-3
     g_rig = torch.randn(rig.x.shape[0], 256, device=dev, generator=gen) * 1e-3
-    bucket = dp.GradBucket(enc.parameters())
+    bucket = dp.GradBucket(enc.parameters(), direct=True)
     opt = dp.FlatAdam(bucket, lr=1e-4, zero_grad_in_step=True)
     bucket.zero()
 
