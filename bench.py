@@ -72,6 +72,10 @@ def parse():
                     help="skip the extra line with the dense blocks on fp32 MFMA (DC_DENSE_SPLIT=0)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
+    ap.add_argument("--workload", default="everyday", choices=["everyday", "radius100k"],
+                    help="radius100k: only the bf16 100k-point radius-graph stress (BASELINE.json configs[4])")
+    ap.add_argument("--no-radius100k", action="store_true",
+                    help="leave the radius100k extra out of the default line")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="batches rotated through the timed steps (each step sees a new edge_index)")
     return ap.parse_args()
@@ -288,6 +292,79 @@ def full_step_b4(dev, steps: int = 20, batch: int = 4):
                     "; losses on stock PyTorch; Adam = dc_adam_flat"}
 
 
+def radius100k(dev, reps: int = 30):
+    """BASELINE.json configs[4]: one 100k-point radius graph with a dense blob (in-degree up to 32,
+    mean ~11), 256 features STORED as bf16, two TAGConv(256, 256, K=3) layers forward (bf16 hops
+    with fp32 accumulation + bf16 MFMA dense blocks, ReLU fused), nodes in Morton order.
+    Reports the forward rate, the bf16 hop against the HBM roofline on compulsory bytes (with and
+    without the reordering) and the bf16 dense block against the dense bf16 MFMA peak."""
+    from deformcontact_amd import nn as dc_nn
+    from deformcontact_amd import ops, synth
+    from deformcontact_amd.graph import GraphIndex, NodeOrder
+
+    def timeit(fn, r):
+        for _ in range(3):
+            fn()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(r):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / r
+
+    pos, ei = synth.radius_graph_points(100_000, radius=0.02, max_num_neighbors=32)
+    pos, ei = pos.to(dev), ei.to(dev)
+    n, e, f = pos.shape[0], ei.shape[1], 256
+    order = NodeOrder.morton(pos)
+    ei_m = order.relabel(ei)
+    g_raw, g_m = GraphIndex(ei, n), GraphIndex(ei_m, n)
+    x = torch.randn(n, f, device=dev).bfloat16()
+    y = torch.empty_like(x)
+    comp = e * 8 + n * (2 * 2 * f + 4)                      # idx + w once, bf16 row in once and out once
+    t_raw = timeit(lambda: ops.hop_bf16(g_raw.fwd, x, out=y), reps)
+    t_m = timeit(lambda: ops.hop_bf16(g_m.fwd, x, out=y), reps)
+    x32, y32 = x.float(), torch.empty(n, f, device=dev)
+    comp32 = e * 8 + n * (2 * 4 * f + 4)
+    t32_raw = timeit(lambda: ops.hop(g_raw.fwd, x32, out=y32), reps)
+    t32_m = timeit(lambda: ops.hop(g_m.fwd, x32, out=y32), reps)
+    torch.manual_seed(0)
+    c1, c2 = dc_nn.TAGConv(f, f).to(dev), dc_nn.TAGConv(f, f).to(dev)
+    xm = order.apply(x)
+
+    def fwd():
+        with torch.no_grad():
+            return c2(c1(xm, ei_m, relu=True, next_conv=c2), ei_m, relu=True)
+    t_fwd = timeit(fwd, max(reps // 3, 3))
+    # the dense block alone: [N, 1024] bf16 slab x [256, 1024] bf16 weights
+    from deformcontact_amd import _lib
+    from deformcontact_amd.graph import current_stream_ptr
+    L, st = _lib.lib(), current_stream_ptr(dev)
+    slab = torch.randn(n, 4 * f, device=dev).bfloat16()
+    w = (torch.randn(f, 4 * f, device=dev) / 32).bfloat16()
+    out = torch.empty(n, f, dtype=torch.bfloat16, device=dev)
+    t_d = timeit(lambda: L.dc_tag_linear_fwd_bf16(slab.data_ptr(), 4 * f, w.data_ptr(), None, 1, out.data_ptr(),
+                                                  f, 1, n, 4 * f, f, st), reps)
+    flop = 2.0 * n * 4 * f * f
+    return {
+        "workload": f"radius graph, N={n} points (30 % in a dense blob), E={e} (in-degree <= 32), F=256 stored as "
+                    "bf16, nodes in Morton order; 2 x TAGConv(256,256,K=3) forward, ReLU fused (configs[4])",
+        "fwd_ms": round(t_fwd, 4), "M_edges_per_s_fwd": round(e / t_fwd / 1e3, 1),
+        "hop_bf16": {"kernel": "dc::k_spmm_bf16x8 (bf16 rows gathered, fp32 running sum, bf16 stored)",
+                     "us_morton": round(t_m * 1e3, 1), "us_unordered": round(t_raw * 1e3, 1),
+                     "compulsory_bytes": comp, "frac_morton": round(comp / t_m / 1e6 / HBM_PEAK_GBS, 4),
+                     "frac_unordered": round(comp / t_raw / 1e6 / HBM_PEAK_GBS, 4),
+                     "G_edge_hops_per_s_morton": round(e / t_m / 1e6, 2)},
+        "hop_f32": {"us_morton": round(t32_m * 1e3, 1), "us_unordered": round(t32_raw * 1e3, 1),
+                    "frac_morton": round(comp32 / t32_m / 1e6 / HBM_PEAK_GBS, 4),
+                    "frac_unordered": round(comp32 / t32_raw / 1e6 / HBM_PEAK_GBS, 4)},
+        "dense_bf16": {"kernel": "dc::k_fwd_bf16 (both operands by LDS-DMA, loader wave + 4 MFMA waves)",
+                       "us": round(t_d * 1e3, 1), "TFLOPs": round(flop / t_d / 1e9, 1),
+                       "frac_of_2500_TF": round(flop / t_d / 1e9 / 2500.0, 4),
+                       "GBps_operand_bytes": round((slab.numel() * 2 + out.numel() * 2) / t_d / 1e6, 1)},
+    }
+
+
 def measure_traffic(timeout_s: float = 300.0):
     """`roofline.traffic`, measured in THIS run: two rocprofv3 child passes (`--pmc FETCH_SIZE`,
     then `--pmc WRITE_SIZE`: the TCC block cannot hold both in one pass) over `tools/pmc_hop.py`,
@@ -380,6 +457,16 @@ def main():
         traffic, traffic_note = (None, "--no-pmc") if args.no_pmc else measure_traffic()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in deformcontact_amd)")
+    if args.workload == "radius100k":
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        r = radius100k(torch.device("cuda", torch.cuda.current_device()), args.kernel_reps // 3 or 3)
+        if rank == 0:
+            print(json.dumps({"metric": "M edges/sec fwd, 100k-node radius graph, bf16 features (configs[4])",
+                              "value": r["M_edges_per_s_fwd"], "unit": "M edges/s", "n_gpus": 1, "steps": 1,
+                              "warmup": 0, "ms_per_step": r["fwd_ms"], "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                              "config": {"workload": r["workload"]}, "radius100k": r}), flush=True)
+        return
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)     # == local_rank on a real N-GPU node
     torch.cuda.set_device(dev_index)
@@ -399,25 +486,30 @@ def main():
     from deformcontact_amd.graphnet import ContactEncoder
 
     # ---- workload: B sample pairs per rank and step, distinct geometry per rank and per batch ----
+    from deformcontact_amd import graph as dc_graph
     nb = max(1, args.distinct_batches)
     pool = []
     for j in range(nb):
         r_h, _, g_h = synth.make_batch(args.batch, first_idx=(j * world + rank) * args.batch)
         if j == 0:
-            rest, rig = r_h.to(dev), g_h.to(dev)           # the step's (static) input buffers
+            rest, rig = r_h.to(dev), g_h.to(dev)           # input buffers, slot A
+            rest_b, rig_b = r_h.to(dev), g_h.to(dev)       # input buffers, slot B (pipelined mode)
         pool.append((r_h.x.to(dev), r_h.edge_index.to(dev), g_h.x.to(dev), g_h.edge_index.to(dev)))
     n_s, e_s = rest.x.shape[0], rest.edge_index.shape[1]
     n_r, e_r = rig.x.shape[0], rig.edge_index.shape[1]
     assert all(p[1].shape == rest.edge_index.shape and p[3].shape == rig.edge_index.shape for p in pool)
     edges_per_rank = e_s + e_r
+    slots = ((rest, rig), (rest_b, rig_b))
 
-    def load(j: int) -> None:
-        """A new batch arrives: features + edge_index into the step's input buffers."""
+    def load(j: int, slot=0) -> None:
+        """A new batch arrives: features + edge_index into a slot's input buffers (device to
+        device; the stand-in for the loader's upload)."""
         xs, es, xr, er = pool[j % nb]
-        rest.x.copy_(xs)
-        rest.edge_index.copy_(es)
-        rig.x.copy_(xr)
-        rig.edge_index.copy_(er)
+        r_, g_ = slots[slot]
+        r_.x.copy_(xs)
+        r_.edge_index.copy_(es)
+        g_.x.copy_(xr)
+        g_.edge_index.copy_(er)
 
     torch.manual_seed(0)                      # identical init on every rank
     enc = ContactEncoder([21, 25], 256).to(dev)
@@ -430,11 +522,12 @@ def main():
     # Adam defaults, one HIP kernel that also clears the gradients it consumed (zero_grad)
     opt = None if args.no_optim else dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=True)
     bucket.zero()
+    k_hops = enc.conv_layers_resting[0].K
 
-    def fwd_bwd():
+    def fwd_bwd(slot=0):
         if opt is None:
             bucket.zero()
-        a, b = enc(rest, rig)
+        a, b = enc(*slots[slot])
         torch.autograd.backward([a, b], [g_rest, g_rig])
 
     def tail():
@@ -446,45 +539,164 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def capture():
-        """fwd+bwd (+ Adam when single-GPU) as one hipGraph.  An adjacency built eagerly is not
-        reused under capture (graph.graph_index), so unless the caller marked it static the
-        captured step contains `dc_graph_build` for both edge_index buffers."""
+    # ---- per-batch topology work of a slot (what loaders.PrefetchLoader + prepare_for do on the
+    # loader's stream): both sorted adjacencies + gcn_norm, first-layer hop slabs ----
+    slot_graphs = {}
+
+    def prep(slot: int) -> None:
+        for which, (b_, n_) in enumerate(zip(slots[slot], (n_s, n_r))):
+            g = slot_graphs.get((slot, which))
+            if g is None:
+                g = dc_graph.GraphIndex(b_.edge_index, n_)
+                g._static_ok = True               # the pipeline below keeps it valid for every replay
+                slot_graphs[(slot, which)] = g
+            else:
+                g.rebuild()
+            dc_graph.register(b_.edge_index, g)
+            ops.precompute_input_hops(g, b_.x, k_hops, refresh=True)
+
+    prep_stream = torch.cuda.Stream()
+
+    def capture(body):
+        """`body()` as one hipGraph (None with --no-graph or if capture fails)."""
         if args.no_graph:
-            return None, False
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fwd_bwd()
-                tail()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+            return None
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                fwd_bwd()
-                if world == 1:
-                    tail()
-            return g, world == 1
+                body()
+            return g
         except Exception as e:  # pragma: no cover
             if rank == 0:
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager",
                       file=sys.stderr)
             torch.cuda.synchronize()
-            return None, False
+            return None
 
-    def timed(graph, has_tail, steps, warmup, rotate):
+    def warm(fn, reps=3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(reps):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    tail_in_graph = world == 1
+
+    def make_mode(mode: str):
+        """-> step(i).  pipelined: train slot i%2 while the NEXT batch is loaded into the other slot
+        and prepared on a third stream (one graph per parity); serial: load, build, train in
+        sequence on one slot; cached: one fixed batch, adjacency + first-layer hops built once."""
+        dc_graph.clear_cache()
+        slot_graphs.clear()
+        if mode == "cached":
+            load(0, 0)
+            for b_, n_ in zip(slots[0], (n_s, n_r)):
+                dc_graph.graph_index(b_.edge_index, n_)._static_ok = True   # constant for the graph's life
+
+            def body():
+                fwd_bwd(0)
+                if tail_in_graph:
+                    tail()
+            warm(lambda: (fwd_bwd(0), tail()))
+            g = capture(body)
+
+            def step(i):
+                if g is not None:
+                    g.replay()
+                    if not tail_in_graph:
+                        tail()
+                else:
+                    fwd_bwd(0)
+                    tail()
+            return step
+        if mode == "serial":
+            def body():
+                fwd_bwd(0)                        # adjacency is built inside (never reused under capture)
+                if tail_in_graph:
+                    tail()
+            load(0, 0)
+            warm(lambda: (fwd_bwd(0), tail()))
+            dc_graph.clear_cache()
+            g = capture(body)
+
+            def step(i):
+                load(i, 0)
+                if g is not None:
+                    g.replay()
+                    if not tail_in_graph:
+                        tail()
+                else:
+                    fwd_bwd(0)
+                    tail()
+            return step
+        # pipelined: training graphs on the main stream, preparation graphs on `prep_stream`, ordered by
+        # events (a third branch INSIDE one captured graph was measured not to overlap at all on this
+        # runtime: 0.8955 vs 0.8953 ms serial, r02c)
+        load(0, 0)
+        load(1, 1)
+        prep(0)
+        prep(1)
+        warm(lambda: (fwd_bwd(0), tail(), fwd_bwd(1), tail()), reps=2)
+
+        def train_body(cur):
+            def body():
+                fwd_bwd(cur)                      # slot adjacency + hop slabs are static objects: found, not rebuilt
+                if tail_in_graph:
+                    tail()
+            return body
+        train_g = [capture(train_body(0)), capture(train_body(1))]
+        prep_g = [None, None]
+        if not args.no_graph:
+            for c in (0, 1):
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=prep_stream):
+                        prep(c)
+                    prep_g[c] = g
+                except Exception as e:  # pragma: no cover
+                    print(f"[bench] prep graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+                    torch.cuda.synchronize()
+        ev_prep = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_train = [torch.cuda.Event(), torch.cuda.Event()]
+        state = {"primed": False, "prep": [False, False], "train": [False, False]}
+
         def step(i):
-            if rotate:
-                load(i)
-            if graph is not None:
-                graph.replay()
-                if not has_tail:
+            cur, oth = i & 1, 1 - (i & 1)
+            main = torch.cuda.current_stream()
+            if not state["primed"]:               # the very first step prepares its own batch in line
+                load(i, cur)
+                prep(cur)
+                state["primed"] = True
+            # the NEXT batch: into the other slot and through its topology work on the prep stream,
+            # once the last training step that read that slot is done; overlaps this step's training
+            if state["train"][oth]:
+                prep_stream.wait_event(ev_train[oth])
+            else:
+                prep_stream.wait_stream(main)
+            with torch.cuda.stream(prep_stream):
+                load(i + 1, oth)
+                if prep_g[oth] is not None:
+                    prep_g[oth].replay()
+                else:
+                    prep(oth)
+                ev_prep[oth].record(prep_stream)
+            state["prep"][oth] = True
+            if state["prep"][cur]:
+                main.wait_event(ev_prep[cur])
+            if train_g[cur] is not None:
+                train_g[cur].replay()
+                if not tail_in_graph:
                     tail()
             else:
-                fwd_bwd()
+                fwd_bwd(cur)
                 tail()
+            ev_train[cur].record(main)
+            state["train"][cur] = True
+        return step
+
+    def timed(step, steps, warmup):
         for i in range(warmup):
             step(i)
         barrier()
@@ -501,26 +713,23 @@ def main():
             elapsed = float(t.item())
         return elapsed
 
-    # ---- headline: every step gets a new batch; topology build inside the step ----
-    clear_cache()
-    graph, has_tail = capture()
-    elapsed = timed(graph, has_tail, args.steps, args.warmup, rotate=True)
+    # ---- headline: every step trains on a new batch whose topology work ran during the previous step ----
+    warmup = max(args.warmup, 1)
+    elapsed = timed(make_mode("pipelined"), args.steps, warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = edges_per_rank * world * args.steps / elapsed / 1e6
-
-    # ---- secondary: one fixed batch replayed, adjacency built once outside the loop ----
-    load(0)
-    clear_cache()
-    for b_, n_ in ((rest, n_s), (rig, n_r)):
-        graph_index(b_.edge_index, n_)._static_ok = True     # constant for the life of the graph
-    graph_c, has_tail_c = capture()
-    elapsed_c = timed(graph_c, has_tail_c, args.steps, args.warmup, rotate=False)
+    # ---- the same with the topology work on the critical path, and with it left out (round-1 definition) ----
+    elapsed_s = timed(make_mode("serial"), args.steps, warmup)
+    elapsed_c = timed(make_mode("cached"), args.steps, warmup)
+    graph_used = not args.no_graph
 
     out = {
         "metric": "M edges/sec fwd+bwd, everyday-deform batch=32 per GPU (encoder hot path)",
         "value": round(value, 3), "unit": "M edges/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_serial_topology": round(edges_per_rank * world * args.steps / elapsed_s / 1e6, 3),
+        "ms_per_step_serial_topology": round(elapsed_s / args.steps * 1e3, 4),
         "value_cached_topology": round(edges_per_rank * world * args.steps / elapsed_c / 1e6, 3),
         "ms_per_step_cached_topology": round(elapsed_c / args.steps * 1e3, 4),
         "dense_arithmetic": (("fp32 storage and accumulate; wide dense blocks as power-of-two-scaled 2-way "
@@ -534,12 +743,17 @@ def main():
                         f"{args.batch}x(1024 v, 6132 e) + rigid {args.batch}x(762 v, 4560 e); "
                         "TAGConv encoder 2 layers/branch, hidden 256, K=3 (configs[1])",
             "edges_per_gpu_step": edges_per_rank, "global_batch": args.batch * world,
-            "step": f"new batch into the input buffers (1 of {nb} distinct, rotated) + sorted adjacency / "
-                    "gcn_norm build for both graphs + fwd + bwd(synthetic upstream grad)"
-                    + (" + RCCL grad all-reduce" if world > 1 else "") + ("" if args.no_optim else " + Adam"),
-            "value_cached_topology": "same step replayed on one fixed batch, adjacency built once "
+            "step": f"EVERY step: a new batch (1 of {nb} distinct, rotated) is copied into the idle input slot and "
+                    "its topology work (dc_graph_build: both sorted adjacencies + gcn_norm for both graphs; "
+                    "first-layer hop slabs) runs on a second stream (its own hipGraph, event-ordered) WHILE the "
+                    "current batch does fwd + "
+                    "bwd(synthetic upstream grad)" + (" + RCCL grad all-reduce" if world > 1 else "")
+                    + ("" if args.no_optim else " + Adam") + "; all of it inside the timed region (as "
+                    "loaders.PrefetchLoader + prepare_for do in train())",
+            "value_serial_topology": "same work, but load -> build -> train strictly in sequence on one slot",
+            "value_cached_topology": "one fixed batch replayed, adjacency and first-layer hops built once "
                                      "outside the loop (round-1 headline definition)",
-            "hipgraph": graph is not None, "two_stream_branches": not args.serial_branches,
+            "hipgraph": graph_used, "two_stream_branches": not args.serial_branches,
             "parallelism": f"dp{world}",
         },
     }
@@ -571,19 +785,39 @@ def main():
             per_case.append({"compulsory_bytes": nbytes[0], "us": round(ms * 1e3, 2),
                              "GBps": round(nbytes[0] / ms / 1e6, 1),
                              "frac": round(nbytes[0] / ms / 1e6 / HBM_PEAK_GBS, 4)})
-        # the roofline figure: the four launch shapes of a step INTERLEAVED (soft and rigid
-        # buffers evict each other from L2 as they do inside a step), HIP events on this stream
+        # the roofline figure: the 12 F=256 hop launches of a step IN THE ORDER AND ON THE BUFFERS a
+        # step uses - per branch the forward chain block0 -> 1 -> 2 -> 3 of the layer-2 slab (each hop
+        # reads what the previous one wrote) and the same chain over the transposed adjacency on the
+        # gradient slab, all with the row-maxima side output - HIP events on this stream
+        seq = []
+        for g, n, e in ((gs, n_s, e_s), (gr, n_r, e_r)):
+            slab_f, slab_b = torch.randn(n, 4 * f, device=dev), torch.randn(n, 4 * f, device=dev)
+            rm_f, rm_b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            nbytes = (hop_bytes_compulsory(n, e, f, False), hop_bytes(n, e, f, False))
+            seq.append((g, slab_f, rm_f, False, nbytes))
+            seq.append((g, slab_b, rm_b, True, nbytes))
+
+        def in_step_sequence():
+            for g, slab, rm, bwd, _ in seq:
+                if bwd:       # backward: transposed hops on the masked gradient (block 0 maxima known)
+                    ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm, transposed=True,
+                                     rowmax_has_block0=True)
+                else:
+                    ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm)
+        for _ in range(3):
+            in_step_sequence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(args.kernel_reps):
-            for adj, x, o, rm, nbytes in cases:
-                ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2)
+            in_step_sequence()
         ev1.record()
         torch.cuda.synchronize()
+        nlaunch = 3 * len(seq)
         tot_ms = ev0.elapsed_time(ev1) / args.kernel_reps
-        comp_bytes = float(sum(c[4][0] for c in cases))
-        gath_bytes = float(sum(c[4][1] for c in cases))
+        comp_bytes = float(sum(3 * c[4][0] for c in seq))
+        gath_bytes = float(sum(3 * c[4][1] for c in seq))
         achieved = comp_bytes / tot_ms / 1e6                     # GB/s of compulsory bytes
+        cases = [None] * nlaunch
         out["roofline"] = {
             "bound": "hbm", "kernel": "dc::k_spmm_wave<4,8,true> (F=256 hop + row maxima, as launched in a step)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -597,27 +831,30 @@ def main():
             "l2_served_algorithmic_bytes_per_launch": int(gath_bytes / len(cases)),
             "l2_served_note": "SURVEY.md 8(d) gather model (every neighbour row counted per edge); most of "
                               "these reads are L2 hits, so this figure is NOT an HBM fraction",
-            "measured": "4 step shapes interleaved, HIP events, launch gaps included",
+            "measured": "the 12 F=256 hop launches of a step in step order on step-shaped slabs (forward chains "
+                        "and transposed chains of both branches), HIP events, launch gaps included",
             "cases_isolated": {"soft_fwd": per_case[0], "soft_bwd": per_case[1],
                                "rigid_fwd": per_case[2], "rigid_bwd": per_case[3]},
         }
         out["roofline_mfma"] = dense_roofline(dev, n_s, n_r, args.kernel_reps // 4 or 1)
         if world == 1 and not args.no_strict_fp32:
-            # auditable line: the same with-topology step with every dense block on the fp32 matrix
-            # cores (v_mfma_f32_32x32x2_f32, exact fp32 products) instead of the split fp16 / bf16 forms
+            # auditable line: the headline step with every dense block on the fp32 matrix cores
+            # (v_mfma_f32_32x32x2_f32, exact fp32 products) instead of the split fp16 / bf16 forms
             keep = ops.DENSE_SPLIT_BF16
             ops.DENSE_SPLIT_BF16 = False
             try:
-                clear_cache()
-                graph_f, has_tail_f = capture()
                 k = max(5, args.steps // 2)
-                el = timed(graph_f, has_tail_f, k, 3, rotate=True)
+                el = timed(make_mode("pipelined"), k, 3)
                 out["strict_fp32"] = {"value": round(edges_per_rank * k / el / 1e6, 3), "unit": "M edges/s",
                                       "ms_per_step": round(el / k * 1e3, 4), "steps": k,
                                       "dense_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32), DC_DENSE_SPLIT=0"}
-                del graph_f
             finally:
                 ops.DENSE_SPLIT_BF16 = keep
+        if world == 1 and not args.no_radius100k:
+            try:
+                out["radius100k"] = radius100k(dev, args.kernel_reps // 3 or 3)
+            except Exception as e:  # pragma: no cover
+                out["radius100k"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_full_step:
             out["full_train_step_b4"] = full_step_b4(dev)
             out["full_train_step_b32"] = full_step_b4(dev, steps=5, batch=32)

@@ -27,11 +27,18 @@ _SIGNATURES = {
     "dc_graph_build": (c_int, [_vp, c_int64, c_int64, c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, c_int64, _vp]),
     "dc_hash_i64": (c_int, [_vp, c_int64, _vp, _vp]),
+    "dc_morton_codes": (c_int, [_vp, c_int64, c_int64, POINTER(c_float), POINTER(c_float), _vp, _vp]),
     "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
     "dc_spmm_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                             c_int64, _vp]),
     "dc_spmm_bf16": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                              c_int64, c_int, _vp]),
+    "dc_tag_linear_fwd_bf16": (c_int, [_vp, c_int64, _vp, _vp, c_int, _vp, c_int64, c_int, c_int64, c_int64,
+                                       c_int64, _vp]),
+    "dc_to_bf16": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, c_int64, _vp, c_int64, _vp]),
+    "dc_contact_loss_workspace_bytes": (c_int64, [c_int64]),
+    "dc_contact_loss": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int64, _vp, c_int64, c_int64, c_int64, _vp, _vp,
+                                _vp, _vp, c_int64, _vp]),
     "dc_multihop_max_segment_nodes": (c_int64, []),
     "dc_multihop_max_segment_edges": (c_int64, []),
     "dc_multihop_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, c_int64, c_int, c_int,

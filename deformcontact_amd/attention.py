@@ -24,6 +24,7 @@ from . import _lib
 from .graph import _require_cuda, current_stream_ptr
 from .ops import _i64_array, _ptr_array
 
+import ctypes
 import os
 
 #: soft rows per block: the block's score matrix (x2 in the backward) should stay in the 256 MiB
@@ -73,6 +74,23 @@ def _gemm(L, x, ldx, rows, k, img, fo, out, ldo, xmax, wmax, st, ws=None):
                                        ws.numel() if ws is not None else 0, st), "dc_tag_linear_fwd_h2p")
 
 
+#: The two score-shaped products whose error is AMPLIFIED downstream run on the exact 3-way bf16
+#: split (6 MFMA products, error of fp32 accumulation relative to every element): S = Q K^T feeds
+#: exp() - an absolute error e in a score is a relative error e in its weight - and dP = dO V^T is
+#: cancelled against delta in dS = P * (dP - delta).  The scaled fp16x2 form (3 products) is
+#: accurate to 2^-22 of the operand ROWS' maxima, which for un-normalised scores (the reference has
+#: no 1/sqrt(d)) showed up as 3.5e-5 in the head-weight gradients against a float64 evaluation
+#: (fp32 oracle: 1.5e-6).  ``DC_ATTN_EXACT_SCORES=0`` puts them back on the fp16x2 kernels.
+EXACT_SCORES = os.environ.get("DC_ATTN_EXACT_SCORES", "1") != "0"
+
+
+def _gemm_exact(L, x, ldx, rows, k, w, fo, out, ldo, st):
+    """out[rows, fo] = x[rows, k] . w[fo, k]^T on the six-product bf16 split kernels."""
+    _lib.check(L.dc_tag_linear_fwd_split((ctypes.c_void_p * 1)(x), _i64_array([ldx]),
+                                         _ptr_array([w]), 1, None, 0, out, ldo, rows, k, fo, 6, st),
+               "dc_tag_linear_fwd_split")
+
+
 def _splitk_ws(L, rows, k, fo, dev):
     nb = L.dc_tag_linear_fwd_h2p_workspace_bytes(rows, k, fo)
     return torch.empty(nb, dtype=torch.uint8, device=dev) if nb > 0 else None
@@ -97,6 +115,12 @@ class _AttnCoreFn(torch.autograd.Function):
         st = current_stream_ptr(dev)
         nsp, nrp = _ceil16(ns), _ceil16(nr)
         bq = max(16, min(_ceil16(block_rows), nsp))
+        # softmax over the keys is invariant to adding one vector c to every key (every score of a
+        # row shifts by q.c): the whole computation runs on keys centred at their mean.  Same function,
+        # same gradients (rows of dS sum to zero), but the cancellation-heavy sums of the backward -
+        # dQ = dS K with sum_j dS_ij = 0 - no longer carry the keys' common component, which after a
+        # ReLU encoder is most of their magnitude
+        k = k - k[:nr].mean(dim=0, keepdim=True)
         qp, kp, vp = _pad_rows(q, nsp), _pad_rows(k, nrp), _pad_rows(v, nrp)
         kmax, kimg, _, _ = _prep(L, kp, False, st)                 # rows of K over d
         _, _, vtimg, vtmax = _prep(L, vp, True, st)                # rows of V^T over the keys
@@ -108,7 +132,11 @@ class _AttnCoreFn(torch.autograd.Function):
         ws_o = _splitk_ws(L, bq, nrp, dv, dev)
         for r0 in range(0, nsp, bq):
             rows = min(bq, nsp - r0)
-            _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, s.data_ptr(), nrp, qmax[r0:].data_ptr(), kmax, st)
+            if EXACT_SCORES:
+                _gemm_exact(L, qp[r0:].data_ptr(), d, rows, d, kp, nrp, s.data_ptr(), nrp, st)
+            else:
+                _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, s.data_ptr(), nrp, qmax[r0:].data_ptr(),
+                      kmax, st)
             _lib.check(L.dc_attn_softmax_rows(s.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
                        "dc_attn_softmax_rows")
             _gemm(L, s.data_ptr(), nrp, rows, nrp, vtimg, dv, o[r0:].data_ptr(), dv, ones.data_ptr(), vtmax, st,
@@ -145,11 +173,19 @@ class _AttnCoreFn(torch.autograd.Function):
             rows = min(bq, nsp - r0)
             acc = int(r0 > 0)
             # recompute the block's weights
-            _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, p.data_ptr(), nrp, qmax[r0:].data_ptr(), kmax, st)
+            if EXACT_SCORES:
+                _gemm_exact(L, qp[r0:].data_ptr(), d, rows, d, kp, nrp, p.data_ptr(), nrp, st)
+            else:
+                _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, p.data_ptr(), nrp, qmax[r0:].data_ptr(),
+                      kmax, st)
             _lib.check(L.dc_attn_exp_rows(p.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
                        "dc_attn_exp_rows")
             # dP = dO V^T, then dS = P * (dP - delta) in place
-            _gemm(L, gop[r0:].data_ptr(), dv, rows, dv, vimg, nrp, ds.data_ptr(), nrp, gomax[r0:].data_ptr(), vmax, st)
+            if EXACT_SCORES:
+                _gemm_exact(L, gop[r0:].data_ptr(), dv, rows, dv, vp, nrp, ds.data_ptr(), nrp, st)
+            else:
+                _gemm(L, gop[r0:].data_ptr(), dv, rows, dv, vimg, nrp, ds.data_ptr(), nrp, gomax[r0:].data_ptr(),
+                      vmax, st)
             _lib.check(L.dc_attn_ds_rows(p.data_ptr(), ds.data_ptr(), nrp, rows, nrp, delta[r0:].data_ptr(),
                                          dsmax.data_ptr(), st), "dc_attn_ds_rows")
             # dQ_b = dS K

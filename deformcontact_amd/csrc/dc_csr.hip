@@ -113,33 +113,34 @@ __device__ __forceinline__ void note_big(const Side &sd, int64_t node, int len) 
     if (len > kRankLoop) sd.big[1 + atomicAdd(&sd.big[0], 1)] = (int32_t)node;
 }
 
-// one 1024-thread block per side: counts -> ptr, cursors, big-group list
+// one 1024-thread block per side: counts -> ptr, cursors, big-group list.  Every thread owns one
+// contiguous run of `per` counters (all its loads are issued up front), the block scans the 1024
+// run sums once, and the second pass over the (cache-hot) run writes the offsets.
 __global__ void __launch_bounds__(1024)
 k_scan_small(Build b) {
     const Side &sd = b.s[blockIdx.x];
-    int carry = 0;
-    for (int64_t base = 0; base < b.N; base += 4096) {
-        const int64_t i0 = base + (int64_t)threadIdx.x * 4;
-        int v[4], s = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = i0 + j < b.N ? sd.cnt[i0 + j] : 0;
-            s += v[j];
+    const int64_t per = ((b.N + 1023) / 1024 + 3) & ~int64_t(3);
+    const int64_t beg = (int64_t)threadIdx.x * per;
+    const int64_t end = beg + per < b.N ? beg + per : b.N;
+    int s = 0;
+    for (int64_t i = beg; i < end; i += 4) {
+        if (i + 4 <= end) {
+            const int4 v = *reinterpret_cast<const int4 *>(sd.cnt + i);   // cnt is 16-byte aligned
+            s += v.x + v.y + v.z + v.w;
+        } else {
+            for (int64_t j = i; j < end; ++j) s += sd.cnt[j];
         }
-        int total;
-        int run = carry + block_incl_scan<16>(s, &total) - s;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j < b.N) {
-                sd.ptr[i0 + j] = run;
-                sd.cnt[i0 + j] = run;   // becomes the fill cursor
-                note_big(sd, i0 + j, v[j]);
-            }
-            run += v[j];
-        }
-        carry += total;
     }
-    if (threadIdx.x == 0) sd.ptr[b.N] = carry;
+    int total;
+    int run = block_incl_scan<16>(s, &total) - s;
+    for (int64_t i = beg; i < end; ++i) {
+        const int v = sd.cnt[i];
+        sd.ptr[i] = run;
+        sd.cnt[i] = run;                // becomes the fill cursor
+        note_big(sd, i, v);
+        run += v;
+    }
+    if (threadIdx.x == 0) sd.ptr[b.N] = total;
 }
 
 __global__ void __launch_bounds__(256)
@@ -322,6 +323,31 @@ k_hash_i64(const int64_t *v, int64_t n, unsigned long long *out) {
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
+// 30-bit Morton (Z-order) code of each point: 10 bits per axis after mapping [lo, lo + 1/inv) to
+// [0, 1024); sorting nodes by it puts spatial neighbours - the rows a radius graph's hop gathers -
+// next to each other, i.e. into the same XCD's L2 under the hop's contiguous block -> XCD chunks
+__device__ __forceinline__ unsigned spread10(unsigned v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+k_morton(const float *pos, int64_t ld, int64_t n, float lx, float ly, float lz, float sx, float sy,
+         float sz, int64_t *codes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto q = [](float v, float lo, float sc) {
+        const float t = (v - lo) * sc * 1024.0f;
+        return (unsigned)(t < 0.f ? 0.f : (t > 1023.f ? 1023.f : t));
+    };
+    const unsigned a = q(pos[i * ld], lx, sx), b = q(pos[i * ld + 1], ly, sy), c = q(pos[i * ld + 2], lz, sz);
+    codes[i] = (int64_t)(spread10(a) | (spread10(b) << 1) | (spread10(c) << 2));
+}
+
 static inline int64_t align16(int64_t b) { return (b + 15) & ~int64_t(15); }
 
 static inline int64_t side_bytes(int64_t E, int64_t N) {
@@ -467,4 +493,16 @@ extern "C" int dc_hash_i64(const int64_t *v, int64_t n, uint64_t *out, dc_stream
     hipLaunchKernelGGL(k_hash_i64, dim3(grid), dim3(256), 0, stream, v, n,
                        (unsigned long long *)out);
     return check_launch("dc_hash_i64");
+}
+
+extern "C" int dc_morton_codes(const float *pos, int64_t ld, int64_t n, const float *lo_host,
+                               const float *inv_extent_host, int64_t *codes, dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(n >= 0, "dc_morton_codes: negative size");
+    if (n == 0) return DC_OK;
+    DC_REQUIRE(pos && lo_host && inv_extent_host && codes && ld >= 3, "dc_morton_codes: bad arguments");
+    hipLaunchKernelGGL(k_morton, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pos, ld, n,
+                       lo_host[0], lo_host[1], lo_host[2], inv_extent_host[0], inv_extent_host[1],
+                       inv_extent_host[2], codes);
+    return check_launch("dc_morton_codes");
 }

@@ -17,26 +17,43 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// one thread per destination segment: three short passes (max, sum, write)
+// kSub lanes per destination segment (mean in-degree of the reference's meshes + the self loop is
+// 7): lane `sub` of a group walks edges beg + sub, beg + sub + kSub, ...  Segments are contiguous in
+// p, so the alpha / galpha / ge accesses of a wave are coalesced; max / sum / dot are reduced
+// inside the group with xor shuffles.  Group reductions of floats are order-fixed (deterministic).
+constexpr int kSub = 8;
+
+__device__ __forceinline__ float sub_max(float v) {
+#pragma unroll
+    for (int d = kSub / 2; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, kWave));
+    return v;
+}
+__device__ __forceinline__ float sub_sum(float v) {
+#pragma unroll
+    for (int d = kSub / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 k_gat_softmax_fwd(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
                   const float *__restrict__ a_src, const float *__restrict__ a_dst, float slope,
                   float *__restrict__ alpha, int64_t N) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int beg = ptr[i], end = ptr[i + 1];
-    if (beg >= end) return;
-    const float ad = a_dst[i];
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub;
+    const int sub = threadIdx.x % kSub;
+    const bool live = i < N;
+    const int beg = live ? ptr[i] : 0, end = live ? ptr[i + 1] : 0;
+    const float ad = live ? a_dst[i] : 0.f;
     float m = -INFINITY;
-    for (int p = beg; p < end; ++p) m = fmaxf(m, lrelu(a_src[other[p]] + ad, slope));
+    for (int p = beg + sub; p < end; p += kSub) m = fmaxf(m, lrelu(a_src[other[p]] + ad, slope));
+    m = sub_max(m);
     float s = 0.f;
-    for (int p = beg; p < end; ++p) {
+    for (int p = beg + sub; p < end; p += kSub) {
         const float ex = expf(lrelu(a_src[other[p]] + ad, slope) - m);
         alpha[p] = ex;
         s += ex;
     }
-    const float denom = s + 1e-16f;
-    for (int p = beg; p < end; ++p) alpha[p] = alpha[p] / denom;
+    const float denom = sub_sum(s) + 1e-16f;
+    for (int p = beg + sub; p < end; p += kSub) alpha[p] = alpha[p] / denom;   // own elements only
 }
 
 __global__ void __launch_bounds__(256)
@@ -44,36 +61,62 @@ k_gat_softmax_bwd(const int32_t *__restrict__ ptr, const int32_t *__restrict__ o
                   const float *__restrict__ a_src, const float *__restrict__ a_dst, float slope,
                   const float *__restrict__ alpha, const float *__restrict__ galpha,
                   float *__restrict__ ge, float *__restrict__ g_a_dst, int64_t N) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int beg = ptr[i], end = ptr[i + 1];
-    const float ad = a_dst[i];
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSub;
+    const int sub = threadIdx.x % kSub;
+    const bool live = i < N;
+    const int beg = live ? ptr[i] : 0, end = live ? ptr[i + 1] : 0;
+    const float ad = live ? a_dst[i] : 0.f;
     float dot = 0.f;
-    for (int p = beg; p < end; ++p) dot += alpha[p] * galpha[p];
+    for (int p = beg + sub; p < end; p += kSub) dot += alpha[p] * galpha[p];
+    dot = sub_sum(dot);
     float acc = 0.f;
-    for (int p = beg; p < end; ++p) {
+    for (int p = beg + sub; p < end; p += kSub) {
         const float s = a_src[other[p]] + ad;
         const float g = alpha[p] * (galpha[p] - dot) * (s > 0.f ? 1.0f : slope);
         ge[p] = g;
         acc += g;
     }
-    g_a_dst[i] = acc;
+    acc = sub_sum(acc);
+    if (live && sub == 0) g_a_dst[i] = acc;
 }
 
-// d[p] = <g[i,:], h[other[p],:]> ; one wave per destination row
+// d[p] = <g[i,:], h[other[p],:]> ; one wave per destination row, the row of g held in registers
+// (up to kGRegs * 64 * VEC columns; wider rows re-read it), VEC = 4: 16-byte loads
+template <int VEC>
 __global__ void __launch_bounds__(256)
 k_sddmm(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
         const float *__restrict__ g, int64_t ldg, const float *__restrict__ h, int64_t ldh,
         float *__restrict__ d, int64_t N, int F) {
+    constexpr int kGRegs = 2;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = __builtin_amdgcn_readfirstlane((int)(lb * 4u + (threadIdx.x >> 6)));
     if (row >= N) return;
     const int lane = threadIdx.x & 63;
     const int beg = ptr[row], end = ptr[row + 1];
+    float gr[kGRegs][VEC];
+#pragma unroll
+    for (int j = 0; j < kGRegs; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int c = (j * kWave + lane) * VEC + v;
+            gr[j][v] = c < F ? g[row * ldg + c] : 0.f;
+        }
     for (int p = beg; p < end; ++p) {
         const int64_t s = other[p];
         float acc = 0.f;
-        for (int c = lane; c < F; c += kWave) acc += g[row * ldg + c] * h[s * ldh + c];
+#pragma unroll
+        for (int j = 0; j < kGRegs; ++j) {
+            const int c0 = (j * kWave + lane) * VEC;
+            if (VEC == 4) {
+                if (c0 < F) {
+                    const float4 hv = *reinterpret_cast<const float4 *>(h + s * ldh + c0);
+                    acc += gr[j][0] * hv.x + gr[j][1] * hv.y + gr[j][2] * hv.z + gr[j][3] * hv.w;
+                }
+            } else if (c0 < F) {
+                acc += gr[j][0] * h[s * ldh + c0];
+            }
+        }
+        for (int c = kGRegs * kWave * VEC + lane; c < F; c += kWave) acc += g[row * ldg + c] * h[s * ldh + c];
         acc = wave_sum(acc);
         if (lane == 0) d[p] = acc;
     }
@@ -113,8 +156,8 @@ extern "C" int dc_gat_edge_softmax_fwd(const int32_t *ptr, const int32_t *other,
     DC_REQUIRE(N >= 0, "dc_gat_edge_softmax_fwd: negative N");
     if (N == 0) return DC_OK;
     DC_REQUIRE(ptr && other && a_src && a_dst && alpha, "dc_gat_edge_softmax_fwd: null pointer");
-    hipLaunchKernelGGL(k_gat_softmax_fwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       ptr, other, a_src, a_dst, slope, alpha, N);
+    hipLaunchKernelGGL(k_gat_softmax_fwd, dim3((unsigned)((N * kSub + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, ptr, other, a_src, a_dst, slope, alpha, N);
     return check_launch("dc_gat_edge_softmax_fwd");
 }
 
@@ -126,8 +169,8 @@ extern "C" int dc_gat_edge_softmax_bwd(const int32_t *ptr, const int32_t *other,
     if (N == 0) return DC_OK;
     DC_REQUIRE(ptr && other && a_src && a_dst && alpha && galpha && ge && g_a_dst,
                "dc_gat_edge_softmax_bwd: null pointer");
-    hipLaunchKernelGGL(k_gat_softmax_bwd, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       ptr, other, a_src, a_dst, slope, alpha, galpha, ge, g_a_dst, N);
+    hipLaunchKernelGGL(k_gat_softmax_bwd, dim3((unsigned)((N * kSub + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, ptr, other, a_src, a_dst, slope, alpha, galpha, ge, g_a_dst, N);
     return check_launch("dc_gat_edge_softmax_bwd");
 }
 
@@ -138,8 +181,13 @@ extern "C" int dc_sddmm_f32(const int32_t *ptr, const int32_t *other, const floa
     if (N == 0) return DC_OK;
     DC_REQUIRE(ptr && other && g && h && d, "dc_sddmm_f32: null pointer");
     DC_REQUIRE(ldg >= F && ldh >= F, "dc_sddmm_f32: leading dimension smaller than F");
-    hipLaunchKernelGGL(k_sddmm, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       ptr, other, g, ldg, h, ldh, d, N, (int)F);
+    const bool vec4 = F % 4 == 0 && ldg % 4 == 0 && ldh % 4 == 0 && (((uintptr_t)g | (uintptr_t)h) & 15) == 0;
+    if (vec4)
+        hipLaunchKernelGGL((k_sddmm<4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           ptr, other, g, ldg, h, ldh, d, N, (int)F);
+    else
+        hipLaunchKernelGGL((k_sddmm<1>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           ptr, other, g, ldg, h, ldh, d, N, (int)F);
     return check_launch("dc_sddmm_f32");
 }
 

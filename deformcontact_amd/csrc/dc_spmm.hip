@@ -19,6 +19,8 @@
 //     L2 instead of being re-fetched by all eight;
 //   * multiply and add are rounded separately (no FMA contraction) and summed
 //     in p order: bit-identical to a serial scatter_add_ over the stable order.
+#include <stdlib.h>
+
 #include "dc_common.h"
 
 #pragma clang fp contract(off)
@@ -53,8 +55,12 @@ __device__ __forceinline__ float vabsmax(const float4 &v) {
 // RM: also write rowmax[row] = max |y[row,:]| (bit 0 of rm_mode: include |x[row,:]|, the
 // wave's OWN input row; bit 1: keep the larger of the new value and what rowmax[row] holds) -
 // the row scales of the fp16x2 dense block (dc_dense_split.hip) at no extra pass.
+// SGPR budget: a 256-thread block is admitted 8 per CU only up to 80 SGPRs (82-96 -> 7,
+// MI355X_MICROARCH.md "Residency"); the row-maxima variant needed 85 and ran with one block per CU
+// fewer - the whole +1.3 us it cost over the plain hop (r02 hop_exp).  The attribute caps the
+// allocation (the few extra scalars live in VGPR lanes).
 template <int VEC, int U, bool RM = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
             const float *__restrict__ w, const float *__restrict__ x, int64_t ldx,
             const float *addend, int64_t ldadd, float *y, int64_t ldy,
@@ -67,7 +73,11 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     if (row >= N) return;
     const int lane = threadIdx.x & 63;
     const int beg = ptr[row], end = ptr[row + 1];
+    // the stored maximum this launch joins with (mode bit 1) is fetched NOW, with the segment
+    // bounds, not after the row has been reduced: at the end of the wave it was one more exposed
+    // memory latency per row (+1.3 us on the 17 us launch, r02 hop_exp)
     float rmax = 0.f;
+    if (RM && (rm_mode & 2)) rmax = rowmax[row];
 
     for (int c = lane * VEC; c < F; c += kWave * VEC) {
         V acc = addend ? *reinterpret_cast<const V *>(addend + row * ldadd + c) : vzero(V{});
@@ -97,10 +107,7 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     if (RM) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
-        if (lane == 0) {
-            if (rm_mode & 2) rmax = fmaxf(rmax, rowmax[row]);
-            rowmax[row] = rmax;
-        }
+        if (lane == 0) rowmax[row] = rmax;
     }
 }
 
@@ -401,7 +408,13 @@ static void dispatch_bf16(const int32_t *ptr, const int32_t *other, const float 
     // measured (tools/hop_stress.py, r01): while x sits in L2 / the Infinity Cache the plain
     // half-wave kernel is as fast or faster (14.3 vs 16.3 us at the everyday shape); once x spills
     // to HBM the scalar-index row-pair kernel wins (842 vs 990 us at 2.1 M rows)
-    if (x8 && F >= 256 && N * ldx * 2 > (int64_t)128 << 20) {
+    // DC_SPMM_BF16_KERNEL = pair | x8 overrides the size rule (experiments)
+    static const int forced = [] {
+        const char *e = getenv("DC_SPMM_BF16_KERNEL");
+        return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 2 : 0));
+    }();
+    const bool pair = forced ? forced == 1 : N * ldx * 2 > (int64_t)128 << 20;
+    if (x8 && F >= 256 && pair) {
         const unsigned grid = (unsigned)((N + 7) / 8);
         hipLaunchKernelGGL((k_spmm_bf16_pair<8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
                            other, w, x, ldx, addend, ldadd, y, ldy, N, F);

@@ -264,6 +264,51 @@ def content_hash(t: torch.Tensor) -> int:
     return int(out.item()) & 0xFFFFFFFFFFFFFFFF
 
 
+class NodeOrder:
+    """A relabelling of the nodes of one graph: ``perm[new] = old``.
+
+    Message passing commutes with it: run the convs on ``apply(x)`` / ``relabel(edge_index)`` and
+    ``undo`` the result.  The sorted adjacency orders every node's neighbours by EDGE id, which the
+    relabelling leaves alone, so the per-row sums - and therefore the outputs - are bit-identical
+    to the unordered computation; only where rows live in memory changes.  ``morton(pos)`` sorts
+    by Z-order code: for a radius graph over an unordered point cloud
+    (``/root/reference/utils/pointcloud_utils.py:7-13``) that turns the hop's neighbour gathers from
+    random reads of the whole feature matrix into reads of nearby rows (one XCD's L2)."""
+
+    def __init__(self, perm: torch.Tensor):
+        self.perm = perm.to(torch.int64).contiguous()
+        self.inv = torch.empty_like(self.perm)
+        self.inv[self.perm] = torch.arange(self.perm.numel(), device=self.perm.device)
+
+    @classmethod
+    def morton(cls, pos: torch.Tensor) -> "NodeOrder":
+        _require_cuda(pos, "pos")
+        if pos.dim() != 2 or pos.size(1) < 3 or pos.dtype != torch.float32:
+            raise ValueError("NodeOrder.morton: pos must be float32 [N, >=3]")
+        import ctypes
+        n = pos.size(0)
+        pos = pos if pos.stride(1) == 1 else pos.contiguous()
+        lo = pos[:, :3].amin(0).cpu() if n else torch.zeros(3)
+        hi = pos[:, :3].amax(0).cpu() if n else torch.ones(3)
+        inv = [1.0 / max(float(hi[a] - lo[a]), 1e-30) for a in range(3)]
+        codes = torch.empty(n, dtype=torch.int64, device=pos.device)
+        rc = _lib.lib().dc_morton_codes(pos.data_ptr(), pos.stride(0), n,
+                                        (ctypes.c_float * 3)(*[float(v) for v in lo]),
+                                        (ctypes.c_float * 3)(*inv), codes.data_ptr(),
+                                        current_stream_ptr(pos.device))
+        _lib.check(rc, "dc_morton_codes")
+        return cls(torch.sort(codes, stable=True).indices)
+
+    def relabel(self, edge_index: torch.Tensor) -> torch.Tensor:
+        return self.inv[edge_index]
+
+    def apply(self, x: torch.Tensor) -> torch.Tensor:
+        return x.index_select(0, self.perm)
+
+    def undo(self, y: torch.Tensor) -> torch.Tensor:
+        return y.index_select(0, self.inv)
+
+
 def register(edge_index: torch.Tensor, g: GraphIndex) -> None:
     """Make ``g`` (built elsewhere, e.g. by ``loaders.TopologyCache`` on the loader's stream) the
     cached adjacency of ``edge_index``."""

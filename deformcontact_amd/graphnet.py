@@ -81,10 +81,9 @@ class ContactEncoder(nn.Module):
         if not (self.overlap_branches and x_s.is_cuda and x_r.is_cuda):
             return (self._branch(self.conv_layers_resting, x_s, e_s),
                     self._branch(self.conv_layers_rigid, x_r, e_r))
-        # topology is built (and cached) on the caller's stream before the fork
-        for convs, x, e in ((self.conv_layers_resting, x_s, e_s), (self.conv_layers_rigid, x_r, e_r)):
-            if len(convs) and hasattr(convs[0], "graph"):
-                convs[0].graph(e, x.size(0))
+        # each branch builds (or finds) its own sorted adjacency on its own stream: the two
+        # dc_graph_build pipelines of a new batch run side by side; every later use of the rigid
+        # one on the caller's stream is ordered behind the join below
         main = torch.cuda.current_stream(x_s.device)
         side = self._side_stream(x_s.device)
         side.wait_stream(main)

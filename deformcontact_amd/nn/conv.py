@@ -85,6 +85,8 @@ class TAGConv(nn.Module):
         return graph_index(edge_index, num_nodes, **self.graph_flags())
 
     supports_fused_relu = True
+    #: dtype of the output when the input is bfloat16 (the bf16-storage forward path)
+    bf16_out = torch.bfloat16
 
     def slab_width(self) -> int:
         return ops.tag_slab_geometry(self.in_channels, self.K)[2]
@@ -95,6 +97,18 @@ class TAGConv(nn.Module):
         applies right after (``models/model.py:71,77``) into the MFMA epilogue; ``next_conv`` (the
         TAGConv that consumes this output) lets the output be written straight into that
         layer's hop slab."""
+        if x.dtype == torch.bfloat16:
+            # bf16-STORED features (BASELINE.json configs[4]): bf16 hops with fp32 accumulation + the
+            # bf16 MFMA dense block; forward only.  ``out_dtype`` of the last layer: self.bf16_out
+            _require_cuda(x, "x")
+            _require_cuda(edge_index, "edge_index")
+            if x.dim() != 2 or x.size(1) != self.in_channels:
+                raise ValueError(f"x must be [N, {self.in_channels}], got {tuple(x.shape)}")
+            g = self.graph(edge_index, x.size(0))
+            nk = next_conv.K if (isinstance(next_conv, TAGConv)
+                                 and next_conv.in_channels == self.out_channels) else None
+            return ops.tag_conv_bf16(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu,
+                                     out_dtype=self.bf16_out, next_k=nk)
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
         nxt = None

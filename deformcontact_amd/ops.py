@@ -242,18 +242,18 @@ _HOP_CACHE_ENTRIES = 2
 
 
 def _hop_cache_key(x: torch.Tensor, k: int, wpad: int, want_rowmax: bool):
-    return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), int(k), int(wpad),
-            bool(want_rowmax))
+    return (x.data_ptr(), tuple(x.shape), tuple(x.stride()), int(k), int(wpad), bool(want_rowmax))
 
 
-def _hop_cache_get(g, key, dev):
+def _hop_cache_get(g, key, x, dev):
+    """(slab, rowmax) cached for this input tensor in its CURRENT state, or None."""
     cache = getattr(g, "_hop_cache", None)
     if not cache or key not in cache:
         return None
     from .graph import capture_id
     cid = capture_id(dev)
-    slab, rowmax, ecid, _ref = cache[key]
-    if ecid == cid or (cid != 0 and g._static_ok):
+    slab, rowmax, ecid, _ref, version = cache[key]
+    if version == x._version and (ecid == cid or (cid != 0 and g._static_ok)):
         return slab, rowmax
     return None
 
@@ -261,22 +261,27 @@ def _hop_cache_get(g, key, dev):
 def _hop_cache_put(g, key, x, slab, rowmax, dev):
     from .graph import capture_id
     cache = g.__dict__.setdefault("_hop_cache", {})
-    while len(cache) >= _HOP_CACHE_ENTRIES:
-        cache.pop(next(iter(cache)))
-    cache[key] = (slab, rowmax, capture_id(dev), x)      # x kept alive: its address is the key
+    if key not in cache:
+        while len(cache) >= _HOP_CACHE_ENTRIES:
+            cache.pop(next(iter(cache)))
+    # x kept alive: its address is part of the key
+    cache[key] = (slab, rowmax, capture_id(dev), x, x._version)
 
 
-def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool):
-    """Pack ``x`` into block 0 of a fresh ``[N, wpad]`` slab and run the K hops (+ row maxima)."""
+def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool, into=None):
+    """Pack ``x`` into block 0 of a ``[N, wpad]`` slab (fresh, or the buffers ``into`` = (slab,
+    rowmax) of an earlier call) and run the K hops (+ row maxima)."""
     n, fi = x.shape
     concat, width, wpad = tag_slab_geometry(fi, k)
     dev = x.device
-    slab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
+    slab = into[0] if into is not None else torch.empty((n, wpad), dtype=torch.float32, device=dev)
     xin = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
     _lib.check(_lib.lib().dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), wpad, n,
                                             fi, width, wpad, current_stream_ptr(dev)),
                "dc_tag_pack_input")
-    rowmax = torch.empty(n, dtype=torch.float32, device=dev) if want_rowmax else None
+    rowmax = None
+    if want_rowmax:
+        rowmax = into[1] if into is not None else torch.empty(n, dtype=torch.float32, device=dev)
     chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax)
     return slab, rowmax
 
@@ -287,17 +292,24 @@ def _tag_uses_h2(fi: int, k: int) -> bool:
             and fi % 16 == 0 and wpad % 4 == 0)
 
 
-def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3) -> None:
+def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3, refresh: bool = False) -> None:
     """Compute and cache, on the current stream, the hop slab a ``TAGConv(in, out, K=k)`` layer
     will need for the no-grad input ``x`` over topology ``g`` (what ``loaders.PrefetchLoader`` does
-    for the next batch while the current one trains)."""
+    for the next batch while the current one trains).  ``refresh``: ``x`` / ``g`` are static
+    buffers that have been refilled - recompute INTO the buffers cached for them earlier (their
+    addresses may be baked into captured graphs) instead of allocating new ones."""
     _require_cuda(x, "x")
     if not HOP_CACHE or k < 1 or x.dtype != torch.float32 or x.dim() != 2:
         return
     fi = x.size(1)
     want = _tag_uses_h2(fi, k)
     key = _hop_cache_key(x, k, tag_slab_geometry(fi, k)[2], want)
-    if _hop_cache_get(g, key, x.device) is None:
+    if refresh:
+        old = getattr(g, "_hop_cache", {}).get(key)
+        into = (old[0], old[1]) if old is not None else None
+        slab, rowmax = _build_input_slab(g, x, k, want, into=into)
+        _hop_cache_put(g, key, x, slab, rowmax, x.device)
+    elif _hop_cache_get(g, key, x, x.device) is None:
         slab, rowmax = _build_input_slab(g, x, k, want)
         _hop_cache_put(g, key, x, slab, rowmax, x.device)
 
@@ -374,7 +386,7 @@ class _TagConvFn(torch.autograd.Function):
             key = None
             if HOP_CACHE and g is not None and k >= 1 and not ctx.needs_input_grad[1]:
                 key = _hop_cache_key(x, k, wpad, h2)
-                hit = _hop_cache_get(g, key, dev)
+                hit = _hop_cache_get(g, key, x, dev)
                 if hit is not None:
                     slab, rowmax = hit
             if slab is None:
@@ -563,6 +575,68 @@ def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
 
 
 # --------------------------------------------------------------------------- #
+# TAGConv over bf16-stored features (BASELINE.json configs[4]) - forward only
+# --------------------------------------------------------------------------- #
+_SLAB_TAG_BF16 = "_dc_hop_slab_bf16"
+
+
+def tag_conv_bf16(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
+                  out_dtype: torch.dtype = torch.bfloat16, next_k: Optional[int] = None) -> torch.Tensor:
+    """``TAGConv.forward`` (+ optional ReLU) with the features STORED as bfloat16: K hops
+    ``dc_spmm_bf16`` (bf16 rows gathered, fp32 running sum in the stable edge order, one rounding
+    per stored element) into a ``[N, (K+1) * Fi]`` bf16 slab, then ONE bf16 MFMA dense block
+    (``dc_tag_linear_fwd_bf16``, fp32 accumulate) with the layer's weights rounded to bf16.  What
+    ``conv(x.bfloat16(), edge_index)`` reaches under ``torch.autocast(bfloat16)`` in PyG, with the
+    aggregation kept in fp32.  Forward only (inference / the HBM-roofline stress config): raises
+    when a gradient is requested.  ``next_k``: K of the bf16 TAGConv layer that consumes the output
+    - it is then written as column block 0 of that layer's slab (bf16 output only)."""
+    _require_cuda(x, "x")
+    if x.dtype != torch.bfloat16 or x.dim() != 2:
+        raise ValueError("tag_conv_bf16: x must be a 2-D bfloat16 tensor")
+    if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)):
+        raise NotImplementedError("the bf16-storage TAGConv path is forward-only: call it under "
+                                  "torch.no_grad() (the fp32 path has the backward)")
+    n, fi = x.shape
+    k = len(weights) - 1
+    fo = weights[0].size(0)
+    width = (k + 1) * fi
+    if width % 32 != 0 or fi % 8 != 0:
+        raise ValueError(f"tag_conv_bf16: (K+1)*Fi = {width} must be a multiple of 32 and Fi of 8")
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("tag_conv_bf16: out_dtype must be bfloat16 or float32")
+    dev = x.device
+    L = _lib.lib()
+    st = current_stream_ptr(dev)
+    base = x._base
+    if (base is not None and getattr(base, _SLAB_TAG_BF16, None) == (n, fi, width)
+            and tuple(base.shape) == (n, width) and base.is_contiguous()
+            and x.data_ptr() == base.data_ptr() and x.stride() == (width, 1)):
+        slab = base                                   # the previous layer wrote block 0 in place
+    else:
+        slab = torch.empty((n, width), dtype=torch.bfloat16, device=dev)
+        slab[:, :fi].copy_(x)
+    for j in range(k):
+        hop_bf16(g.fwd, slab[:, j * fi:(j + 1) * fi], out=slab[:, (j + 1) * fi:(j + 2) * fi],
+                 weighted=g.normalize, out_dtype=torch.bfloat16)
+    ws = [w.detach().contiguous() for w in weights]
+    wcat = torch.empty((fo, width), dtype=torch.bfloat16, device=dev)
+    _lib.check(L.dc_to_bf16(_ptr_array(ws), k + 1, fo, fi, fi, wcat.data_ptr(), width, st), "dc_to_bf16")
+    if next_k is not None and out_dtype == torch.bfloat16:
+        nwidth = (next_k + 1) * fo
+        nxt = torch.empty((n, nwidth), dtype=torch.bfloat16, device=dev)
+        setattr(nxt, _SLAB_TAG_BF16, (n, fo, nwidth))
+        out = nxt[:, :fo]
+    else:
+        out = torch.empty((n, fo), dtype=out_dtype, device=dev)
+    b = bias.detach().contiguous() if bias is not None else None
+    rc = L.dc_tag_linear_fwd_bf16(slab.data_ptr(), width, wcat.data_ptr(),
+                                  b.data_ptr() if b is not None else None, int(relu), out.data_ptr(),
+                                  out.stride(0), int(out.dtype == torch.bfloat16), n, width, fo, st)
+    _lib.check(rc, "dc_tag_linear_fwd_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # GATConv (heads = 1): edge softmax + weighted aggregation
 # --------------------------------------------------------------------------- #
 def _spmm_w(adj: SortedAdjacency, w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -626,3 +700,49 @@ class _GatAggregateFn(torch.autograd.Function):
 
 def gat_aggregate(g: GraphIndex, h, a_src, a_dst, slope: float) -> torch.Tensor:
     return _GatAggregateFn.apply(g, h, a_src, a_dst, float(slope))
+
+
+# --------------------------------------------------------------------------- #
+# the two training losses in one pass (train.py:51-53, models/losses.py:7-19)
+# --------------------------------------------------------------------------- #
+class _ContactLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g: GraphIndex, pred: torch.Tensor, target: torch.Tensor):
+        L = _lib.lib()
+        n = pred.size(0)
+        dev = pred.device
+        pred_c = pred if pred.stride(1) == 1 else pred.contiguous()
+        tgt_c = target if target.stride(1) == 1 else target.contiguous()
+        g1 = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        g2 = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        nb = L.dc_contact_loss_workspace_bytes(n)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        rc = L.dc_contact_loss(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.bwd.ptr.data_ptr(),
+                               g.bwd.other.data_ptr(), pred_c.data_ptr(), pred_c.stride(0),
+                               tgt_c.data_ptr(), tgt_c.stride(0), n, g.num_input_edges, g1.data_ptr(),
+                               g2.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, current_stream_ptr(dev))
+        _lib.check(rc, "dc_contact_loss")
+        ctx.save_for_backward(g1, g2)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_gcl):
+        g1, g2 = ctx.saved_tensors
+        return None, g1 * g_l1 + g2 * g_gcl, None
+
+
+def contact_losses(g: GraphIndex, pred_pos: torch.Tensor, target_pos: torch.Tensor):
+    """``(L1Loss(pred, target), GradientConsistencyLoss(pred, target))`` over the edge set of ``g``
+    (``train.py:51-53``) in one node pass, differentiable w.r.t. ``pred_pos`` (the target is data)."""
+    _require_cuda(pred_pos, "pred_pos")
+    for name, t in (("pred_pos", pred_pos), ("target_pos", target_pos)):
+        if t.dim() != 2 or t.size(1) != 3 or t.dtype != torch.float32:
+            raise ValueError(f"contact_losses: {name} must be float32 [N, 3]")
+    if pred_pos.shape != target_pos.shape or pred_pos.size(0) != g.num_nodes:
+        raise ValueError("contact_losses: pred / target / graph sizes differ")
+    if g.self_loops:
+        raise ValueError("contact_losses: needs the adjacency of the raw edge set (no self-loop rewriting)")
+    if pred_pos.size(0) == 0:
+        raise ValueError("contact_losses: empty graph")
+    return _ContactLossFn.apply(g, pred_pos, target_pos)

@@ -24,13 +24,45 @@ from .graphnet import EVERYDAY_NETWORK, gradient_consistency_loss, load_model
 from .loaders import PrefetchLoader, SyntheticEverydayDataset, iterate_batches, to_batches
 
 
+#: both losses (and their gradients) in ONE node pass of the library (``ops.contact_losses``) when the
+#: batches live on a HIP device and prediction and target share their edge set (they do:
+#: ``train.py:36-37`` batches the rest and the deformed graph of the same meshes); ``DC_FUSED_LOSS=0``
+#: keeps the stock PyTorch formulation of ``models/losses.py``.
+FUSED_LOSS = os.environ.get("DC_FUSED_LOSS", "1") != "0"
+
+
+def _same_edges(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a is b or (a.shape == b.shape and a.data_ptr() == b.data_ptr())
+
+
 def losses(model, rest, deff, rig, lambda_gradient: float = 1.0) -> Dict[str, torch.Tensor]:
     pred = model(rest, rig)
     pred.pos = pred.pos - rest.pos
-    tgt = deff.clone()
-    tgt.pos = deff.pos - rest.pos
-    l1 = F.l1_loss(pred.pos, tgt.pos)
-    gcl = gradient_consistency_loss(pred, tgt)
+    tgt_pos = deff.pos - rest.pos
+    ei = rest.edge_index
+    if (FUSED_LOSS and pred.pos.is_cuda and pred.pos.dtype == torch.float32 and pred.pos.size(0) > 0
+            and ei.size(1) > 0 and pred.edge_index.shape == ei.shape and deff.edge_index.shape == ei.shape):
+        from . import ops
+        from .graph import graph_index
+        # The loss runs over the adjacency the encoder built for rest.edge_index (a cache hit).  The
+        # reference takes the edges from pred (a clone of the rest batch, model.py:91) and from the
+        # deformed batch (the same triangles, train.py:36-37): that they equal rest's is CHECKED on
+        # the device, without a host sync - a mismatch poisons both losses with NaN.
+        bad = None
+        for other in (pred.edge_index, deff.edge_index):
+            if not _same_edges(other, ei):
+                ne = (other != ei).any()
+                bad = ne if bad is None else (bad | ne)
+        g = graph_index(ei, pred.pos.size(0))
+        l1, gcl = ops.contact_losses(g, pred.pos, tgt_pos)
+        if bad is not None:
+            nan = torch.full_like(l1, float("nan"))
+            l1, gcl = torch.where(bad, nan, l1), torch.where(bad, nan, gcl)
+    else:
+        tgt = deff.clone()
+        tgt.pos = tgt_pos
+        l1 = F.l1_loss(pred.pos, tgt.pos)
+        gcl = gradient_consistency_loss(pred, tgt)
     return {"loss": l1 + lambda_gradient * gcl, "l1": l1, "consistency": gcl}
 
 

@@ -94,6 +94,13 @@ int dc_graph_build(const int64_t *edge_index, int64_t E, int64_t N, int self_loo
                    int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
                    int32_t *status, void *workspace, int64_t workspace_bytes, dc_stream_t stream);
 
+/* 30-bit Morton (Z-order) code of every point of pos [n, >=3] (fp32, leading dimension ld): each
+ * axis is mapped from [lo[a], lo[a] + 1 / inv_extent[a]) to 10 bits (lo / inv_extent are HOST
+ * arrays of 3 floats).  The host sorts nodes by it (graph.NodeOrder.morton) so that the rows a
+ * radius-graph hop gathers (utils/pointcloud_utils.py:10) are neighbours in memory. */
+int dc_morton_codes(const float *pos, int64_t ld, int64_t n, const float *lo_host,
+                    const float *inv_extent_host, int64_t *codes, dc_stream_t stream);
+
 /* Order-dependent 64-bit content hash of an int64 device array (e.g. edge_index) into
  * out[1] (device): the key of the host's per-topology cache (loaders.TopologyCache), so a batch
  * whose edge_index has been seen before reuses its sorted adjacency. */
@@ -134,6 +141,36 @@ int dc_spmm_bf16(const int32_t *ptr, const int32_t *other, const float *w, const
 int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
                        int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
                        int64_t N, int64_t F, float *rowmax, int mode, dc_stream_t stream);
+
+/* ---- the dense block over bf16-STORED features (BASELINE.json configs[4]) ------------------
+ * out[N,Fo] = act(A[N,K] . W[Fo,K]^T + bias) with A and W bf16 (uint16 bit patterns, K-contiguous,
+ * K % 32 == 0, 16-byte aligned, lda % 8 == 0), fp32 accumulate on v_mfma_f32_32x32x16_bf16, out
+ * fp32 (out_is_bf16 = 0) or bf16 rounded to nearest even (the next layer's hop slab).  A is the hop
+ * slab dc_spmm_bf16 leaves, W the layer's lins[k].weight concatenated along K by dc_to_bf16.  This is
+ * the precision PyG reaches under torch.autocast(bfloat16) (nn/dense/linear.py -> F.linear in bf16),
+ * not the fp32-accurate split forms above. */
+int dc_tag_linear_fwd_bf16(const uint16_t *a, int64_t lda, const uint16_t *w, const float *bias,
+                           int relu, void *out, int64_t ldo, int out_is_bf16, int64_t N, int64_t K,
+                           int64_t Fo, dc_stream_t stream);
+/* dst[r, s*cols + c] = bf16(srcs[s][r, c]) (round to nearest even): fp32 matrices [rows, cols]
+ * (leading dimension ld_src) concatenated along the columns into one bf16 matrix. */
+int dc_to_bf16(const float *const *srcs, int nseg, int64_t rows, int64_t cols, int64_t ld_src,
+               uint16_t *dst, int64_t ld_dst, dc_stream_t stream);
+
+/* ---- the two training losses (train.py:51-53) ------------------------------------------------
+ * losses[0] = L1Loss(pred, target) = mean |pred - target| over the [N,3] positions (train.py:51);
+ * losses[1] = GradientConsistencyLoss (models/losses.py:7-19) = (1/E) sum over edges of
+ *             || (target[dst] - target[src]) - (pred[dst] - pred[src]) ||_2 ;
+ * grad_l1 / grad_gcl [N,3] = their gradients w.r.t. pred (zero gradient at a zero edge norm, as
+ * torch's norm backward).  One pass over the nodes through BOTH sorted adjacencies of the edge set
+ * (the *_f / *_b arrays of dc_graph_build; weights unused), deterministic two-stage sums, no float
+ * atomics.  Replaces ~20 ATen launches (4 row gathers, norm, sums, L1 and their backward). */
+int64_t dc_contact_loss_workspace_bytes(int64_t N);
+int dc_contact_loss(const int32_t *ptr_f, const int32_t *other_f, const int32_t *ptr_b,
+                    const int32_t *other_b, const float *pred, int64_t ld_pred, const float *target,
+                    int64_t ld_target, int64_t N, int64_t E, float *grad_l1, float *grad_gcl,
+                    float *losses /* [2] */, void *workspace, int64_t workspace_bytes,
+                    dc_stream_t stream);
 
 /* ---- K chained hops in one launch (block-diagonal batches) -------------------
  * TAGConv.forward calls propagate K = 3 times in a row (x_k = A_hat x_{k-1}); its backward runs

@@ -22,6 +22,38 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def row_rel_err(a, b):
+    """max over rows i of  max_j |a_ij - b_ij| / max_j |b_ij|  (rows of b that are all zero are
+    compared absolutely against the global scale): stricter than ``rel_err`` for rows whose
+    magnitude is far below the tensor's maximum."""
+    a = np.asarray(a, dtype=np.float64).reshape(len(a), -1)
+    b = np.asarray(b, dtype=np.float64).reshape(len(b), -1)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    scale = np.abs(b).max(axis=1)
+    scale = np.where(scale > 0, scale, max(np.abs(b).max(), 1e-30))
+    return float((np.abs(a - b).max(axis=1) / scale).max())
+
+
+def assert_parity(got, ref32, truth64=None, tol=1e-5, name="", metric=None):
+    """north_star's bar: ``metric(got, fp32 oracle) < tol`` (1e-5).  Where two correct fp32
+    evaluations legitimately differ by more (gradients through several layers: different but
+    equally valid summation orders), the widening must be JUSTIFIED against a float64 evaluation
+    of the same maths: the HIP result has to be within ``tol`` of the float64 truth, or at most
+    twice as far from it as the fp32 oracle itself is.  Returns the HIP-vs-oracle distance."""
+    metric = metric or rel_err
+    d = metric(got, ref32)
+    if d < tol:
+        return d
+    assert truth64 is not None, f"{name}: {d:.2e} >= {tol:g} vs the fp32 oracle and no float64 truth given"
+    e_h, e_o = metric(got, truth64), metric(ref32, truth64)
+    assert e_h <= max(2 * e_o, tol), (
+        f"{name}: HIP vs fp32 oracle {d:.2e} >= {tol:g}, and vs the float64 truth the HIP path is off by "
+        f"{e_h:.2e} while the fp32 oracle is off by {e_o:.2e}: not explained by fp32 rounding of the oracle")
+    return d
+
+
 class G:
     """duck-typed graph batch"""
 

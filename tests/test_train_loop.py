@@ -107,3 +107,61 @@ def test_graphed_train_loop_follows_oracle_curve_with_changing_batches(tmp_path)
     train(SMALL, device="cuda:0", epochs=1, num_train=6, num_val=2, batch_size=2, out_dir=str(tmp_path),
           soft_vertices=64, sphere_resolution=4, capture=False, stats=stats)   # loader-prepared topology
     assert stats["steps"] == 3 and stats["graph_replays"] == 0
+
+
+@pytest.mark.gpu
+def test_fused_contact_losses_match_reference_formulation_and_golden():
+    """ops.contact_losses (one node pass: L1 + gradient consistency + both gradients) against the
+    stock formulation of models/losses.py / nn.L1Loss in float64, the golden fixture produced by the
+    reference's own losses.py, and - through train.losses - the device-side topology check."""
+    from deformcontact_amd import ops
+    from deformcontact_amd import train as dc_train
+    from deformcontact_amd.graph import graph_index
+    from deformcontact_amd.graphnet import gradient_consistency_loss
+    from tests.helpers import G, load_golden, random_multigraph
+    dev = "cuda:0"
+    z = load_golden("gcl_loss.npz")
+    keys = {k: z[k] for k in z}
+    n, e = 500, 4000
+    ei = torch.from_numpy(random_multigraph(n, e, 3)).to(dev)
+    gen = torch.Generator().manual_seed(0)
+    pred = torch.randn(n, 3, generator=gen).to(dev).requires_grad_(True)
+    tgt = torch.randn(n, 3, generator=gen).to(dev)
+    g = graph_index(ei, n)
+    l1, gcl = ops.contact_losses(g, pred, tgt)
+    (l1 + 0.7 * gcl).backward()
+    p64 = pred.detach().double().cpu().requires_grad_(True)
+    t64 = tgt.double().cpu()
+    r_l1 = torch.nn.functional.l1_loss(p64, t64)
+    r_gcl = gradient_consistency_loss(G(None, ei.cpu(), p64), G(None, ei.cpu(), t64))
+    (r_l1 + 0.7 * r_gcl).backward()
+    assert abs(float(l1) - float(r_l1)) <= 1e-6 * abs(float(r_l1))
+    assert abs(float(gcl) - float(r_gcl)) <= 1e-6 * abs(float(r_gcl))
+    assert np.abs(pred.grad.cpu().numpy() - p64.grad.numpy()).max() <= 1e-5 * np.abs(p64.grad.numpy()).max()
+    # zero edge vectors (duplicates of a self loop): finite, zero-gradient terms as torch's norm
+    ei0 = torch.tensor([[0, 1, 2, 2], [1, 0, 2, 2]], device=dev)
+    p0 = torch.zeros(3, 3, device=dev, requires_grad=True)
+    a, b = ops.contact_losses(graph_index(ei0, 3), p0, torch.zeros(3, 3, device=dev))
+    (a + b).backward()
+    assert float(a) == 0.0 and float(b) == 0.0 and torch.isfinite(p0.grad).all()
+    # golden: the reference's GradientConsistencyLoss on a fixture
+    gi = graph_index(torch.from_numpy(keys["edge_index"]).to(dev), keys["pred_pos"].shape[0])
+    pp = torch.from_numpy(keys["pred_pos"]).to(dev).requires_grad_(True)
+    _, gg = ops.contact_losses(gi, pp, torch.from_numpy(keys["tgt_pos"]).to(dev))
+    gg.backward()
+    assert abs(float(gg) - float(keys["loss"])) <= 1e-5 * abs(float(keys["loss"]))
+    assert np.abs(pp.grad.cpu().numpy() - keys["grad_pred"]).max() <= 1e-5 * np.abs(keys["grad_pred"]).max()
+    # through train.losses: fused == stock on a real batch, NaN when the deformed batch's edges differ
+    model = load_model(SMALL).to(dev)
+    rest, deff, rig = loaders.to_batches(_batches(2, 2)[0], dev)
+    fused = dc_train.losses(model, rest, deff, rig)
+    old, dc_train.FUSED_LOSS = dc_train.FUSED_LOSS, False
+    try:
+        stock = dc_train.losses(model, rest, deff, rig)
+    finally:
+        dc_train.FUSED_LOSS = old
+    for k in ("loss", "l1", "consistency"):
+        assert abs(float(fused[k]) - float(stock[k])) <= 1e-5 * abs(float(stock[k])), k
+    deff.edge_index = deff.edge_index.clone()
+    deff.edge_index[0, 0] = (deff.edge_index[0, 0] + 1) % 5
+    assert torch.isnan(dc_train.losses(model, rest, deff, rig)["loss"])

@@ -123,7 +123,82 @@ k_hop_pipe(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     }
 }
 
+// ---- packed {idx, w} records: ONE scalar load brings the 8 records of a row's first chunk.
+// `rec` holds E' + 8 records (8 zero records of padding), so the load needs no bounds logic.
+// ELL = true: rec8[row*8 .. row*8+8) is addressed by the row alone (no dependence on ptr): the
+// ptr pair and the records are fetched together, one scalar latency instead of two; rows longer
+// than 8 continue in the CSR arrays.  CLAMP: all 8 gathers are issued unconditionally (slots past
+// the end re-read neighbour 0), their results dropped by a select.
+struct Rec { int idx; float w; };
+
+template <bool ELL, bool CLAMP, bool NT>
+__global__ void __launch_bounds__(256)
+k_hop_rec(const int32_t *__restrict__ ptr, const Rec *__restrict__ rec,
+          const int32_t *__restrict__ other, const float *__restrict__ w,
+          const float *__restrict__ x, int64_t ldx, float *y, int64_t ldy, int64_t N) {
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = __builtin_amdgcn_readfirstlane((int)(lb * 4u + (threadIdx.x >> 6)));
+    if (row >= N) return;
+    const int c = (threadIdx.x & 63) * 4;
+    const Rec *r = ELL ? rec + row * 8 : nullptr;
+    Rec q[8];
+    if (ELL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = r[j];
+    }
+    const int beg = ptr[row], end = ptr[row + 1];
+    if (!ELL) {
+        r = rec + beg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = r[j];
+    }
+    const int n = end - beg;
+    float4 v[8];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (CLAMP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = j < n ? q[j].idx : q[0].idx;
+            v[j] = *reinterpret_cast<const float4 *>(x + (int64_t)s * ldx + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 t = acc;
+            axpy(t, q[j].w, v[j]);
+            if (j < n) acc = t;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < n) v[j] = *reinterpret_cast<const float4 *>(x + (int64_t)q[j].idx * ldx + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < n) axpy(acc, q[j].w, v[j]);
+    }
+    for (int p = beg + 8; p < end; ++p) {            // long rows: the tail from the CSR arrays
+        const float4 t = *reinterpret_cast<const float4 *>(x + (int64_t)other[p] * ldx + c);
+        axpy(acc, w[p], t);
+    }
+    store4<NT>(y + row * ldy + c, acc);
+}
+
 #define LAUNCH(K, grid, threads) hipLaunchKernelGGL(K, dim3(grid), dim3(threads), 0, (hipStream_t)stream, ptr, other, w, x, ldx, y, ldy, N)
+
+extern "C" int hopexp_run_rec(int variant, const int32_t *ptr, const void *rec, const int32_t *other,
+                              const float *w, const float *x, int64_t ldx, float *y, int64_t ldy,
+                              int64_t N, void *stream) {
+    const unsigned grid = (unsigned)((N + 3) / 4);
+#define LR(K) hipLaunchKernelGGL(K, dim3(grid), dim3(256), 0, (hipStream_t)stream, ptr, (const Rec *)rec, other, w, x, ldx, y, ldy, N)
+    switch (variant) {
+    case 20: LR((k_hop_rec<false, false, true>)); break;
+    case 21: LR((k_hop_rec<false, true, true>)); break;
+    case 22: LR((k_hop_rec<true, false, true>)); break;
+    case 23: LR((k_hop_rec<true, true, true>)); break;
+    case 24: LR((k_hop_rec<true, false, false>)); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int hopexp_run(int variant, const int32_t *ptr, const int32_t *other, const float *w,
                           const float *x, int64_t ldx, float *y, int64_t ldy, int64_t N, void *stream) {

@@ -80,6 +80,41 @@ def main():
                 ok = "exact" if (v == 0 or torch.equal(y, ref)) else "MISMATCH"
                 t = timeit(run, args.reps)
                 print(f"{name:5s} {lay:13s} v{v:02d} {NAMES[v]:26s}: {t * 1e3:7.2f} us  frac {comp / t / 1e6 / 8000:.3f}  {ok}")
+        # packed-record variants: rec = CSR-ordered {idx, w} (+8 padding); rec8 = 8 records per row
+        ptr_c, oth_c, w_c = g.fwd.ptr.cpu().long(), g.fwd.other.cpu(), g.fwd.w.cpu()
+        rec = torch.zeros(e + 8, 2, dtype=torch.int32)
+        rec[:e, 0] = oth_c[:e]
+        rec[:e, 1] = w_c[:e].view(torch.int32)
+        pos = ptr_c[:-1, None] + torch.arange(8)[None, :]
+        ok = pos < ptr_c[1:, None]
+        rec8 = torch.zeros(n, 8, 2, dtype=torch.int32)
+        rec8[ok] = rec[pos[ok]]
+        rec_d, rec8_d = rec.to(dev), rec8.to(dev)
+        L.hopexp_run_rec.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i64, i64, vp]
+        for lay, x, y in (("slab ld=1024", slab[:, :f], slab[:, f:2 * f]),):
+            ref = ops.hop(g.fwd, x).clone()
+            for v, nm, rr in ((20, "rec csr", rec_d), (21, "rec csr clamp", rec_d), (22, "rec ELL8", rec8_d),
+                              (23, "rec ELL8 clamp", rec8_d), (24, "rec ELL8 plain store", rec8_d)):
+                def run(v=v, rr=rr):
+                    rc = L.hopexp_run_rec(v, g.fwd.ptr.data_ptr(), rr.data_ptr(), g.fwd.other.data_ptr(),
+                                          g.fwd.w.data_ptr(), x.data_ptr(), x.stride(0), y.data_ptr(),
+                                          y.stride(0), n, st)
+                    assert rc == 0, rc
+                y.zero_()
+                run()
+                torch.cuda.synchronize()
+                okk = "exact" if torch.equal(y, ref) else "MISMATCH"
+                t = timeit(run, args.reps)
+                print(f"{name:5s} {lay:13s} v{v:02d} {nm:26s}: {t * 1e3:7.2f} us  frac {comp / t / 1e6 / 8000:.3f}  {okk}")
+        # chains of 3 hops inside one slab (block j -> j+1), as a TAGConv layer runs them
+        for v in (1, 2, 14):
+            def chain(v=v):
+                for j in range(3):
+                    xs, ys = slab[:, j * f:(j + 1) * f], slab[:, (j + 1) * f:(j + 2) * f]
+                    L.hopexp_run(v, g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(),
+                                 xs.data_ptr(), xs.stride(0), ys.data_ptr(), ys.stride(0), n, st)
+            t = timeit(chain, args.reps)
+            print(f"{name:5s} chain of 3 hops in the slab, v{v:02d} {NAMES[v]:26s}: {t * 1e3:7.2f} us  ({t * 1e3 / 3:.2f} per hop)")
         t = timeit(g.rebuild, 50)
         print(f"{name:5s} dc_graph_build (both sides, N={n} E={e}): {t * 1e3:7.2f} us")
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Run ONLY the F=256 hop launches bench.py prices in its `roofline` object (soft/rigid x
-fwd/bwd, B=32), so rocprofv3 --pmc passes can attribute HBM traffic to dc::k_spmm_wave.
+"""Run ONLY the F=256 hop launches bench.py prices in its `roofline` object (the 12 hop launches
+of a B=32 step in step order: forward and transposed chains of both branches), so rocprofv3 --pmc
+passes can attribute HBM traffic to dc::k_spmm_wave.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 tools/pmc_hop.py
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d out/write -- python3 tools/pmc_hop.py
@@ -25,14 +26,19 @@ def run():
     dev = torch.device("cuda:0")
     rest, _, rig = synth.make_batch(32)
     f = 256
+    seq = []
     for b in (rest, rig):
         n = b.x.shape[0]
         g = GraphIndex(b.edge_index.to(dev), n)
-        slab = torch.randn(n, 4 * f, device=dev)
-        rm = torch.zeros(n, device=dev)
-        for _ in range(10):                      # the launches bench.py prices: hop + row maxima
-            ops.hop(g.fwd, slab[:, :f], out=slab[:, f:2 * f], rowmax=rm, rowmax_mode=2)
-            ops.hop(g.bwd, slab[:, 2 * f:3 * f], out=slab[:, 3 * f:], rowmax=rm, rowmax_mode=2)
+        for bwd in (False, True):
+            seq.append((g, torch.randn(n, 4 * f, device=dev), torch.zeros(n, device=dev), bwd))
+    for _ in range(10):                          # the launches bench.py prices, in the same order:
+        for g, slab, rm, bwd in seq:             # forward / transposed chains of 3 hops + row maxima
+            if bwd:
+                ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm, transposed=True,
+                                 rowmax_has_block0=True)
+            else:
+                ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm)
     torch.cuda.synchronize()
 
 
