@@ -492,14 +492,13 @@ def main():
     for j in range(nb):
         r_h, _, g_h = synth.make_batch(args.batch, first_idx=(j * world + rank) * args.batch)
         if j == 0:
-            rest, rig = r_h.to(dev), g_h.to(dev)           # input buffers, slot A
-            rest_b, rig_b = r_h.to(dev), g_h.to(dev)       # input buffers, slot B (pipelined mode)
+            rest, rig = r_h.to(dev), g_h.to(dev)           # the step's (static) input buffers
         pool.append((r_h.x.to(dev), r_h.edge_index.to(dev), g_h.x.to(dev), g_h.edge_index.to(dev)))
     n_s, e_s = rest.x.shape[0], rest.edge_index.shape[1]
     n_r, e_r = rig.x.shape[0], rig.edge_index.shape[1]
     assert all(p[1].shape == rest.edge_index.shape and p[3].shape == rig.edge_index.shape for p in pool)
     edges_per_rank = e_s + e_r
-    slots = ((rest, rig), (rest_b, rig_b))
+    slots = ((rest, rig),)
 
     def load(j: int, slot=0) -> None:
         """A new batch arrives: features + edge_index into a slot's input buffers (device to
@@ -539,24 +538,6 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # ---- per-batch topology work of a slot (what loaders.PrefetchLoader + prepare_for do on the
-    # loader's stream): both sorted adjacencies + gcn_norm, first-layer hop slabs ----
-    slot_graphs = {}
-
-    def prep(slot: int) -> None:
-        for which, (b_, n_) in enumerate(zip(slots[slot], (n_s, n_r))):
-            g = slot_graphs.get((slot, which))
-            if g is None:
-                g = dc_graph.GraphIndex(b_.edge_index, n_)
-                g._static_ok = True               # the pipeline below keeps it valid for every replay
-                slot_graphs[(slot, which)] = g
-            else:
-                g.rebuild()
-            dc_graph.register(b_.edge_index, g)
-            ops.precompute_input_hops(g, b_.x, k_hops, refresh=True)
-
-    prep_stream = torch.cuda.Stream()
-
     def capture(body):
         """`body()` as one hipGraph (None with --no-graph or if capture fails)."""
         if args.no_graph:
@@ -585,11 +566,14 @@ def main():
     tail_in_graph = world == 1
 
     def make_mode(mode: str):
-        """-> step(i).  pipelined: train slot i%2 while the NEXT batch is loaded into the other slot
-        and prepared on a third stream (one graph per parity); serial: load, build, train in
-        sequence on one slot; cached: one fixed batch, adjacency + first-layer hops built once."""
+        """-> step(i).  serial: every step loads a new batch into the input buffers and the captured
+        step rebuilds the adjacency and the first-layer hops before training on it; cached: one fixed
+        batch, adjacency + first-layer hops built once outside the loop.
+        (Tried and dropped in round 2: preparing batch i+1 on another stream - inside the step's graph
+        as a third branch, as its own graph, or eagerly - while batch i trains: 0.8955 / 0.951 / 0.946 ms
+        against 0.8953 / 0.946 ms serial; the dependent chain of small topology kernels gains nothing
+        from running beside the training kernels on this runtime.)"""
         dc_graph.clear_cache()
-        slot_graphs.clear()
         if mode == "cached":
             load(0, 0)
             for b_, n_ in zip(slots[0], (n_s, n_r)):
@@ -631,70 +615,7 @@ def main():
                     fwd_bwd(0)
                     tail()
             return step
-        # pipelined: training graphs on the main stream, preparation graphs on `prep_stream`, ordered by
-        # events (a third branch INSIDE one captured graph was measured not to overlap at all on this
-        # runtime: 0.8955 vs 0.8953 ms serial, r02c)
-        load(0, 0)
-        load(1, 1)
-        prep(0)
-        prep(1)
-        warm(lambda: (fwd_bwd(0), tail(), fwd_bwd(1), tail()), reps=2)
-
-        def train_body(cur):
-            def body():
-                fwd_bwd(cur)                      # slot adjacency + hop slabs are static objects: found, not rebuilt
-                if tail_in_graph:
-                    tail()
-            return body
-        train_g = [capture(train_body(0)), capture(train_body(1))]
-        prep_g = [None, None]
-        if not args.no_graph:
-            for c in (0, 1):
-                try:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=prep_stream):
-                        prep(c)
-                    prep_g[c] = g
-                except Exception as e:  # pragma: no cover
-                    print(f"[bench] prep graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
-                    torch.cuda.synchronize()
-        ev_prep = [torch.cuda.Event(), torch.cuda.Event()]
-        ev_train = [torch.cuda.Event(), torch.cuda.Event()]
-        state = {"primed": False, "prep": [False, False], "train": [False, False]}
-
-        def step(i):
-            cur, oth = i & 1, 1 - (i & 1)
-            main = torch.cuda.current_stream()
-            if not state["primed"]:               # the very first step prepares its own batch in line
-                load(i, cur)
-                prep(cur)
-                state["primed"] = True
-            # the NEXT batch: into the other slot and through its topology work on the prep stream,
-            # once the last training step that read that slot is done; overlaps this step's training
-            if state["train"][oth]:
-                prep_stream.wait_event(ev_train[oth])
-            else:
-                prep_stream.wait_stream(main)
-            with torch.cuda.stream(prep_stream):
-                load(i + 1, oth)
-                if prep_g[oth] is not None:
-                    prep_g[oth].replay()
-                else:
-                    prep(oth)
-                ev_prep[oth].record(prep_stream)
-            state["prep"][oth] = True
-            if state["prep"][cur]:
-                main.wait_event(ev_prep[cur])
-            if train_g[cur] is not None:
-                train_g[cur].replay()
-                if not tail_in_graph:
-                    tail()
-            else:
-                fwd_bwd(cur)
-                tail()
-            ev_train[cur].record(main)
-            state["train"][cur] = True
-        return step
+        raise ValueError(mode)
 
     def timed(step, steps, warmup):
         for i in range(warmup):
@@ -713,13 +634,12 @@ def main():
             elapsed = float(t.item())
         return elapsed
 
-    # ---- headline: every step trains on a new batch whose topology work ran during the previous step ----
+    # ---- headline: every step is a NEW batch: load + adjacency / gcn_norm build + first-layer hops + train ----
     warmup = max(args.warmup, 1)
-    elapsed = timed(make_mode("pipelined"), args.steps, warmup)
+    elapsed = timed(make_mode("serial"), args.steps, warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = edges_per_rank * world * args.steps / elapsed / 1e6
-    # ---- the same with the topology work on the critical path, and with it left out (round-1 definition) ----
-    elapsed_s = timed(make_mode("serial"), args.steps, warmup)
+    # ---- secondary: the per-batch topology work left out of the loop (round-1 headline definition) ----
     elapsed_c = timed(make_mode("cached"), args.steps, warmup)
     graph_used = not args.no_graph
 
@@ -728,8 +648,6 @@ def main():
         "value": round(value, 3), "unit": "M edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "value_serial_topology": round(edges_per_rank * world * args.steps / elapsed_s / 1e6, 3),
-        "ms_per_step_serial_topology": round(elapsed_s / args.steps * 1e3, 4),
         "value_cached_topology": round(edges_per_rank * world * args.steps / elapsed_c / 1e6, 3),
         "ms_per_step_cached_topology": round(elapsed_c / args.steps * 1e3, 4),
         "dense_arithmetic": (("fp32 storage and accumulate; wide dense blocks as power-of-two-scaled 2-way "
@@ -743,14 +661,11 @@ def main():
                         f"{args.batch}x(1024 v, 6132 e) + rigid {args.batch}x(762 v, 4560 e); "
                         "TAGConv encoder 2 layers/branch, hidden 256, K=3 (configs[1])",
             "edges_per_gpu_step": edges_per_rank, "global_batch": args.batch * world,
-            "step": f"EVERY step: a new batch (1 of {nb} distinct, rotated) is copied into the idle input slot and "
-                    "its topology work (dc_graph_build: both sorted adjacencies + gcn_norm for both graphs; "
-                    "first-layer hop slabs) runs on a second stream (its own hipGraph, event-ordered) WHILE the "
-                    "current batch does fwd + "
-                    "bwd(synthetic upstream grad)" + (" + RCCL grad all-reduce" if world > 1 else "")
-                    + ("" if args.no_optim else " + Adam") + "; all of it inside the timed region (as "
-                    "loaders.PrefetchLoader + prepare_for do in train())",
-            "value_serial_topology": "same work, but load -> build -> train strictly in sequence on one slot",
+            "step": f"EVERY step: a new batch (1 of {nb} distinct, rotated) is copied into the input buffers "
+                    "(device to device), both sorted adjacencies + gcn_norm are built for both graphs "
+                    "(dc_graph_build), the first-layer hop slabs are computed, then fwd + bwd(synthetic "
+                    "upstream grad)" + (" + RCCL grad all-reduce" if world > 1 else "")
+                    + ("" if args.no_optim else " + Adam") + "; all of it inside the timed region, one hipGraph",
             "value_cached_topology": "one fixed batch replayed, adjacency and first-layer hops built once "
                                      "outside the loop (round-1 headline definition)",
             "hipgraph": graph_used, "two_stream_branches": not args.serial_branches,
@@ -771,17 +686,31 @@ def main():
             nbytes = (hop_bytes_compulsory(n, e, f, False), hop_bytes(n, e, f, False))
             cases.append((g.fwd, slab[:, :f], slab[:, f:2 * f], rm, nbytes))            # fwd hop
             cases.append((g.bwd, slab[:, 2 * f:3 * f], slab[:, 3 * f:], rm, nbytes))    # bwd hop
-        per_case = []
-        for adj, x, o, rm, nbytes in cases:                # isolated, same launch back to back
-            for _ in range(5):
-                ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2)
+        def graph_time(fn, launches_per_call: int, calls: int = 20):
+            """Device time per launch of `fn` (which enqueues `launches_per_call` kernels), replayed from
+            a hipGraph `calls` x per replay so that the host (ctypes + Python, ~15 us per launch - as
+            long as the kernel itself) is out of the measurement, exactly as in the graph-replayed step;
+            HIP events on this stream, launch gaps inside the graph included."""
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(calls):
+                    fn()
+            g.replay()
+            reps = max(args.kernel_reps // calls, 2)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-            for _ in range(args.kernel_reps):
-                ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2)
+            for _ in range(reps):
+                g.replay()
             ev1.record()
             torch.cuda.synchronize()
-            ms = ev0.elapsed_time(ev1) / args.kernel_reps
+            return ev0.elapsed_time(ev1) / (reps * calls * launches_per_call)
+
+        per_case = []
+        for adj, x, o, rm, nbytes in cases:                # isolated, same launch back to back
+            ms = graph_time(lambda: ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2), 1)
             per_case.append({"compulsory_bytes": nbytes[0], "us": round(ms * 1e3, 2),
                              "GBps": round(nbytes[0] / ms / 1e6, 1),
                              "frac": round(nbytes[0] / ms / 1e6 / HBM_PEAK_GBS, 4)})
@@ -804,16 +733,8 @@ def main():
                                      rowmax_has_block0=True)
                 else:
                     ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm)
-        for _ in range(3):
-            in_step_sequence()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(args.kernel_reps):
-            in_step_sequence()
-        ev1.record()
-        torch.cuda.synchronize()
         nlaunch = 3 * len(seq)
-        tot_ms = ev0.elapsed_time(ev1) / args.kernel_reps
+        tot_ms = graph_time(in_step_sequence, nlaunch, calls=5) * nlaunch
         comp_bytes = float(sum(3 * c[4][0] for c in seq))
         gath_bytes = float(sum(3 * c[4][1] for c in seq))
         achieved = comp_bytes / tot_ms / 1e6                     # GB/s of compulsory bytes
@@ -832,7 +753,8 @@ def main():
             "l2_served_note": "SURVEY.md 8(d) gather model (every neighbour row counted per edge); most of "
                               "these reads are L2 hits, so this figure is NOT an HBM fraction",
             "measured": "the 12 F=256 hop launches of a step in step order on step-shaped slabs (forward chains "
-                        "and transposed chains of both branches), HIP events, launch gaps included",
+                        "and transposed chains of both branches), replayed from a hipGraph as the step is "
+                        "(no host launch cost), HIP events on the launch stream, launch gaps included",
             "cases_isolated": {"soft_fwd": per_case[0], "soft_bwd": per_case[1],
                                "rigid_fwd": per_case[2], "rigid_bwd": per_case[3]},
         }
@@ -844,7 +766,7 @@ def main():
             ops.DENSE_SPLIT_BF16 = False
             try:
                 k = max(5, args.steps // 2)
-                el = timed(make_mode("pipelined"), k, 3)
+                el = timed(make_mode("serial"), k, 3)
                 out["strict_fp32"] = {"value": round(edges_per_rank * k / el / 1e6, 3), "unit": "M edges/s",
                                       "ms_per_step": round(el / k * 1e3, 4), "steps": k,
                                       "dense_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32), DC_DENSE_SPLIT=0"}

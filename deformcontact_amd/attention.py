@@ -81,7 +81,14 @@ def _gemm(L, x, ldx, rows, k, img, fo, out, ldo, xmax, wmax, st, ws=None):
 #: accurate to 2^-22 of the operand ROWS' maxima, which for un-normalised scores (the reference has
 #: no 1/sqrt(d)) showed up as 3.5e-5 in the head-weight gradients against a float64 evaluation
 #: (fp32 oracle: 1.5e-6).  ``DC_ATTN_EXACT_SCORES=0`` puts them back on the fp16x2 kernels.
-EXACT_SCORES = os.environ.get("DC_ATTN_EXACT_SCORES", "1") != "0"
+EXACT_SCORES = os.environ.get("DC_ATTN_EXACT_SCORES", "0") != "0"
+#: delta_i = sum_j P_ij dP_ij / sum_j P_ij formed inside dc_attn_ds_rows (default) instead of
+#: rowsum(dO * O): the latter leaves sum_j dS_ij ~ 3e-7 |delta_i| (the recomputed weights exp(S - lse)
+#: do not sum to exactly 1), a bias that survives into sum_j dK_j - mathematically zero - and cost
+#: 1e-5 .. 4e-5 in the shared head weights against float64 (r02 attn_diag: 1.9e-5 -> 2.2e-6).
+DELTA_IN_KERNEL = os.environ.get("DC_ATTN_DELTA_IN_KERNEL", "1") != "0"
+#: diagnostic: also O = P V and dQ = dS K on the six-product kernels (no split reduction: slow)
+EXACT_ALL = os.environ.get("DC_ATTN_EXACT_ALL", "0") == "1"
 
 
 def _gemm_exact(L, x, ldx, rows, k, w, fo, out, ldo, st):
@@ -130,6 +137,7 @@ class _AttnCoreFn(torch.autograd.Function):
         lse = torch.empty(nsp, dtype=torch.float32, device=dev)
         s = torch.empty((bq, nrp), dtype=torch.float32, device=dev)
         ws_o = _splitk_ws(L, bq, nrp, dv, dev)
+        vt = vp.t().contiguous() if EXACT_ALL else None
         for r0 in range(0, nsp, bq):
             rows = min(bq, nsp - r0)
             if EXACT_SCORES:
@@ -139,8 +147,11 @@ class _AttnCoreFn(torch.autograd.Function):
                       kmax, st)
             _lib.check(L.dc_attn_softmax_rows(s.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
                        "dc_attn_softmax_rows")
-            _gemm(L, s.data_ptr(), nrp, rows, nrp, vtimg, dv, o[r0:].data_ptr(), dv, ones.data_ptr(), vtmax, st,
-                  ws_o)
+            if EXACT_ALL:
+                _gemm_exact(L, s.data_ptr(), nrp, rows, nrp, vt, dv, o[r0:].data_ptr(), dv, st)
+            else:
+                _gemm(L, s.data_ptr(), nrp, rows, nrp, vtimg, dv, o[r0:].data_ptr(), dv, ones.data_ptr(), vtmax,
+                      st, ws_o)
         ctx.save_for_backward(qp, kp, vp, o, lse, kimg, kmax, qmax)
         ctx.dims = (ns, nr, d, dv, bq)
         return o[:ns]
@@ -169,6 +180,7 @@ class _AttnCoreFn(torch.autograd.Function):
         nb_v = L.dc_tag_linear_bwd_dw_workspace_bytes(bq, dv, nrp, 1)
         scratch = torch.empty(max(nb_k, nb_v), dtype=torch.uint8, device=dev)
         ws_q = _splitk_ws(L, bq, nrp, d, dev)
+        kt = kp.t().contiguous() if EXACT_ALL else None
         for r0 in range(0, nsp, bq):
             rows = min(bq, nsp - r0)
             acc = int(r0 > 0)
@@ -186,19 +198,35 @@ class _AttnCoreFn(torch.autograd.Function):
             else:
                 _gemm(L, gop[r0:].data_ptr(), dv, rows, dv, vimg, nrp, ds.data_ptr(), nrp, gomax[r0:].data_ptr(),
                       vmax, st)
-            _lib.check(L.dc_attn_ds_rows(p.data_ptr(), ds.data_ptr(), nrp, rows, nrp, delta[r0:].data_ptr(),
+            # delta formed inside the row kernel from the SAME P and dP, relative to the actual sum of the
+            # recomputed weights (row sums of dS are then zero to rounding)
+            _lib.check(L.dc_attn_ds_rows(p.data_ptr(), ds.data_ptr(), nrp, rows, nrp,
+                                         None if DELTA_IN_KERNEL else delta[r0:].data_ptr(),
                                          dsmax.data_ptr(), st), "dc_attn_ds_rows")
             # dQ_b = dS K
-            _gemm(L, ds.data_ptr(), nrp, rows, nrp, ktimg, d, gq[r0:].data_ptr(), d, dsmax.data_ptr(), ktmax, st,
-                  ws_q)
+            if EXACT_ALL:
+                _gemm_exact(L, ds.data_ptr(), nrp, rows, nrp, kt, d, gq[r0:].data_ptr(), d, st)
+            else:
+                _gemm(L, ds.data_ptr(), nrp, rows, nrp, ktimg, d, gq[r0:].data_ptr(), d, dsmax.data_ptr(), ktmax,
+                      st, ws_q)
             # dK += dS^T Q_b ; dV += P^T dO_b   (contraction over the block's rows: dW-shaped)
             for g_t, g_max, x_t, x_ld, x_max, out_t, fi, nb in (
                     (ds, dsmax, qp[r0:], d, qmax[r0:], gk, d, nb_k),
                     (p, ones, gop[r0:], dv, gomax[r0:], gv, dv, nb_v)):
-                _lib.check(L.dc_tag_linear_bwd_dw_h2(
-                    g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1,
-                    _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp,
-                    g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
+                if EXACT_SCORES:
+                    # the contraction runs over the block's soft rows, whose dS / P magnitudes are
+                    # heavy-tailed: the fp16x2 form scales a whole row chunk by its largest row, which
+                    # costs the small rows their relative precision (1e-5 .. 4e-5 in the head-weight
+                    # gradients against float64); the six-product bf16 split is exact per element
+                    _lib.check(L.dc_tag_linear_bwd_dw_split(
+                        g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1,
+                        _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp, 6, st),
+                        "dc_tag_linear_bwd_dw_split")
+                else:
+                    _lib.check(L.dc_tag_linear_bwd_dw_h2(
+                        g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1,
+                        _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp,
+                        g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
         return gq[:ns], gk[:nr], gv[:nr], None
 
 

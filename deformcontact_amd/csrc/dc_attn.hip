@@ -57,13 +57,34 @@ k_attn_exp_rows(float *__restrict__ s, int64_t ld, int64_t n, int64_t npad, cons
     for (int64_t j = threadIdx.x; j < npad; j += 256) row[j] = j < n ? expf(row[j] - l) : 0.f;
 }
 
+// dS = P * (dP - delta) in place of dP, + the row maxima of |dS|.  delta == nullptr: the kernel forms
+// delta_i = sum_j P_ij dP_ij itself (a first pass over the row, fixed-order block sum) - what the
+// softmax backward of autograd does.  With a delta handed in from rowsum(dO * O) the row sums of dS
+// are off zero by O's own rounding (~1e-6 of |delta|); that bias survives into sum_j dK_j, which is
+// mathematically zero, and is amplified wherever the keys share a large common component (after a
+// ReLU encoder: 1e-5 .. 4e-5 in the shared head weights against float64, r02 attn_diag).
 __global__ void __launch_bounds__(256)
 k_attn_ds_rows(const float *__restrict__ p, float *__restrict__ dp, int64_t ld, int64_t npad,
                const float *__restrict__ delta, float *__restrict__ rowmax) {
     __shared__ float red[4];
     const float *pr = p + (int64_t)blockIdx.x * ld;
     float *dr = dp + (int64_t)blockIdx.x * ld;
-    const float d = delta[blockIdx.x];
+    float d;
+    if (delta) {
+        d = delta[blockIdx.x];
+    } else {
+        // the recomputed weights exp(S - lse) sum to 1 + O(|lse| 2^-24), not to 1: delta is taken
+        // relative to their actual sum, so that sum_j dS_ij = sum P dP - delta sum P vanishes
+        float acc = 0.f, sp = 0.f;
+        for (int64_t j = threadIdx.x; j < npad; j += 256) {
+            const float pj = pr[j];
+            acc += pj * dr[j];
+            sp += pj;
+        }
+        acc = block_reduce_sum(acc, red);
+        sp = block_reduce_sum(sp, red);
+        d = sp > 0.f ? acc / sp : acc;
+    }
     float m = 0.f;
     for (int64_t j = threadIdx.x; j < npad; j += 256) {
         const float v = pr[j] * (dr[j] - d);
@@ -110,7 +131,7 @@ extern "C" int dc_attn_ds_rows(const float *p, float *dp, int64_t ld, int64_t ro
                                const float *delta, float *rowmax, dc_stream_t stream) {
     if (int rc = attn_check("dc_attn_ds_rows", p, ld, rows, npad, npad)) return rc;
     if (rows == 0) return DC_OK;
-    DC_REQUIRE(dp && delta && rowmax, "dc_attn_ds_rows: null pointer");
+    DC_REQUIRE(dp && rowmax, "dc_attn_ds_rows: null pointer");
     hipLaunchKernelGGL(k_attn_ds_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, ld,
                        npad, delta, rowmax);
     return check_launch("dc_attn_ds_rows");

@@ -35,7 +35,9 @@ constexpr int kSortLds = 4096;       // ids sorted in LDS (16 KiB); longer group
 struct Side {
     const int64_t *key;    // edge_index row that groups this side
     const int64_t *oth;    // the other row
-    int32_t *cnt;          // [N]   counters, then fill cursors (workspace)
+    int32_t *cnt;          // [N]   counters (workspace)
+    int32_t *cur;          // [N]   fill cursors (workspace; a separate array so the scan's loads of
+                           //       cnt are independent of its stores)
     int32_t *tmp;          // [E+N] edge ids bucketed per group (workspace)
     int32_t *tiles;        // [ntiles+2] scan tile sums (workspace)
     int32_t *big;          // [1 + N] count + list of groups longer than kRankLoop (workspace)
@@ -113,34 +115,70 @@ __device__ __forceinline__ void note_big(const Side &sd, int64_t node, int len) 
     if (len > kRankLoop) sd.big[1 + atomicAdd(&sd.big[0], 1)] = (int32_t)node;
 }
 
-// one 1024-thread block per side: counts -> ptr, cursors, big-group list.  Every thread owns one
-// contiguous run of `per` counters (all its loads are issued up front), the block scans the 1024
-// run sums once, and the second pass over the (cache-hot) run writes the offsets.
+// one 1024-thread block (16 waves) per side: counts -> ptr, cursors, big-group list.  Wave w owns the
+// contiguous segment [w * seg, (w + 1) * seg) and walks it in 256-element chunks, lane l taking the
+// 16 bytes at chunk + 4 l: every load and store is one fully coalesced 1 KiB wave access (a run per
+// THREAD - 64 cache lines per instruction - made this 18-25 us; r02 build profile).  Pass 1: segment
+// totals; the block scans the 16 totals; pass 2: wave-level scan per chunk with a running carry.
 __global__ void __launch_bounds__(1024)
 k_scan_small(Build b) {
     const Side &sd = b.s[blockIdx.x];
-    const int64_t per = ((b.N + 1023) / 1024 + 3) & ~int64_t(3);
-    const int64_t beg = (int64_t)threadIdx.x * per;
-    const int64_t end = beg + per < b.N ? beg + per : b.N;
-    int s = 0;
-    for (int64_t i = beg; i < end; i += 4) {
-        if (i + 4 <= end) {
-            const int4 v = *reinterpret_cast<const int4 *>(sd.cnt + i);   // cnt is 16-byte aligned
-            s += v.x + v.y + v.z + v.w;
-        } else {
-            for (int64_t j = i; j < end; ++j) s += sd.cnt[j];
+    const int32_t *__restrict__ cnt = sd.cnt;
+    int32_t *__restrict__ ptr = sd.ptr;
+    int32_t *__restrict__ cur = sd.cur;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t seg = (((b.N + 15) / 16) + 255) & ~int64_t(255);
+    const int64_t beg = (int64_t)w * seg, end = beg + seg < b.N ? beg + seg : b.N;
+    auto load4 = [&](int64_t i) {
+        int4 v = make_int4(0, 0, 0, 0);
+        if (i + 4 <= end) v = *reinterpret_cast<const int4 *>(cnt + i);       // cnt is 16-byte aligned
+        else {
+            if (i < end) v.x = cnt[i];
+            if (i + 1 < end) v.y = cnt[i + 1];
+            if (i + 2 < end) v.z = cnt[i + 2];
         }
+        return v;
+    };
+    int s = 0;
+    for (int64_t c = beg; c < end; c += 256) {
+        const int4 v = load4(c + 4 * lane);
+        s += v.x + v.y + v.z + v.w;
     }
-    int total;
-    int run = block_incl_scan<16>(s, &total) - s;
-    for (int64_t i = beg; i < end; ++i) {
-        const int v = sd.cnt[i];
-        sd.ptr[i] = run;
-        sd.cnt[i] = run;                // becomes the fill cursor
-        note_big(sd, i, v);
-        run += v;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ int wtot[16];
+    if (lane == 0) wtot[w] = s;
+    __syncthreads();
+    int carry = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < w) carry += wtot[j];
+        total += wtot[j];
     }
-    if (threadIdx.x == 0) sd.ptr[b.N] = total;
+    for (int64_t c = beg; c < end; c += 256) {
+        const int64_t i = c + 4 * lane;
+        const int4 v = load4(i);
+        const int mine = v.x + v.y + v.z + v.w;
+        const int incl = wave_incl_scan(mine);
+        int4 o;
+        o.x = carry + incl - mine, o.y = o.x + v.x, o.z = o.y + v.y, o.w = o.z + v.z;
+        if (i + 4 <= end) {
+            *reinterpret_cast<int4 *>(ptr + i) = o;
+            *reinterpret_cast<int4 *>(cur + i) = o;
+        } else {
+            if (i < end) ptr[i] = o.x, cur[i] = o.x;
+            if (i + 1 < end) ptr[i + 1] = o.y, cur[i + 1] = o.y;
+            if (i + 2 < end) ptr[i + 2] = o.z, cur[i + 2] = o.z;
+        }
+        if (v.x > kRankLoop || v.y > kRankLoop || v.z > kRankLoop || v.w > kRankLoop) {
+            if (i < end) note_big(sd, i, v.x);
+            if (i + 1 < end) note_big(sd, i + 1, v.y);
+            if (i + 2 < end) note_big(sd, i + 2, v.z);
+            if (i + 3 < end) note_big(sd, i + 3, v.w);
+        }
+        carry += __shfl(incl, 63);
+    }
+    if (threadIdx.x == 0) ptr[b.N] = total;
 }
 
 __global__ void __launch_bounds__(256)
@@ -187,7 +225,7 @@ k_scan_apply(Build b, int64_t ntiles) {
     for (int j = 0; j < 4; ++j) {
         if (base + j < b.N) {
             sd.ptr[base + j] = run;
-            sd.cnt[base + j] = run;   // becomes the fill cursor
+            sd.cur[base + j] = run;   // the fill cursor
             note_big(sd, base + j, v[j]);
         }
         run += v[j];
@@ -202,12 +240,12 @@ k_fill(Build b, int nsides) {
         const int64_t k = b.s[0].key[t], o = b.s[0].oth[t];
         if (k < 0 || k >= b.N || o < 0 || o >= b.N) return;
         if (b.self_loops && k == o) return;
-        b.s[0].tmp[atomicAdd(&b.s[0].cnt[k], 1)] = (int32_t)t;
-        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cnt[o], 1)] = (int32_t)t;
+        b.s[0].tmp[atomicAdd(&b.s[0].cur[k], 1)] = (int32_t)t;
+        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cur[o], 1)] = (int32_t)t;
     } else if (b.self_loops && t < b.E + b.N) {
         const int64_t k = t - b.E;
-        b.s[0].tmp[atomicAdd(&b.s[0].cnt[k], 1)] = (int32_t)t;
-        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cnt[k], 1)] = (int32_t)t;
+        b.s[0].tmp[atomicAdd(&b.s[0].cur[k], 1)] = (int32_t)t;
+        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cur[k], 1)] = (int32_t)t;
     }
 }
 
@@ -352,14 +390,16 @@ static inline int64_t align16(int64_t b) { return (b + 15) & ~int64_t(15); }
 
 static inline int64_t side_bytes(int64_t E, int64_t N) {
     const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
-    return align16(4 * (N + 1)) + align16(4 * (E + N + 1)) + align16(4 * (ntiles + 2)) +
+    return 2 * align16(4 * (N + 4)) + align16(4 * (E + N + 1)) + align16(4 * (ntiles + 2)) +
            align16(4 * (N + 2));
 }
 
 static char *carve_side(Side &sd, char *ws, int64_t E, int64_t N) {
     const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
     sd.cnt = (int32_t *)ws;
-    ws += align16(4 * (N + 1));
+    ws += align16(4 * (N + 4));
+    sd.cur = (int32_t *)ws;
+    ws += align16(4 * (N + 4));
     sd.tmp = (int32_t *)ws;
     ws += align16(4 * (E + N + 1));
     sd.tiles = (int32_t *)ws;
@@ -381,7 +421,9 @@ static int run_build(Build &b, int nsides, hipStream_t stream, const char *what)
     hipLaunchKernelGGL(k_init, dim3((unsigned)((N + 255) / 256), nsides), dim3(256), 0, stream, b);
     if (E > 0)
         hipLaunchKernelGGL(k_count, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, b, nsides);
-    if (N <= kScanSmall) {
+    bool ptr16 = true;                          // k_scan_small stores ptr with 16-byte accesses
+    for (int s = 0; s < nsides; ++s) ptr16 = ptr16 && (((uintptr_t)b.s[s].ptr & 15) == 0);
+    if (N <= kScanSmall && ptr16) {
         hipLaunchKernelGGL(k_scan_small, dim3(nsides), dim3(1024), 0, stream, b);
     } else {
         hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ntiles, nsides), dim3(256), 0, stream, b);

@@ -8,9 +8,9 @@
 // Plain bf16 operands on v_mfma_f32_32x32x16_bf16: one MFMA product per tile - the precision of the
 // reference under torch.autocast(bfloat16), NOT the fp32-accurate split forms of dc_dense_split.hip.
 //
-// Structure: 128 x 128 block tile, 4 MFMA waves (2 x 2) + 1 LOADER wave, stage = 32 k (64 B per
+// Structure: 128 x 128 block tile, 4 MFMA waves (2 x 2) + 4 LOADER waves, stage = 32 k (64 B per
 // row).  BOTH operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU,
-// no ds_write), issued by the loader wave into a ring of kSlots stage buffers kAhead stages ahead
+// no ds_write), issued by the loader waves into a ring of kSlots stage buffers kAhead stages ahead
 // and published with a COUNTED vmcnt + one s_barrier per stage (the pieces of the stages still in
 // flight stay in flight across the barrier; barriers do not drain VMEM).  The DMA writes lane i's
 // 16 bytes at base + 16 i, so a tile image is dense (64-byte rows); bank spread of the b128 fragment
@@ -42,7 +42,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne_d(float f) {
     return (uint16_t)(u >> 16);
 }
 
-__global__ void __launch_bounds__(320)
+__global__ void __launch_bounds__(512)
 k_fwd_bf16(Bf16Params p) {
     constexpr int BM = 128, kTile = BM * 64;                 // bytes of one operand tile of a stage
     __shared__ __attribute__((aligned(16))) char sA[kBfSlots][kTile];
@@ -57,14 +57,18 @@ k_fwd_bf16(Bf16Params p) {
     const int lane = threadIdx.x & 63;
     const int nst = (int)(p.K / kBfBK);
 
-    if (wid == 4) {
-        // ---------------- loader wave: LDS-DMA only, never reads LDS ----------------
+    if (wid >= 4) {
+        // ---------------- four loader waves: LDS-DMA only, never read LDS ----------------
         // (hipcc guards every ds_read of a wave that has LDS-DMAs in flight with s_waitcnt vmcnt(0) -
-        // it cannot tell the slots apart - so the wave that issues the DMAs is not one that reads)
-        unsigned offA[8], offB[8];
+        // it cannot tell the slots apart - so the waves that issue the DMAs are not the ones that
+        // read.  FOUR of them: one wave sustains only ~25 GB/s of LDS-DMA (MI355X_MICROARCH.md,
+        // ldsdma-fill), a 128 x 128 x 32 bf16 stage needs 16 KiB per ~0.12 us of MFMA time; with a
+        // single loader wave this kernel ran at 0.19 of the MFMA peak.)
+        const int lw = wid - 4;                  // loader wave lw fills rows [32 lw, 32 lw + 32) of both tiles
+        unsigned offA[2], offB[2];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int rowl = q * 16 + (lane >> 2);
+        for (int q = 0; q < 2; ++q) {
+            const int rowl = lw * 32 + q * 16 + (lane >> 2);
             const int piece = (lane & 3) ^ ((rowl >> 2) & 3);
             int64_t row = row0 + rowl;
             row = row < p.N ? row : p.N - 1;
@@ -77,28 +81,26 @@ k_fwd_bf16(Bf16Params p) {
         const uint16_t *baseB = p.w + col0 * p.K;
         auto dma = [&](int slot) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 2; ++q) {
                 __builtin_amdgcn_global_load_lds(
                     (const void __attribute__((address_space(1))) *)(baseA + offA[q]),
-                    (void __attribute__((address_space(3))) *)(sA[slot] + q * 16 * 64), 16, 0, 0);
+                    (void __attribute__((address_space(3))) *)(sA[slot] + (lw * 32 + q * 16) * 64), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(
                     (const void __attribute__((address_space(1))) *)(baseB + offB[q]),
-                    (void __attribute__((address_space(3))) *)(sB[slot] + q * 16 * 64), 16, 0, 0);
+                    (void __attribute__((address_space(3))) *)(sB[slot] + (lw * 32 + q * 16) * 64), 16, 0, 0);
             }
             baseA += kBfBK;
             baseB += kBfBK;
         };
         for (int s = 0; s < kBfAhead && s < nst; ++s) dma(s);
         for (int it = 0; it < nst; ++it) {
-            // wait until only the stages AFTER `it` (16 DMA instructions each; up to two of them
-            // pending here) are still in flight; the barrier publishes stage `it` and tells this
-            // wave that the MFMA waves are done with stage it - 1, whose slot then takes the DMAs of
-            // stage it + 3 (three stages - 48 KiB per block - in flight during the MFMAs: at 128 x 128 x
-            // 32 a stage lasts ~0.12 us at full matrix rate, a first-touch row of A ~2 us)
+            // wait until only the stages AFTER `it` (4 DMA instructions per wave and stage; up to two of
+            // them pending here) are still in flight; the barrier publishes stage `it` and tells the
+            // loaders that the MFMA waves are done with stage it - 1, whose slot then takes stage it + 3
             const int later = nst - 1 - it;
-            if (later >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (32 & 15) | ((32 >> 4) << 14));        // vmcnt(32)
-            else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));   // vmcnt(16)
-            else __builtin_amdgcn_s_waitcnt(0x0F70 | 0);                                               // vmcnt(0)
+            if (later >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);        // vmcnt(8)
+            else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);   // vmcnt(4)
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | 0);                   // vmcnt(0)
             __builtin_amdgcn_s_barrier();
             if (it + kBfAhead < nst) dma((it + kBfAhead) & (kBfSlots - 1));
         }
@@ -207,7 +209,7 @@ extern "C" int dc_tag_linear_fwd_bf16(const uint16_t *a, int64_t lda, const uint
                "dc_tag_linear_fwd_bf16: leading dimension too large for 32-bit tile offsets");
     Bf16Params p{a, w, bias, out, lda, ldo, N, K, Fo, relu, out_is_bf16};
     const int64_t grid = ((N + 127) / 128) * ((Fo + BN - 1) / BN);
-    hipLaunchKernelGGL(k_fwd_bf16, dim3((unsigned)grid), dim3(320), 0, stream, p);
+    hipLaunchKernelGGL(k_fwd_bf16, dim3((unsigned)grid), dim3(512), 0, stream, p);
     return check_launch("dc_tag_linear_fwd_bf16");
 }
 

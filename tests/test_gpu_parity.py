@@ -757,6 +757,18 @@ def test_full_size_encoder_vs_oracle(everyday_b32):
     enc = ContactEncoder([21, 25], 256)
     ref = ContactEncoder([21, 25], 256, conv_module=pyg_ref)
     ref.load_state_dict(enc.state_dict())
+    # 15 M pre-activations: a few of them lie within fp32 rounding of zero, where the fp32 and float64
+    # evaluations disagree about the ReLU - one flipped mask element moves a bias gradient by 1e-4 of its
+    # maximum, whatever the precision of the sums.  The layer biases are therefore raised so that no
+    # pre-activation comes near the kink (checked below); masks themselves are covered at sizes where
+    # such ties do not occur (test_conv_forward_backward_vs_oracle, the golden fixtures).
+    with torch.no_grad():
+        for name, p_ in enc.named_parameters():
+            if name.endswith(".bias"):
+                p_.fill_(6.0)
+            elif ".1.lins." in name:
+                p_.mul_(0.1)        # layer 2 sees inputs around 6: keep its sums well inside the bias
+    ref.load_state_dict(enc.state_dict())
     ref64 = ContactEncoder([21, 25], 256, conv_module=pyg_ref)
     ref64.load_state_dict(enc.state_dict())
     ref64 = ref64.double()
@@ -772,6 +784,7 @@ def test_full_size_encoder_vs_oracle(everyday_b32):
     torch.autograd.backward([ra, rb], [ga, gb])
     ta, tb = ref64(G(rest_c.x.double(), rest_c.edge_index), G(rig_c.x.double(), rig_c.edge_index))
     torch.autograd.backward([ta, tb], [ga.double(), gb.double()])
+    assert float(ta.min()) > 0.05 and float(tb.min()) > 0.05, "a ReLU came near its kink: raise the biases"
     assert rel_err(_np(a), _np(ra)) < TOL and rel_err(_np(b), _np(rb)) < TOL
     assert_parity(_np(a), _np(ra), _np(ta), TOL, "soft per row", metric=row_rel_err)
     assert_parity(_np(b), _np(rb), _np(tb), TOL, "rigid per row", metric=row_rel_err)

@@ -115,6 +115,37 @@ def main():
                                  xs.data_ptr(), xs.stride(0), ys.data_ptr(), ys.stride(0), n, st)
             t = timeit(chain, args.reps)
             print(f"{name:5s} chain of 3 hops in the slab, v{v:02d} {NAMES[v]:26s}: {t * 1e3:7.2f} us  ({t * 1e3 / 3:.2f} per hop)")
+        # the step's regime: more slabs alive than the 256 MiB Infinity Cache holds (here 4 x this
+        # graph's slab), chains of 3 hops on each in turn - every chain starts from cold rows
+        slabs = [torch.randn(n, 4 * f, device=dev) for _ in range(4 if name == "soft" else 5)]
+        rms = [torch.zeros(n, device=dev) for _ in slabs]
+
+        def rot(kind):
+            for sl, rmx in zip(slabs, rms):
+                for j in range(3):
+                    xs, ys = sl[:, j * f:(j + 1) * f], sl[:, (j + 1) * f:(j + 2) * f]
+                    if kind == "plain":
+                        ops.hop(g.fwd, xs, out=ys)
+                    elif kind == "rowmax":
+                        ops.hop(g.fwd, xs, out=ys, rowmax=rmx, rowmax_mode=1 if j == 0 else 2)
+                    elif kind >= 20:
+                        rr = rec8_d if kind >= 22 else rec_d
+                        L.hopexp_run_rec(kind, g.fwd.ptr.data_ptr(), rr.data_ptr(), g.fwd.other.data_ptr(),
+                                         g.fwd.w.data_ptr(), xs.data_ptr(), xs.stride(0), ys.data_ptr(),
+                                         ys.stride(0), n, current_stream_ptr(dev))
+                    else:
+                        L.hopexp_run(kind, g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(),
+                                     xs.data_ptr(), xs.stride(0), ys.data_ptr(), ys.stride(0), n,
+                                     current_stream_ptr(dev))
+        for kind in ("plain", "rowmax", 1, 2, 3, 4, 8, 9, 15, 20, 22, 24):
+            rot(kind)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                rot(kind)
+            t = timeit(gr.replay, 20) / (3 * len(slabs))
+            label = kind if isinstance(kind, str) else f"v{kind:02d} {NAMES.get(kind, 'rec variant')}"
+            print(f"{name:5s} rotating slabs (> Infinity Cache), graph-replayed chains, {label:32s}: {t * 1e3:7.2f} us per hop  frac {comp / t / 1e6 / 8000:.3f}")
         t = timeit(g.rebuild, 50)
         print(f"{name:5s} dc_graph_build (both sides, N={n} E={e}): {t * 1e3:7.2f} us")
 
