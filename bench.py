@@ -292,6 +292,42 @@ def full_step_b4(dev, steps: int = 20, batch: int = 4):
                     "; losses on stock PyTorch; Adam = dc_adam_flat"}
 
 
+def train_loop(dev, batch: int = 4, steps: int = 40):
+    """BASELINE.json configs[2]: the REAL loop - `train.train()`'s inner loop on the synthetic dataset: a
+    new batch every step from `loaders.PrefetchLoader` (worker-thread assembly, pinned upload on a side
+    stream), whole train step (encoder + attention + decoder + both losses + Adam) replayed from ONE
+    hipGraph that contains the per-batch topology work (`train.GraphedTrainStep`).  Host wall time per
+    step, everything included."""
+    from deformcontact_amd import dp
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
+    from deformcontact_amd.loaders import PrefetchLoader, SyntheticEverydayDataset
+    from deformcontact_amd.train import GraphedTrainStep
+    torch.manual_seed(0)
+    model = load_model(EVERYDAY_NETWORK).to(dev)
+    bucket = dp.GradBucket(model.parameters(), direct=True)
+    opt = dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=True)
+    bucket.zero()
+    stepper = GraphedTrainStep(model, opt, bucket, 1.0, eager_steps=2)
+    ds = SyntheticEverydayDataset((steps + 8) * batch)
+    times, losses_ = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i, (_, (rest, deff, rig)) in enumerate(PrefetchLoader(ds, batch, dev, shuffle=False, depth=3)):
+        out = stepper(rest, deff, rig)
+        if i == 7:                                   # graph captured, loader warm
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        if i >= steps + 7:
+            break
+    loss = float(out["loss"])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 3), "batch": batch, "steps": steps, "graph_replays": stepper.replays,
+            "final_loss": round(loss, 6),
+            "note": "new batch every step (PrefetchLoader), one hipGraph per step incl. adjacency build; host wall "
+                    "time, bounded below by the loader's single worker thread assembling the meshes"}
+
+
 def radius100k(dev, reps: int = 30):
     """BASELINE.json configs[4]: one 100k-point radius graph with a dense blob (in-degree up to 32,
     mean ~11), 256 features STORED as bf16, two TAGConv(256, 256, K=3) layers forward (bf16 hops
@@ -778,6 +814,10 @@ def main():
             except Exception as e:  # pragma: no cover
                 out["radius100k"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_full_step:
+            try:
+                out["train_loop_b4"] = train_loop(dev)
+            except Exception as e:  # pragma: no cover
+                out["train_loop_b4"] = {"error": f"{type(e).__name__}: {e}"}
             out["full_train_step_b4"] = full_step_b4(dev)
             out["full_train_step_b32"] = full_step_b4(dev, steps=5, batch=32)
         if world == 1 and not args.no_cpu_baseline:
