@@ -123,6 +123,68 @@ k_hop_pipe(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     }
 }
 
+// ---- software-pipelined INDEX stream: a wave walks RW consecutive rows; while the gathers of row r
+// are in flight (vmcnt) the segment bounds of row r+2 and the neighbour ids / weights of row r+1 are
+// fetched by scalar loads (lgkmcnt - a different counter, so waiting for one does not wait for the
+// other).  The dependent chain per row shrinks from bounds -> ids -> gathers -> store to gathers -> store.
+template <int RW, bool NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+k_hop_swp(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
+          const float *__restrict__ w, const float *__restrict__ x, int64_t ldx, float *y,
+          int64_t ldy, int64_t N) {
+    constexpr int U = 8;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t row0 = ((int64_t)lb * 4 + wave) * RW;
+    if (row0 >= N) return;
+    const int c = (threadIdx.x & 63) * 4;
+    const int nrow = (int)((N - row0) < RW ? (N - row0) : RW);
+    int beg = ptr[row0], end = ptr[row0 + 1];
+    int s[U], sn[U];
+    float ww[U], wn[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const bool ok = beg + j < end;
+        s[j] = ok ? other[beg + j] : 0;
+        ww[j] = ok ? w[beg + j] : 0.f;
+    }
+    int nend = nrow > 1 ? ptr[row0 + 2] : end;
+    for (int r = 0; r < nrow; ++r) {
+        const int64_t row = row0 + r;
+        const int n = end - beg;
+        float4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (j < n) v[j] = *reinterpret_cast<const float4 *>(x + (int64_t)s[j] * ldx + c);
+        // next row's ids / weights and the bounds after it, while those gathers fly
+        const int nbeg = end;
+        int nnend = nend;
+        if (r + 1 < nrow) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const bool ok = nbeg + j < nend;
+                sn[j] = ok ? other[nbeg + j] : 0;
+                wn[j] = ok ? w[nbeg + j] : 0.f;
+            }
+            if (r + 2 < nrow) nnend = ptr[row + 3];
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            if (j < n) axpy(acc, ww[j], v[j]);
+        for (int p = beg + U; p < end; ++p) {          // long rows: the tail, one at a time
+            const float4 t = *reinterpret_cast<const float4 *>(x + (int64_t)other[p] * ldx + c);
+            axpy(acc, w[p], t);
+        }
+        store4<NT>(y + row * ldy + c, acc);
+        beg = nbeg;
+        end = nend;
+        nend = nnend;
+#pragma unroll
+        for (int j = 0; j < U; ++j) { s[j] = sn[j]; ww[j] = wn[j]; }
+    }
+}
+
 // ---- packed {idx, w} records: ONE scalar load brings the 8 records of a row's first chunk.
 // `rec` holds E' + 8 records (8 zero records of padding), so the load needs no bounds logic.
 // ELL = true: rec8[row*8 .. row*8+8) is addressed by the row alone (no dependence on ptr): the
@@ -220,6 +282,10 @@ extern "C" int hopexp_run(int variant, const int32_t *ptr, const int32_t *other,
     case 13: LAUNCH((k_hop_pipe<8, 2, false, 8>), blocks(8, 2), 128); break;
     case 14: LAUNCH((k_hop_chunk<1, 4, false, 4>), blocks(1, 4), 256); break;
     case 15: LAUNCH((k_hop_pipe<4, 4, false, 6>), blocks(4, 4), 256); break;
+    case 16: LAUNCH((k_hop_swp<2, false>), blocks(2, 4), 256); break;
+    case 17: LAUNCH((k_hop_swp<4, false>), blocks(4, 4), 256); break;
+    case 18: LAUNCH((k_hop_swp<8, false>), blocks(8, 4), 256); break;
+    case 19: LAUNCH((k_hop_swp<16, false>), blocks(16, 4), 256); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
