@@ -138,20 +138,21 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
     launches, flops = [], 0.0
     keep = []
     for n in (n_s, n_r):
-        slab = torch.randn(n, nseg * fi, device=dev)
+        slab = ops._alloc_slab(n, nseg * fi, dev).normal_()      # the product's (row-padded) slab layout
+        lds = slab.stride(0)
         xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
         ws = [torch.randn(fo, fi, device=dev) / 16 for _ in range(nseg)]
         bias, out, g = torch.randn(fo, device=dev), torch.empty(n, fo, device=dev), torch.randn(n, fo, device=dev)
         gws = [torch.empty(fo, fi, device=dev) for _ in range(nseg)]
         gb = torch.empty(fo, device=dev)
-        gslab = torch.empty(n, nseg * fi, device=dev)
+        gslab = ops._alloc_slab(n, nseg * fi, dev)
         gxs = [gslab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
         nb = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi, fo, nseg)
         wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
         pa_x, pa_w, pa_gw, pa_gx, pa_ld = (_ptr_array(xs), _ptr_array(ws), _ptr_array(gws),
-                                            _ptr_array(gxs), _i64_array([nseg * fi] * nseg))
+                                            _ptr_array(gxs), _i64_array([lds] * nseg))
         keep += [slab, ws, bias, out, g, gws, gb, gslab, scratch, wsx, pa_x, pa_w, pa_gw, pa_gx, pa_ld]
         split, npd = ops.DENSE_SPLIT_BF16, ops.DENSE_PRODUCTS
 
@@ -190,13 +191,13 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
                                  wtmax.data_ptr(), st)
             keep += [wimg, wtimg]
 
-            def fwd(n=n, slab=slab, wimg=wimg, bias=bias, out=out, rowmax=rowmax, wmax=wmax):
-                L.dc_tag_linear_fwd_h2p(slab.data_ptr(), nseg * fi, wimg.data_ptr(), bias.data_ptr(), 1,
+            def fwd(n=n, slab=slab, wimg=wimg, bias=bias, out=out, rowmax=rowmax, wmax=wmax, lds=lds):
+                L.dc_tag_linear_fwd_h2p(slab.data_ptr(), lds, wimg.data_ptr(), bias.data_ptr(), 1,
                                         out.data_ptr(), fo, n, nseg * fi, fo, rowmax.data_ptr(),
                                         wmax.data_ptr(), None, 0, st)
 
             def dx(n=n, gslab=gslab, wtimg=wtimg, gx=gx, growmax=growmax, wtmax=wtmax):
-                L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), nseg * fo, wtimg.data_ptr(), None, 0, gx.data_ptr(),
+                L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gslab.stride(0), wtimg.data_ptr(), None, 0, gx.data_ptr(),
                                         fi, n, nseg * fo, fi, growmax.data_ptr(), wtmax.data_ptr(), None, 0, st)
 
             def dw(n=n, g=g, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb,
@@ -717,7 +718,7 @@ def main():
         f = 256
         cases = []
         for g, n, e in ((gs, n_s, e_s), (gr, n_r, e_r)):
-            slab = torch.randn(n, 4 * f, device=dev)        # a hop slab: K+1 column blocks
+            slab = ops._alloc_slab(n, 4 * f, dev).normal_()  # a hop slab: K+1 column blocks, product layout
             rm = torch.zeros(n, device=dev)
             nbytes = (hop_bytes_compulsory(n, e, f, False), hop_bytes(n, e, f, False))
             cases.append((g.fwd, slab[:, :f], slab[:, f:2 * f], rm, nbytes))            # fwd hop
@@ -756,7 +757,7 @@ def main():
         # gradient slab, all with the row-maxima side output - HIP events on this stream
         seq = []
         for g, n, e in ((gs, n_s, e_s), (gr, n_r, e_r)):
-            slab_f, slab_b = torch.randn(n, 4 * f, device=dev), torch.randn(n, 4 * f, device=dev)
+            slab_f, slab_b = ops._alloc_slab(n, 4 * f, dev).normal_(), ops._alloc_slab(n, 4 * f, dev).normal_()
             rm_f, rm_b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
             nbytes = (hop_bytes_compulsory(n, e, f, False), hop_bytes(n, e, f, False))
             seq.append((g, slab_f, rm_f, False, nbytes))

@@ -274,9 +274,9 @@ def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool,
     n, fi = x.shape
     concat, width, wpad = tag_slab_geometry(fi, k)
     dev = x.device
-    slab = into[0] if into is not None else torch.empty((n, wpad), dtype=torch.float32, device=dev)
+    slab = into[0] if into is not None else _alloc_slab(n, wpad, dev)
     xin = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
-    _lib.check(_lib.lib().dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), wpad, n,
+    _lib.check(_lib.lib().dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), slab.stride(0), n,
                                             fi, width, wpad, current_stream_ptr(dev)),
                "dc_tag_pack_input")
     rowmax = None
@@ -337,18 +337,37 @@ def tag_slab_geometry(fi: int, k: int):
 
 _SLAB_TAG = "_dc_hop_slab"
 
+#: floats of padding behind every row of a hop slab whose row is a multiple of 1 KiB: with the natural
+#: leading dimension (1024 floats = 4 KiB for the hidden-256 layers) the rows of a tile / the neighbour
+#: rows of a hop sit a power of two apart and alias in the memory channels - measured on MI355X
+#: (tools/exp/ld_pad.py, operands from beyond the Infinity Cache): F = 256 hop 20.7 -> 18.3 us, wide
+#: forward block 92.6 -> 82.3 us with 64 floats (256 B) of padding; +16 / +80 floats (rows no longer
+#: 128-byte aligned) give nothing.  ``DC_SLAB_PAD=0`` disables.
+SLAB_PAD = int(os.environ.get("DC_SLAB_PAD", "64"))
+
+
+def _alloc_slab(n: int, wpad: int, dev, tag=None) -> torch.Tensor:
+    """``[n, wpad]`` view of a fresh row-major buffer whose leading dimension is padded off the power of
+    two (``SLAB_PAD``); ``tag`` marks the BASE as a slab this library owns (``_as_slab_block0``)."""
+    pad = SLAB_PAD if (SLAB_PAD > 0 and (wpad * 4) % 1024 == 0) else 0
+    base = torch.empty((n, wpad + pad), dtype=torch.float32, device=dev)
+    if tag is not None:
+        setattr(base, _SLAB_TAG, tag)
+    return base[:, :wpad] if pad else base
+
 
 def _as_slab_block0(x: torch.Tensor, n: int, fi: int, wpad: int):
     """If ``x`` is column block 0 of a ``[n, wpad]`` hop slab THIS LIBRARY allocated for it (the
-    previous layer's forward wrote its output there and tagged the buffer), return that buffer;
-    else None.  Shape and stride alone are not enough: a caller's own ``feat[:, :fi]`` view of a
-    wider tensor looks the same, and the hops would overwrite its other columns."""
+    previous layer's forward wrote its output there and tagged the buffer), return that slab (a
+    ``[n, wpad]`` view of the possibly row-padded buffer); else None.  Shape and stride alone are not
+    enough: a caller's own ``feat[:, :fi]`` view of a wider tensor looks the same, and the hops would
+    overwrite its other columns."""
     base = x._base
     if (base is not None and getattr(base, _SLAB_TAG, None) == (n, fi, wpad)
-            and base.dim() == 2 and tuple(base.shape) == (n, wpad)
-            and base.is_contiguous() and x.stride() == (wpad, 1) and x.shape == (n, fi)
+            and base.dim() == 2 and base.size(0) == n and base.size(1) >= wpad
+            and base.is_contiguous() and x.stride() == (base.size(1), 1) and x.shape == (n, fi)
             and x.data_ptr() == base.data_ptr() and base.dtype == torch.float32):
-        return base
+        return base[:, :wpad] if base.size(1) > wpad else base
     return None
 
 
@@ -403,15 +422,14 @@ class _TagConvFn(torch.autograd.Function):
             _lib.check(L.dc_tag_pack_weights(_ptr_array(wc), k + 1, wcat.data_ptr(), fo, fi, wpad,
                                              st), "dc_tag_pack_weights")
             ws = [wcat]                                              # [Fo, wpad]
-            xs, ldxs, fi_eff = [slab], [wpad], wpad
+            xs, ldxs, fi_eff = [slab], [slab.stride(0)], wpad
         else:
             ws = [w.contiguous() for w in weights]
-            xs, ldxs, fi_eff = blocks, [wpad] * (k + 1), fi
+            xs, ldxs, fi_eff = blocks, [slab.stride(0)] * (k + 1), fi
         if next_geom is not None:
             # the output IS column block 0 of the next TAGConv layer's hop slab (no copy there)
             next_width, next_wpad = next_geom
-            nxt = torch.empty((n, next_wpad), dtype=torch.float32, device=dev)
-            setattr(nxt, _SLAB_TAG, (n, fo, next_wpad))      # recognised by _as_slab_block0
+            nxt = _alloc_slab(n, next_wpad, dev, tag=(n, fo, next_wpad))   # recognised by _as_slab_block0
             if next_wpad > next_width:
                 nxt[:, next_width:].zero_()          # K padding of a narrow next layer
             out = nxt[:, :fo]
@@ -436,7 +454,7 @@ class _TagConvFn(torch.autograd.Function):
                                             wt.data_ptr() if wt is not None else None,
                                             wt_rowmax.data_ptr() if wt is not None else None, st),
                        "dc_tag_weight_prep")
-            rc = L.dc_tag_linear_fwd_h2p(slab.data_ptr(), wpad, wimg.data_ptr(),
+            rc = L.dc_tag_linear_fwd_h2p(slab.data_ptr(), slab.stride(0), wimg.data_ptr(),
                                          b.data_ptr() if b is not None else None, int(relu),
                                          out.data_ptr(), ldo, n, width, fo,
                                          rowmax.data_ptr(), wmax.data_ptr(), None, 0, st)
@@ -467,12 +485,12 @@ class _TagConvFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[5:])
         mask_ptr = out.data_ptr() if out is not None else None
         ldm = out.stride(0) if out is not None else fo
-        wpad = slab.size(1)
+        wpad, lds = slab.size(1), slab.stride(0)
         if concat:
-            xs, ldxs, fi_eff, nseg = [slab], [wpad], wpad, 1
+            xs, ldxs, fi_eff, nseg = [slab], [lds], wpad, 1
         else:
             xs = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-            ldxs, fi_eff, nseg = [wpad] * (k + 1), fi, k + 1
+            ldxs, fi_eff, nseg = [lds] * (k + 1), fi, k + 1
 
         h2 = ctx.h2
         gws: List[Optional[torch.Tensor]] = [None] * (k + 1)
@@ -485,14 +503,15 @@ class _TagConvFn(torch.autograd.Function):
             # ONE dense block with the (K+1)*Fo reduction and the transposed weights.  gm and its
             # row maxima also feed dW (no mask reads there).
             gwid = (k + 1) * fo
-            gslab = torch.empty((n, gwid), dtype=torch.float32, device=dev)
+            gslab = _alloc_slab(n, gwid, dev)
+            gld = gslab.stride(0)
             g_rowmax = torch.empty(n, dtype=torch.float32, device=dev)
             hop_rowmax = torch.empty(n, dtype=torch.float32, device=dev) if need_x else None
-            _lib.check(L.dc_tag_mask_grad(gout.data_ptr(), ldg, mask_ptr, ldm, gslab.data_ptr(), gwid, n,
+            _lib.check(L.dc_tag_mask_grad(gout.data_ptr(), ldg, mask_ptr, ldm, gslab.data_ptr(), gld, n,
                                           fo, g_rowmax.data_ptr(),
                                           hop_rowmax.data_ptr() if need_x else None, st),
                        "dc_tag_mask_grad")
-            g_ptr, g_ld, mask_ptr = gslab.data_ptr(), gwid, None
+            g_ptr, g_ld, mask_ptr = gslab.data_ptr(), gld, None
             if need_x:
                 chained_hops(g, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
                              rowmax_has_block0=True)
@@ -504,7 +523,7 @@ class _TagConvFn(torch.autograd.Function):
                                                     wt.data_ptr(), wt_rowmax.data_ptr(), st),
                                "dc_tag_weight_prep")
                 gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
-                rc = L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gwid, wt.data_ptr(), None, 0, gx.data_ptr(),
+                rc = L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gld, wt.data_ptr(), None, 0, gx.data_ptr(),
                                              fi, n, gwid, fi, hop_rowmax.data_ptr(), wt_rowmax.data_ptr(),
                                              None, 0, st)
                 _lib.check(rc, "dc_tag_linear_fwd_h2 (dX)")
@@ -542,9 +561,10 @@ class _TagConvFn(torch.autograd.Function):
                 gb = gb_out
 
         if need_x:
-            gslab = torch.empty((n, wpad), dtype=torch.float32, device=dev)
+            gslab = _alloc_slab(n, wpad, dev)
             gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
             gxs = [gslab] if concat else gblocks
+            ldxs = [gslab.stride(0)] * len(ldxs)
             if DENSE_SPLIT_BF16:
                 wsb = L.dc_tag_linear_bwd_dx_split_workspace_bytes(fi_eff, fo, nseg)
                 wsx = torch.empty(wsb, dtype=torch.uint8, device=dev)
@@ -607,13 +627,20 @@ def tag_conv_bf16(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = Fa
     dev = x.device
     L = _lib.lib()
     st = current_stream_ptr(dev)
+    def alloc(rows, wid, tag=None):
+        pad = 2 * SLAB_PAD if (SLAB_PAD > 0 and (wid * 2) % 1024 == 0) else 0      # same byte padding as fp32
+        b = torch.empty((rows, wid + pad), dtype=torch.bfloat16, device=dev)
+        if tag is not None:
+            setattr(b, _SLAB_TAG_BF16, tag)
+        return b[:, :wid] if pad else b
+
     base = x._base
     if (base is not None and getattr(base, _SLAB_TAG_BF16, None) == (n, fi, width)
-            and tuple(base.shape) == (n, width) and base.is_contiguous()
-            and x.data_ptr() == base.data_ptr() and x.stride() == (width, 1)):
-        slab = base                                   # the previous layer wrote block 0 in place
+            and base.size(0) == n and base.size(1) >= width and base.is_contiguous()
+            and x.data_ptr() == base.data_ptr() and x.stride() == (base.size(1), 1)):
+        slab = base[:, :width] if base.size(1) > width else base   # the previous layer wrote block 0 in place
     else:
-        slab = torch.empty((n, width), dtype=torch.bfloat16, device=dev)
+        slab = alloc(n, width)
         slab[:, :fi].copy_(x)
     for j in range(k):
         hop_bf16(g.fwd, slab[:, j * fi:(j + 1) * fi], out=slab[:, (j + 1) * fi:(j + 2) * fi],
@@ -623,13 +650,12 @@ def tag_conv_bf16(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = Fa
     _lib.check(L.dc_to_bf16(_ptr_array(ws), k + 1, fo, fi, fi, wcat.data_ptr(), width, st), "dc_to_bf16")
     if next_k is not None and out_dtype == torch.bfloat16:
         nwidth = (next_k + 1) * fo
-        nxt = torch.empty((n, nwidth), dtype=torch.bfloat16, device=dev)
-        setattr(nxt, _SLAB_TAG_BF16, (n, fo, nwidth))
+        nxt = alloc(n, nwidth, tag=(n, fo, nwidth))
         out = nxt[:, :fo]
     else:
         out = torch.empty((n, fo), dtype=out_dtype, device=dev)
     b = bias.detach().contiguous() if bias is not None else None
-    rc = L.dc_tag_linear_fwd_bf16(slab.data_ptr(), width, wcat.data_ptr(),
+    rc = L.dc_tag_linear_fwd_bf16(slab.data_ptr(), slab.stride(0), wcat.data_ptr(),
                                   b.data_ptr() if b is not None else None, int(relu), out.data_ptr(),
                                   out.stride(0), int(out.dtype == torch.bfloat16), n, width, fo, st)
     _lib.check(rc, "dc_tag_linear_fwd_bf16")

@@ -1224,7 +1224,7 @@ def test_two_layer_bf16_stack_slab_handoff_and_fp32_head():
     c2.bf16_out = torch.float32
     with torch.no_grad():
         h = c1(x, ei, relu=True, next_conv=c2)
-        assert h._base is not None and h._base.shape == (n, 4 * f)
+        assert h._base is not None and h._base.shape[0] == n and h._base.shape[1] >= 4 * f
         y = c2(h, ei, relu=True)
         h_plain = c1(x, ei, relu=True)
         y_plain = c2(h_plain, ei, relu=True)

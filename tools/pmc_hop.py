@@ -31,7 +31,7 @@ def run():
         n = b.x.shape[0]
         g = GraphIndex(b.edge_index.to(dev), n)
         for bwd in (False, True):
-            seq.append((g, torch.randn(n, 4 * f, device=dev), torch.zeros(n, device=dev), bwd))
+            seq.append((g, ops._alloc_slab(n, 4 * f, dev).normal_(), torch.zeros(n, device=dev), bwd))
     for _ in range(10):                          # the launches bench.py prices, in the same order:
         for g, slab, rm, bwd in seq:             # forward / transposed chains of 3 hops + row maxima
             if bwd:
