@@ -112,6 +112,46 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
 }
 
 
+// Broadcast of the value held by lane J of each 16-lane DPP row to all lanes of that row: a VALU move with
+// the row_share modifier - no LDS round trip (ds_bpermute, which __shfl compiles to, has ~100 cycles of
+// latency behind an lgkmcnt wait, in front of every chunk's gathers).
+template <int J>
+__device__ __forceinline__ int row_share_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0xF, false);
+}
+template <int J>
+__device__ __forceinline__ float row_share_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, false));
+}
+// ids / weights of a chunk of 8 edges for a lane group of L >= 8 lanes (sub = lane index inside the group):
+// L >= 16: the first 8 lanes of EVERY 16-lane row load them (one coalesced 32-byte load each), row_share
+// hands them round; L == 8: the group's 8 lanes load, __shfl hands round
+template <int L>
+__device__ __forceinline__ void chunk_ids(const int32_t *__restrict__ other, const float *__restrict__ w,
+                                          int p, int end, int sub, int (&s)[8], float (&ww)[8]) {
+    if (L >= 16) {
+        const int q = sub & 15;
+        const bool mine = q < 8 && p + q < end;
+        const int my_s = mine ? other[p + q] : 0;
+        const float my_w = mine ? (w ? w[p + q] : 1.0f) : 0.0f;
+        s[0] = row_share_i<0>(my_s), s[1] = row_share_i<1>(my_s), s[2] = row_share_i<2>(my_s);
+        s[3] = row_share_i<3>(my_s), s[4] = row_share_i<4>(my_s), s[5] = row_share_i<5>(my_s);
+        s[6] = row_share_i<6>(my_s), s[7] = row_share_i<7>(my_s);
+        ww[0] = row_share_f<0>(my_w), ww[1] = row_share_f<1>(my_w), ww[2] = row_share_f<2>(my_w);
+        ww[3] = row_share_f<3>(my_w), ww[4] = row_share_f<4>(my_w), ww[5] = row_share_f<5>(my_w);
+        ww[6] = row_share_f<6>(my_w), ww[7] = row_share_f<7>(my_w);
+    } else {
+        const bool mine = sub < 8 && p + sub < end;
+        const int my_s = mine ? other[p + sub] : 0;
+        const float my_w = mine ? (w ? w[p + sub] : 1.0f) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s[j] = __shfl(my_s, j, L);
+            ww[j] = __shfl(my_w, j, L);
+        }
+    }
+}
+
 // ---- L lanes per row, 64/L rows per wave (narrow feature rows) -------------
 template <int VEC, int L, int U>
 __global__ void __launch_bounds__(256)
@@ -137,17 +177,10 @@ k_spmm_sub(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
             int s[U];
             float ww[U];
             V v[U];
-            if (L >= U) {
-                // ids / weights of the chunk: one coalesced load each by the first U lanes of the row's
-                // lane group, handed round with shuffles (2 vector-memory instructions instead of 2 U)
-                const bool mine = sub < U && p + sub < end;
-                const int my_s = mine ? other[p + sub] : 0;
-                const float my_w = mine ? (w ? w[p + sub] : 1.0f) : 0.0f;
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    s[j] = __shfl(my_s, j, L);
-                    ww[j] = __shfl(my_w, j, L);
-                }
+            if (L >= U && U == 8) {
+                // ids / weights of the chunk: one coalesced load each, handed round inside the lane
+                // group (2 vector-memory instructions per chunk instead of 2 U)
+                chunk_ids<L>(other, w, p, end, sub, s, ww);
             } else {
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
@@ -238,19 +271,11 @@ k_spmm_bf16x8(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other
             int s[U];
             float ww[U];
             uint4 q[U];
-            if (L >= U) {
-                // the U neighbour ids / weights of the chunk: ONE coalesced load each by the first U
-                // lanes of the row's lane group, handed round with shuffles - two vector-memory
-                // instructions per chunk instead of 2 U (with bf16 rows a wave serves two rows, so every
-                // instruction saved counts twice: 1.5 -> 0.63 per edge)
-                const bool mine = sub < U && p + sub < end;
-                const int my_s = mine ? other[p + sub] : 0;
-                const float my_w = mine ? (w ? w[p + sub] : 1.0f) : 0.0f;
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    s[j] = __shfl(my_s, j, L);
-                    ww[j] = __shfl(my_w, j, L);
-                }
+            if (L >= U && U == 8) {
+                // the 8 neighbour ids / weights of the chunk: ONE coalesced load each, handed round inside
+                // the lane group - two vector-memory instructions per chunk instead of 16 (with bf16 rows a
+                // wave serves two rows, so every instruction saved counts twice: 1.5 -> 0.63 per edge)
+                chunk_ids<L>(other, w, p, end, sub, s, ww);
             } else {
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
