@@ -1,0 +1,245 @@
+// dc_dense_h2w.hip -- the forward-shaped fp16x2 dense block for the wide layers, 128 x 256 tiles (gfx950).
+//
+//   out[N,Fo] = act(x[N,K] . W[Fo,K]^T + b),  W handed over as the scaled, split image of
+//   dc_tag_weight_prep (one 64-byte record {h1[16], h2[16]} per row and 16 k), x fp32 (hop slab).
+//   Same arithmetic as k_fwd_h2 (dc_dense_h2.hip): products h2*h1 + h1*h2 + h1*h1 in that order, fp32
+//   accumulate, k ascending in steps of 16 - the results are bit-identical to it.
+//
+// Why a second kernel (r02 ablations of k_fwd_h2 on cold operands, tools/exp/dense_abl.py): that kernel
+// takes 81 us for the soft layer-2 block; with its MFMAs removed it still takes 67 us, with all global
+// traffic removed 52 us.  Neither half is near the 20.6 us the matrix pipe needs:
+//   * data movement: 64-byte row pieces (half cache lines), one 16-wide stage of prefetch that the
+//     per-stage vmcnt(0) drains - 16 KB in flight per CU, i.e. a latency-bound 2 TB/s stream of x;
+//   * the loop itself: 12 MFMAs (384 cycles) per wave between barriers against ~600 cycles of fragment-read
+//     latency and barrier skew.
+// Here: BK = 32 (x rows move as full 128-byte lines, 24 MFMAs per wave and barrier), one 128 x 256 tile
+// per 512-thread workgroup (x is staged and split ONCE for all 256 output columns instead of once per
+// 128), both operands staged through registers with the loads of stage it+3 issued at the top of stage it
+// and written to LDS at the end of stage it+2 (three register sets: ~3 stages = 48 KB of x in flight per
+// CU, counted vmcnt - no LDS-DMA in the kernel, so hipcc's waits stay counted and __syncthreads() is a
+// bare s_barrier).  LDS rows are 128 bytes = 8 pieces of 16 bytes (piece q = 4*kstep + 2*plane + half);
+// piece q of row r sits at position q ^ F(r), F(r) = ((r >> 1) & 7) ^ 2*(r & 1): conflict-free
+// ds_read_b128 fragment reads (each 16-lane group sees 8 even and 8 odd rows with 8 distinct F each) and
+// conflict-free ds_write_b64 of the split x (two adjacent rows per 16-lane group land on disjoint pieces).
+#include "dc_dense.h"
+
+namespace dc {
+
+using hw_f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using hw_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using hw_f32x4 = __attribute__((ext_vector_type(4))) float;
+using hw_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int kWBM = 128, kWBN = 256, kWBK = 32;
+constexpr int kWRow = 128;                              // bytes per LDS row (both operands)
+constexpr int kWSzA = kWBM * kWRow, kWSzB = kWBN * kWRow;
+
+__device__ __forceinline__ int hw_swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 1); }
+
+template <bool FULL>
+__global__ void __launch_bounds__(512)
+k_fwd_h2w(FwdParams p) {
+    __shared__ __attribute__((aligned(16))) char sA[2 * kWSzA];
+    __shared__ __attribute__((aligned(16))) char sB[2 * kWSzB];
+    __shared__ __attribute__((aligned(16))) float s_inv[kWBM];
+    const unsigned ntn = (unsigned)((p.Fo + kWBN - 1) / kWBN);
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = (int64_t)(lb / ntn) * kWBM, col0 = (int64_t)(lb % ntn) * kWBN;
+    const int wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
+    const int lane = threadIdx.x & 63;
+    const int k8 = threadIdx.x & 7, r = threadIdx.x >> 3;          // staging: 8 threads per 128-byte row
+    const int64_t lda = p.x[0].ld;
+
+    unsigned offA[2], offB[4];
+    int ldsAh[2], ldsAl[2], ldsB[4];
+    float scA[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rl = r + 64 * j;
+        int64_t row = row0 + rl;
+        row = (FULL || row < p.N) ? row : p.N - 1;
+        offA[j] = (unsigned)((row - row0) * lda + 4 * k8);
+        // this thread's 4 k: k-step k8 >> 2, half (k8 >> 1) & 1, 8-byte slot k8 & 1 of the piece
+        const int q = 4 * (k8 >> 2) + ((k8 >> 1) & 1), f = hw_swz(rl);
+        ldsAh[j] = rl * kWRow + 16 * (q ^ f) + 8 * (k8 & 1);
+        ldsAl[j] = rl * kWRow + 16 * ((q + 2) ^ f) + 8 * (k8 & 1);
+        const float m = p.h2.a_rowmax[row];
+        scA[j] = h2_scale(m);
+        if (k8 == 0) s_inv[rl] = h2_unscale(m);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = r + 64 * j;
+        int64_t col = col0 + rl;
+        col = (FULL || col < p.Fo) ? col : p.Fo - 1;
+        offB[j] = (unsigned)((col - col0) * p.Fi + 4 * k8);           // 4-byte units, 16 bytes per piece
+        ldsB[j] = rl * kWRow + 16 * (k8 ^ hw_swz(rl));
+    }
+
+    f32x16 acc[2][2];
+    zero_acc<2>(acc);
+    const int nst = (int)(p.Fi / kWBK);
+    const float *baseA = p.x[0].p + row0 * lda;                       // wave-uniform running bases
+    const float *baseB = p.w[0].p + col0 * p.Fi;
+    hw_f32x4 va0[2], va1[2], va2[2];                                  // three register sets, named: no runtime index
+    hw_u32x4 vb0[4], vb1[4], vb2[4];
+
+    auto gload_set = [&](hw_f32x4 (&va)[2], hw_u32x4 (&vb)[4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) va[j] = *reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vb[j] = *reinterpret_cast<const hw_u32x4 *>(baseB + offB[j]);
+        baseA += kWBK;
+        baseB += kWBK;
+    };
+    auto lstore_set = [&](const hw_f32x4 (&va)[2], const hw_u32x4 (&vb)[4], int b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<hw_u32x4 *>(sB + b * kWSzB + ldsB[j]) = vb[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const hw_f32x4 v = va[j] * scA[j];
+            hw_f16x4 h, l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const _Float16 a = (_Float16)v[i];
+                h[i] = a;
+                l[i] = (_Float16)(v[i] - (float)a);
+            }
+            *reinterpret_cast<hw_f16x4 *>(sA + b * kWSzA + ldsAh[j]) = h;
+            *reinterpret_cast<hw_f16x4 *>(sA + b * kWSzA + ldsAl[j]) = l;
+        }
+    };
+    auto gload = [&](int set) {
+        if (set == 0) gload_set(va0, vb0); else if (set == 1) gload_set(va1, vb1); else gload_set(va2, vb2);
+    };
+    auto lstore = [&](int set, int b) {
+        if (set == 0) lstore_set(va0, vb0, b); else if (set == 1) lstore_set(va1, vb1, b); else lstore_set(va2, vb2, b);
+    };
+    const int fr = lane & 31, fh = lane >> 5, fsw = hw_swz(fr);
+    const int fragA = (wm * 64 + fr) * kWRow, fragB = (wn * 64 + fr) * kWRow;
+    hw_f16x8 fa[2][2], fb[2][2];
+    auto frags = [&](int b, int ks) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                fa[mb][pl] = *reinterpret_cast<const hw_f16x8 *>(sA + b * kWSzA + fragA + mb * 32 * kWRow +
+                                                                 16 * ((4 * ks + 2 * pl + fh) ^ fsw));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                fb[nb][pl] = *reinterpret_cast<const hw_f16x8 *>(sB + b * kWSzB + fragB + nb * 32 * kWRow +
+                                                                 16 * ((4 * ks + 2 * pl + fh) ^ fsw));
+    };
+    auto mma = [&]() {
+        constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};       // smallest terms first (as k_fwd_h2)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mb][pa[t]], fb[nb][pb[t]],
+                                                                         acc[mb][nb], 0, 0, 0);
+    };
+    auto compute = [&](int b) {
+        frags(b, 0);
+        mma();
+        frags(b, 1);
+        mma();
+    };
+
+    // Stage s lives in LDS buffer s & 1 and travels through register set s % 3: its loads are issued at the
+    // top of stage s-3 and written to LDS at the end of stage s-1 - almost three stages (48 KB of x per CU)
+    // in flight, which is what an HBM miss under load needs (MI355X_MICROARCH.md: ~72 KiB per CU hide it)
+    gload(0);
+    if (nst > 1) gload(1);
+    if (nst > 2) gload(2);
+    lstore(0, 0);
+    __syncthreads();
+    int it = 0, cur = 0;
+#define DC_H2W_STAGE(SET_LOAD, SET_STORE)                                                             \
+    gload(SET_LOAD);                                  /* stage it+3 */                                \
+    __builtin_amdgcn_sched_barrier(0);                /* (hipcc otherwise sinks the loads below the MFMAs) */ \
+    compute(cur);                                                                                     \
+    lstore(SET_STORE, cur ^ 1);                       /* stage it+1 */                                \
+    __syncthreads();                                                                                  \
+    cur ^= 1;
+    for (; it + 5 < nst; it += 3) {                   // steady state, three stages per trip (static register sets)
+        DC_H2W_STAGE(0, 1)
+        DC_H2W_STAGE(1, 2)
+        DC_H2W_STAGE(2, 0)
+    }
+#undef DC_H2W_STAGE
+#define DC_H2W_TAIL(K, SET_LOAD, SET_STORE)                                                           \
+    if (it + K < nst) {                                                                               \
+        if (it + K + 3 < nst) gload(SET_LOAD);                                                        \
+        compute(cur);                                                                                 \
+        if (it + K + 1 < nst) lstore(SET_STORE, cur ^ 1);                                             \
+        __syncthreads();                                                                              \
+        cur ^= 1;                                                                                     \
+    }
+    for (; it < nst; it += 3) {                       // last stages (at most five), same static sets
+        DC_H2W_TAIL(0, 0, 1)
+        DC_H2W_TAIL(1, 1, 2)
+        DC_H2W_TAIL(2, 2, 0)
+    }
+#undef DC_H2W_TAIL
+
+    // epilogue: C/D fragment (reg, lane) -> row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col lane & 31
+    const bool relu = p.relu != 0;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int64_t col = col0 + wn * 64 + nb * 32 + c;
+        const bool cok = FULL || col < p.Fo;
+        const int64_t colc = cok ? col : p.Fo - 1;
+        const float bcol = p.bias ? p.bias[colc] : 0.f;
+        const float icol = h2_unscale(p.h2.b_rowmax[colc]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rl = wm * 64 + mb * 32 + 8 * g + 4 * h;
+                const float4 si = *reinterpret_cast<const float4 *>(&s_inv[rl]);
+                const float sv[4] = {si.x, si.y, si.z, si.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t row = row0 + rl + i;
+                    float v = (acc[mb][nb][4 * g + i] * sv[i]) * icol;
+                    v += bcol;
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (FULL || (cok && row < p.N)) p.out[row * p.ldo + col] = v;
+                }
+            }
+    }
+}
+
+static inline bool hw_al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
+static inline int hw_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// eligible: one K segment, pre-split weights, K % 32 == 0, no split reduction, enough row tiles to give
+// every CU one (a 128 x 256 tile is a whole CU's work: small N stays with the 64/128 x 128 kernel)
+bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
+    static const int wide = hw_env_int("DC_H2_WIDE", 1);
+    if (!wide || !p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1 || p.ksplit > 1)
+        return false;
+    if (p.Fi % kWBK != 0 || p.Fi < kWBK) return false;
+    if (p.x[0].ld * kWBM >= ((int64_t)1 << 30) || p.Fi * kWBN >= ((int64_t)1 << 30)) return false;
+    if (!hw_al16(p.x[0].p) || !hw_al16(p.w[0].p) || p.x[0].ld % 4 != 0) return false;
+    const int64_t tiles = ((p.N + kWBM - 1) / kWBM) * ((p.Fo + kWBN - 1) / kWBN);
+    static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
+    if (tiles < min_tiles || tiles >= (int64_t)INT32_MAX) return false;
+    const dim3 gd((unsigned)tiles), bd(512);
+    if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
+        hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);
+    else
+        hipLaunchKernelGGL((k_fwd_h2w<false>), gd, bd, 0, hs, p);
+    return true;
+}
+
+}  // namespace dc
