@@ -14,8 +14,8 @@
 //     latency and barrier skew.
 // Here: BK = 32 (x rows move as full 128-byte lines, 24 MFMAs per wave and barrier), one 128 x 256 tile
 // per 512-thread workgroup (x is staged and split ONCE for all 256 output columns instead of once per
-// 128), both operands staged through registers with the loads of stage it+3 issued at the top of stage it
-// and written to LDS at the end of stage it+2 (three register sets: ~3 stages = 48 KB of x in flight per
+// 128), both operands staged through registers with the loads of stage it+2 issued at the top of stage it
+// and written to LDS at the end of stage it+1 (two register sets: ~2 stages = 64 KB of x in flight per
 // CU, counted vmcnt - no LDS-DMA in the kernel, so hipcc's waits stay counted and __syncthreads() is a
 // bare s_barrier).  LDS rows are 128 bytes = 8 pieces of 16 bytes (piece q = 4*kstep + 2*plane + half);
 // piece q of row r sits at position q ^ F(r), F(r) = ((r >> 1) & 7) ^ 2*(r & 1): conflict-free
@@ -36,11 +36,11 @@ constexpr int kWSzA = kWBM * kWRow, kWSzB = kWBN * kWRow;
 
 __device__ __forceinline__ int hw_swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 1); }
 
-template <bool FULL>
+template <bool FULL, bool kNtA = false>
 __global__ void __launch_bounds__(512)
 k_fwd_h2w(FwdParams p) {
-    __shared__ __attribute__((aligned(16))) char sA[2 * kWSzA];
-    __shared__ __attribute__((aligned(16))) char sB[2 * kWSzB];
+    __shared__ __attribute__((aligned(16))) char sA[3 * kWSzA];      // ring of three stages: 144 KB
+    __shared__ __attribute__((aligned(16))) char sB[3 * kWSzB];
     __shared__ __attribute__((aligned(16))) float s_inv[kWBM];
     const unsigned ntn = (unsigned)((p.Fo + kWBN - 1) / kWBN);
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -81,20 +81,24 @@ k_fwd_h2w(FwdParams p) {
     const int nst = (int)(p.Fi / kWBK);
     const float *baseA = p.x[0].p + row0 * lda;                       // wave-uniform running bases
     const float *baseB = p.w[0].p + col0 * p.Fi;
-    hw_f32x4 va0[2], va1[2], va2[2];                                  // three register sets, named: no runtime index
-    hw_u32x4 vb0[4], vb1[4], vb2[4];
+    hw_f32x4 va0[2], va1[2];                                          // two register sets, named: no runtime index
+    hw_u32x4 vb0[4], vb1[4];
 
     auto gload_set = [&](hw_f32x4 (&va)[2], hw_u32x4 (&vb)[4]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) va[j] = *reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]);
+        for (int j = 0; j < 2; ++j)
+            va[j] = kNtA ? __builtin_nontemporal_load(reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]))
+                         : *reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) vb[j] = *reinterpret_cast<const hw_u32x4 *>(baseB + offB[j]);
         baseA += kWBK;
         baseB += kWBK;
     };
-    auto lstore_set = [&](const hw_f32x4 (&va)[2], const hw_u32x4 (&vb)[4], int b) {
+    auto lstore_b = [&](const hw_u32x4 (&vb)[4], int b) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<hw_u32x4 *>(sB + b * kWSzB + ldsB[j]) = vb[j];
+    };
+    auto lstore_a = [&](const hw_f32x4 (&va)[2], int b) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const hw_f32x4 v = va[j] * scA[j];
@@ -110,15 +114,25 @@ k_fwd_h2w(FwdParams p) {
         }
     };
     auto gload = [&](int set) {
-        if (set == 0) gload_set(va0, vb0); else if (set == 1) gload_set(va1, vb1); else gload_set(va2, vb2);
+        if (set == 0) gload_set(va0, vb0); else gload_set(va1, vb1);
+    };
+    auto lstoreB = [&](int set, int b) {
+        if (set == 0) lstore_b(vb0, b); else lstore_b(vb1, b);
+    };
+    auto lstoreA = [&](int set, int b) {
+        if (set == 0) lstore_a(va0, b); else lstore_a(va1, b);
     };
     auto lstore = [&](int set, int b) {
-        if (set == 0) lstore_set(va0, vb0, b); else if (set == 1) lstore_set(va1, vb1, b); else lstore_set(va2, vb2, b);
+        lstoreB(set, b);
+        lstoreA(set, b);
     };
     const int fr = lane & 31, fh = lane >> 5, fsw = hw_swz(fr);
     const int fragA = (wm * 64 + fr) * kWRow, fragB = (wn * 64 + fr) * kWRow;
-    hw_f16x8 fa[2][2], fb[2][2];
-    auto frags = [&](int b, int ks) {
+    // fragment registers: two sets (one k-step each), so that the reads of the next k-step - also the first
+    // one of the NEXT stage, whose buffer has been complete since the previous barrier - are in flight
+    // under the MFMAs of the current one and no MFMA waits on LDS latency behind a barrier
+    hw_f16x8 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
+    auto frags = [&](hw_f16x8 (&fa)[2][2], hw_f16x8 (&fb)[2][2], int b, int ks) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -132,7 +146,7 @@ k_fwd_h2w(FwdParams p) {
                 fb[nb][pl] = *reinterpret_cast<const hw_f16x8 *>(sB + b * kWSzB + fragB + nb * 32 * kWRow +
                                                                  16 * ((4 * ks + 2 * pl + fh) ^ fsw));
     };
-    auto mma = [&]() {
+    auto mma = [&](const hw_f16x8 (&fa)[2][2], const hw_f16x8 (&fb)[2][2]) {
         constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};       // smallest terms first (as k_fwd_h2)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -143,49 +157,63 @@ k_fwd_h2w(FwdParams p) {
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mb][pa[t]], fb[nb][pb[t]],
                                                                          acc[mb][nb], 0, 0, 0);
     };
-    auto compute = [&](int b) {
-        frags(b, 0);
-        mma();
-        frags(b, 1);
-        mma();
-    };
+    auto nextb = [](int b) { return b == 2 ? 0 : b + 1; };
 
-    // Stage s lives in LDS buffer s & 1 and travels through register set s % 3: its loads are issued at the
-    // top of stage s-3 and written to LDS at the end of stage s-1 - almost three stages (48 KB of x per CU)
-    // in flight, which is what an HBM miss under load needs (MI355X_MICROARCH.md: ~72 KiB per CU hide it)
-    gload(0);
-    if (nst > 1) gload(1);
-    if (nst > 2) gload(2);
+    // Stage s lives in LDS buffer s % 3.  During stage it: the loads of stage it+3 are issued (register set
+    // it & 1 ... see below), stage it+2 is written to LDS (its loads were issued at the top of stage it-1),
+    // the barrier at the end of stage it makes it readable from the end of stage it+1 on.
+    //   register set of stage s: s & 1; loads(s) at the top of stage s-3, store(s) at the end of stage s-2
+    gload(0);                                          // stage 0
+    if (nst > 1) gload(1);                             // stage 1
     lstore(0, 0);
+    if (nst > 2) gload(0);                             // stage 2
+    if (nst > 1) lstore(1, 1);
     __syncthreads();
-    int it = 0, cur = 0;
+    frags(fa0, fb0, 0, 0);
+    int it = 0, cur = 0;                               // cur = it % 3
+    // steady state: two stages per trip (static register sets); needs stages it+3 and it+4 to exist
+    // Inside a stage the order is pinned in three regions (hipcc schedules within a region only; left to itself
+    // it hoists the split's first multiplies - and with them the vmcnt wait for the staged tile - to the top
+    // of the stage and bunches the fragment reads right in front of the MFMAs that need them):
+    //   loads of stage it+3 | reads k-step 1, 12 MFMAs k-step 0, B tile of stage it+2 -> LDS |
+    //   reads k-step 0 of stage it+1, 12 MFMAs k-step 1, split + A tile of stage it+2 -> LDS | barrier
 #define DC_H2W_STAGE(SET_LOAD, SET_STORE)                                                             \
-    gload(SET_LOAD);                                  /* stage it+3 */                                \
-    __builtin_amdgcn_sched_barrier(0);                /* (hipcc otherwise sinks the loads below the MFMAs) */ \
-    compute(cur);                                                                                     \
-    lstore(SET_STORE, cur ^ 1);                       /* stage it+1 */                                \
-    __syncthreads();                                                                                  \
-    cur ^= 1;
-    for (; it + 5 < nst; it += 3) {                   // steady state, three stages per trip (static register sets)
-        DC_H2W_STAGE(0, 1)
-        DC_H2W_STAGE(1, 2)
-        DC_H2W_STAGE(2, 0)
+    {                                                                                                 \
+        const int b1 = nextb(cur), b2 = nextb(b1);                                                    \
+        gload(SET_LOAD);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        frags(fa1, fb1, cur, 1);                                                                      \
+        mma(fa0, fb0);                                                                                \
+        lstoreB(SET_STORE, b2);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        frags(fa0, fb0, b1, 0);                                                                       \
+        mma(fa1, fb1);                                                                                \
+        lstoreA(SET_STORE, b2);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        __syncthreads();                                                                              \
+        cur = b1;                                                                                     \
+    }
+    for (; it + 4 < nst; it += 2) {
+        DC_H2W_STAGE(1, 0)                             // loads stage it+3, stores stage it+2
+        DC_H2W_STAGE(0, 1)                             // loads stage it+4, stores stage it+3
     }
 #undef DC_H2W_STAGE
-#define DC_H2W_TAIL(K, SET_LOAD, SET_STORE)                                                           \
-    if (it + K < nst) {                                                                               \
-        if (it + K + 3 < nst) gload(SET_LOAD);                                                        \
-        compute(cur);                                                                                 \
-        if (it + K + 1 < nst) lstore(SET_STORE, cur ^ 1);                                             \
-        __syncthreads();                                                                              \
-        cur ^= 1;                                                                                     \
+    for (; it < nst; ++it) {                           // last stages (at most four)
+        const int b1 = nextb(cur), b2 = nextb(b1);
+        const bool even = (it & 1) == 0;
+        if (it + 3 < nst) {
+            if (even) gload(1); else gload(0);
+        }
+        frags(fa1, fb1, cur, 1);
+        mma(fa0, fb0);
+        if (it + 1 < nst) frags(fa0, fb0, b1, 0);
+        mma(fa1, fb1);
+        if (it + 2 < nst) {
+            if (even) lstore(0, b2); else lstore(1, b2);
+        }
+        __syncthreads();
+        cur = b1;
     }
-    for (; it < nst; it += 3) {                       // last stages (at most five), same static sets
-        DC_H2W_TAIL(0, 0, 1)
-        DC_H2W_TAIL(1, 1, 2)
-        DC_H2W_TAIL(2, 2, 0)
-    }
-#undef DC_H2W_TAIL
 
     // epilogue: C/D fragment (reg, lane) -> row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col lane & 31
     const bool relu = p.relu != 0;
@@ -235,7 +263,10 @@ bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
     if (tiles < min_tiles || tiles >= (int64_t)INT32_MAX) return false;
     const dim3 gd((unsigned)tiles), bd(512);
-    if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
+    static const int nt = hw_env_int("DC_H2_WIDE_NT", 0);
+    if (nt && p.N % kWBM == 0 && p.Fo % kWBN == 0)
+        hipLaunchKernelGGL((k_fwd_h2w<true, true>), gd, bd, 0, hs, p);
+    else if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
         hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);
     else
         hipLaunchKernelGGL((k_fwd_h2w<false>), gd, bd, 0, hs, p);

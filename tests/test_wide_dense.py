@@ -1,0 +1,72 @@
+"""The 128 x 256 (`k_fwd_h2w`, default for the wide layers) and 256 x 256 (`k_fwd_h2x`, DC_H2_WIDE=2) forms
+of the forward-shaped fp16x2 dense block: bit-identical to the 64/128 x 128 kernel (`k_fwd_h2`) and within
+2e-6 per row of float64, on ragged shapes (rows / columns that do not fill a tile, odd stage counts).
+
+The tile shape is chosen from environment variables read once per process, so every variant runs in a child
+process (which also keeps the selection of THIS process - the default - untouched)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+from deformcontact_amd import _lib, ops
+from deformcontact_amd.graph import current_stream_ptr
+from deformcontact_amd.ops import _i64_array, _ptr_array
+
+dev = torch.device("cuda:0")
+L = _lib.lib()
+gen = torch.Generator().manual_seed(1234)
+worst = 0.0
+for n, k, fo, relu, bias_on, ldpad in ((1000, 96, 256, True, True, 0), (4112, 1024, 256, True, True, 64),
+                                       (515, 64, 320, False, True, 4), (256, 32, 256, False, False, 0),
+                                       (2048, 160, 200, True, False, 8), (33, 1024, 17, True, True, 0)):
+    st = current_stream_ptr(dev)
+    slab_base = (torch.rand(n, k + ldpad, generator=gen) * 4 - 2).to(dev)
+    slab_base *= torch.logspace(-4, 0, n).unsqueeze(1).to(dev)            # rows on very different scales
+    slab = slab_base[:, :k]
+    w = ((torch.rand(fo, k, generator=gen) * 2 - 1) / k ** 0.5).to(dev)
+    bias = (torch.rand(fo, generator=gen) - 0.5).to(dev) if bias_on else None
+    rowmax = slab.abs().amax(1).contiguous()
+    wmax = ops.weight_rowmax([w])
+    wimg = torch.empty(fo, k, device=dev)
+    _lib.check(L.dc_tag_weight_prep(_ptr_array([w]), 1, fo, k, wmax.data_ptr(), wimg.data_ptr(), None, None, st), "prep")
+    out = torch.full((n, fo), float("nan"), device=dev)
+    _lib.check(L.dc_tag_linear_fwd_h2p(slab.data_ptr(), slab.stride(0), wimg.data_ptr(),
+                                       bias.data_ptr() if bias_on else None, int(relu), out.data_ptr(), fo, n, k, fo,
+                                       rowmax.data_ptr(), wmax.data_ptr(), None, 0, st), "fwd_h2p")
+    # the 64/128 x 128 kernel through the generic entry (fp32 weights, split in the kernel: never the wide shapes)
+    ref32 = torch.empty(n, fo, device=dev)
+    _lib.check(L.dc_tag_linear_fwd_h2(_ptr_array([slab]), _i64_array([slab.stride(0)]), _ptr_array([w]), 1,
+                                      bias.data_ptr() if bias_on else None, int(relu), ref32.data_ptr(), fo, n, k, fo,
+                                      rowmax.data_ptr(), wmax.data_ptr(), st), "fwd_h2")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref32), ("not bit-identical to k_fwd_h2", n, k, fo)
+    ref = slab.double().cpu() @ w.double().cpu().t()
+    if bias_on:
+        ref = ref + bias.double().cpu()
+    if relu:
+        ref = ref.clamp_min(0)
+    den = ref.abs().amax(1, keepdim=True).clamp_min(1e-300)
+    err = float(((out.double().cpu() - ref).abs() / den).max())
+    assert err < 2e-6, (err, n, k, fo)
+    worst = max(worst, err)
+print("OK", worst)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wide", ["1", "2"])
+def test_wide_dense_tiles_bit_identical_and_fp32_accurate(wide):
+    env = dict(os.environ, DC_H2_WIDE=wide, DC_H2_WIDE_MIN_TILES="1")
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.strip().splitlines()[-1].startswith("OK")

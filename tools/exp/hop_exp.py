@@ -137,7 +137,29 @@ def main():
                         L.hopexp_run(kind, g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(),
                                      xs.data_ptr(), xs.stride(0), ys.data_ptr(), ys.stride(0), n,
                                      current_stream_ptr(dev))
-        for kind in ("plain", "rowmax", 1, 3, 16, 17, 18, 19, 24):
+        # the same chains over SEPARATE contiguous [n, 256] blocks (row stride 1 KiB instead of the slab's 4 KiB + pad)
+        cslabs = [[torch.randn(n, f, device=dev) for _ in range(4)] for _ in slabs]
+
+        def rot_contig(kind):
+            for blocks in cslabs:
+                for j in range(3):
+                    xs, ys = blocks[j], blocks[j + 1]
+                    if kind == "plain":
+                        ops.hop(g.fwd, xs, out=ys)
+                    else:
+                        L.hopexp_run(kind, g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(),
+                                     xs.data_ptr(), xs.stride(0), ys.data_ptr(), ys.stride(0), n,
+                                     current_stream_ptr(dev))
+        for kind in ("plain", 0, 1):
+            rot_contig(kind)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                rot_contig(kind)
+            t = timeit(gr.replay, 20) / (3 * len(cslabs))
+            label = kind if isinstance(kind, str) else f"v{kind:02d} {NAMES.get(kind, 'rec variant')}"
+            print(f"{name:5s} rotating CONTIGUOUS blocks (> Infinity Cache), graph-replayed chains, {label:32s}: {t * 1e3:7.2f} us per hop  frac {comp / t / 1e6 / 8000:.3f}")
+        for kind in ("plain", "rowmax", 0, 1, 24):
             rot(kind)
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
