@@ -547,6 +547,193 @@ k_dw_split(DwParams p) {
     }
 }
 
+// ---- dW, fp16x2, 128 (Fo) x 256 (Fi) tiles, 32 nodes per stage (r02) ------------------------------
+// Same arithmetic as k_dw_split<2, false, 2> over the same node chunks (partials bit-identical); what changes
+// is the shape of the loop, for the reasons measured on the forward-shaped block (dc_dense_h2w.hip): with
+// 128 x 128 tiles a launch moves 536 MB from L2 to the CUs (g is re-read by 8 column tiles, x by 2 row
+// tiles) and runs 12 MFMAs per wave between barriers.  Here a workgroup of 8 waves owns a 128 x 256 tile
+// (one whole segment wide: 402 MB per launch), a stage is 32 nodes = two 16-deep k-steps (24 MFMAs per wave
+// and barrier), and the loads of stage it+2 are issued at the top of stage it (two register sets).
+constexpr int kDwK = 32;                                   // nodes per stage
+template <int COLS> struct TrImage32 {
+    static constexpr int ROWB = COLS * 2 + 64;             // bytes per node row of one plane (see TrImage)
+    static constexpr int PLANE = kDwK * ROWB;
+    static constexpr int BYTES = 2 * PLANE;
+};
+
+__global__ void __launch_bounds__(512)
+k_dw_h2w(DwParams p) {
+    using IA = TrImage32<128>;
+    using IB = TrImage32<256>;
+    constexpr int kStage = IA::BYTES + IB::BYTES, kOffB = IA::BYTES;      // 20,480 + 36,864 B
+    __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
+    const unsigned per_chunk = 2u * (unsigned)p.nseg;                     // (Fo half, segment) tiles
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);                 // a chunk's tiles share one L2
+    const unsigned chunk = lb / per_chunk, rem = lb % per_chunk;
+    const int s = (int)(rem >> 1);
+    const int64_t o0 = (int64_t)(rem & 1) * 128;
+    const int64_t n_beg = (int64_t)chunk * p.chunk_rows;
+    const int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
+    const int wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
+    const bool do_bias = p.bias_partial && s == 0;
+
+    // one power-of-two scale per operand and chunk: maxima of the row maxima over the chunk's nodes
+    float am = 0.f, bm = 0.f;
+    for (int64_t i = n_beg + threadIdx.x; i < n_end; i += 512) {
+        am = fmaxf(am, p.h2.a_rowmax[i]);
+        bm = fmaxf(bm, p.h2.b_rowmax[i]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        am = fmaxf(am, __shfl_xor(am, o));
+        bm = fmaxf(bm, __shfl_xor(bm, o));
+    }
+    {
+        float *red = reinterpret_cast<float *>(lds);
+        if ((threadIdx.x & 63) == 0) red[wid] = am, red[8 + wid] = bm;
+        __syncthreads();
+        am = bm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) am = fmaxf(am, red[i]), bm = fmaxf(bm, red[8 + i]);
+        __syncthreads();
+    }
+    const float sca = h2_scale(am), scb = h2_scale(bm), inva = h2_unscale(am), invb = h2_unscale(bm);
+
+    // staging: g tile 32 x 128 (32 float4 per node row, 16 rows per pass), x tile 32 x 256 (64 per row, 8 rows)
+    const int c4g = threadIdx.x & 31, krg = threadIdx.x >> 5;
+    const int c4x = threadIdx.x & 63, krx = threadIdx.x >> 6;
+    const int64_t ldg = p.g.ld, ldx = p.x[s].ld;
+    unsigned offg[2], offx[4];
+    int ldsg[2], ldsx[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        offg[j] = (unsigned)((krg + 16 * j) * ldg + 4 * c4g);
+        ldsg[j] = (krg + 16 * j) * IA::ROWB + 8 * c4g;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        offx[j] = (unsigned)((krx + 8 * j) * ldx + 4 * c4x);
+        ldsx[j] = kOffB + (krx + 8 * j) * IB::ROWB + 8 * c4x;
+    }
+    const float *baseg = p.g.p + n_beg * ldg + o0;                        // wave-uniform running bases
+    const float *basex = p.x[s].p + n_beg * ldx;
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    f32x4 vg0[2], vg1[2], vx0[4], vx1[4];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](f32x4 (&vg)[2], f32x4 (&vx)[4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vg[j] = *reinterpret_cast<const f32x4 *>(baseg + offg[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vx[j] = *reinterpret_cast<const f32x4 *>(basex + offx[j]);
+        baseg += kDwK * ldg;
+        basex += kDwK * ldx;
+    };
+    auto split_store = [&](char *dst, int plane, f32x4 v, float sc) {
+        v = v * sc;
+        f16x4 h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 a = (_Float16)v[i];
+            h[i] = a;
+            l[i] = (_Float16)(v[i] - (float)a);
+        }
+        *reinterpret_cast<f16x4 *>(dst) = h;
+        *reinterpret_cast<f16x4 *>(dst + plane) = l;
+    };
+    auto lstore = [&](const f32x4 (&vg)[2], const f32x4 (&vx)[4], int b) {
+        char *buf = lds + b * kStage;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            split_store(buf + ldsg[j], IA::PLANE, vg[j], sca);
+            if (do_bias) bsum += vg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_store(buf + ldsx[j], IB::PLANE, vx[j], scb);
+    };
+    f32x16 acc[2][2];
+    zero_acc<2>(acc);
+    auto compute = [&](int b) {
+        const char *buf = lds + b * kStage;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            SplitFrag<2, 2> f;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    f.a[mb][pl] = tr_operand<IA::ROWB>(buf + pl * IA::PLANE + ks * 16 * IA::ROWB, wm * 64 + mb * 32);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    f.b[nb][pl] = tr_operand<IB::ROWB>(buf + kOffB + pl * IB::PLANE + ks * 16 * IB::ROWB,
+                                                       wn * 64 + nb * 32);
+            }
+            mma_split<2, 2>(f, acc);
+        }
+    };
+
+    const int nst = (int)((n_end - n_beg) / kDwK);
+    if (nst > 0) {
+        gload(vg0, vx0);
+        if (nst > 1) gload(vg1, vx1);
+        lstore(vg0, vx0, 0);
+    }
+    __syncthreads();
+    int it = 0;
+#define DC_DW_STAGE(CUR, VG_L, VX_L, VG_S, VX_S)                                                      \
+    gload(VG_L, VX_L);                                 /* stage it+2 */                               \
+    __builtin_amdgcn_sched_barrier(0);                 /* keep the loads at the top of the stage */   \
+    compute(CUR);                                                                                     \
+    lstore(VG_S, VX_S, CUR ^ 1);                       /* stage it+1 */                               \
+    __syncthreads();
+    for (; it + 3 < nst; it += 2) {
+        DC_DW_STAGE(0, vg0, vx0, vg1, vx1)
+        DC_DW_STAGE(1, vg1, vx1, vg0, vx0)
+    }
+#undef DC_DW_STAGE
+#define DC_DW_TAIL(K, CUR, VG_L, VX_L, VG_S, VX_S)                                                    \
+    if (it + K < nst) {                                                                               \
+        if (it + K + 2 < nst) gload(VG_L, VX_L);                                                      \
+        compute(CUR);                                                                                 \
+        if (it + K + 1 < nst) lstore(VG_S, VX_S, CUR ^ 1);                                            \
+        __syncthreads();                                                                              \
+    }
+    for (; it < nst; it += 2) {
+        DC_DW_TAIL(0, 0, vg0, vx0, vg1, vx1)
+        DC_DW_TAIL(1, 1, vg1, vx1, vg0, vx0)
+    }
+#undef DC_DW_TAIL
+
+    float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
+    for_each_acc<2>(acc, wm, wn, [&](int r, int c, float v) {
+        out[(o0 + r) * p.Fi + c] = (v * inva) * invb;
+    });
+    if (do_bias) {                                      // column sums of g over the chunk's nodes
+        f32x4 *red = reinterpret_cast<f32x4 *>(lds);
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 16; ++g) t += red[g * 32 + threadIdx.x];
+            float *bp = p.bias_partial + (int64_t)chunk * p.Fo + o0 + 4 * threadIdx.x;
+            bp[0] = t[0], bp[1] = t[1], bp[2] = t[2], bp[3] = t[3];
+        }
+    }
+}
+
+// eligible: fp16x2, pre-masked g, Fo = 256, every segment 256 wide, node chunks that are whole stages
+static bool dw_h2w_launch(const DwParams &p, hipStream_t hs) {
+    static const int wide = getenv("DC_DW_WIDE") ? atoi(getenv("DC_DW_WIDE")) : 1;
+    if (!wide || p.has_mask || p.Fo != 256 || p.Fi != 256 || p.N % kDwK != 0 || p.chunk_rows % kDwK != 0)
+        return false;
+    if (p.g.ld * kDwK >= ((int64_t)1 << 30)) return false;
+    for (int s = 0; s < p.nseg; ++s)
+        if (p.x[s].ld * kDwK >= ((int64_t)1 << 30)) return false;
+    const dim3 gd((unsigned)(2 * p.nseg * p.nchunks)), bd(512);
+    hipLaunchKernelGGL(k_dw_h2w, gd, bd, 0, hs, p);
+    return true;
+}
+
 // wt[s][f][o] = w[s][o][f] for up to kMaxSeg segments in one launch (32x32 LDS tiles)
 struct TransposeParams {
     const float *w[kMaxSeg];
@@ -642,6 +829,7 @@ bool dw_split_launch(const DwParams &p, int mb, int np, hipStream_t hs) {
     if (p.has_mask && (!al16(p.mask.p) || p.mask.ld % 4 != 0)) return false;
     for (int s = 0; s < p.nseg; ++s)
         if (!al16(p.x[s].p) || p.x[s].ld % 4 != 0) return false;
+    if (np == 2 && dw_h2w_launch(p, hs)) return true;
     const int64_t tiles = ((p.Fo + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN);
     const dim3 gd((unsigned)(tiles * p.nseg * p.nchunks)), bd(256);
 #define DC_L(MB_, M_)                                                                 \

@@ -70,3 +70,61 @@ def test_wide_dense_tiles_bit_identical_and_fp32_accurate(wide):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.strip().splitlines()[-1].startswith("OK")
+
+
+CHILD_DW = r"""
+import hashlib
+import sys
+import torch
+sys.path.insert(0, %(root)r)
+from deformcontact_amd import _lib, ops
+from deformcontact_amd.graph import current_stream_ptr
+from deformcontact_amd.ops import _i64_array, _ptr_array
+
+dev = torch.device("cuda:0")
+L = _lib.lib()
+gen = torch.Generator().manual_seed(99)
+digest = hashlib.sha1()
+worst = 0.0
+for n, nseg in ((4096, 4), (2080, 1), (8192 + 32, 3)):
+    fi = fo = 256
+    st = current_stream_ptr(dev)
+    slab = ops._alloc_slab(n, nseg * fi, dev)
+    slab.copy_((torch.rand(n, nseg * fi, generator=gen) * 2 - 1).to(dev) * torch.logspace(-3, 0, n).unsqueeze(1).to(dev))
+    g = ((torch.rand(n, fo, generator=gen) * 2 - 1) * torch.logspace(0, -3, n).unsqueeze(1)).to(dev)
+    xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+    gws = [torch.empty(fo, fi, device=dev) for _ in range(nseg)]
+    gb = torch.empty(fo, device=dev)
+    nb = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    growmax, xrowmax = g.abs().amax(1).contiguous(), slab.abs().amax(1).contiguous()
+    _lib.check(L.dc_tag_linear_bwd_dw_h2(g.data_ptr(), fo, None, fo, _ptr_array(xs), _i64_array([slab.stride(0)] * nseg),
+                                         nseg, _ptr_array(gws), nseg, fi, gb.data_ptr(), 0, scratch.data_ptr(), nb,
+                                         n, fi, fo, growmax.data_ptr(), xrowmax.data_ptr(), st), "dw_h2")
+    torch.cuda.synchronize()
+    for s in range(nseg):
+        ref = g.double().cpu().t() @ xs[s].double().cpu()
+        err = float((gws[s].double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (err, n, s)
+        worst = max(worst, err)
+        digest.update(gws[s].cpu().numpy().tobytes())
+    refb = g.double().cpu().sum(0)
+    assert float((gb.double().cpu() - refb).abs().max() / refb.abs().max()) < 2e-6
+print("OK", worst, digest.hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_wide_dw_tiles_bit_identical_to_128x128_and_fp32_accurate():
+    """`k_dw_h2w` (128 x 256 tiles, 32 nodes per stage; default for the wide layers) against float64, and
+    bit for bit against `k_dw_split<2, false, 2>` (DC_DW_WIDE=0) - same chunks, same k order."""
+    digests = []
+    for wide in ("1", "0"):
+        env = dict(os.environ, DC_DW_WIDE=wide)
+        r = subprocess.run([sys.executable, "-c", CHILD_DW % {"root": ROOT}], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        last = r.stdout.strip().splitlines()[-1].split()
+        assert last[0] == "OK"
+        digests.append(last[2])
+    assert digests[0] == digests[1]
