@@ -122,11 +122,15 @@ def cpu_baseline(batch: int, budget_s: float):
                       f"{cores} threads (of {os.cpu_count()} logical CPUs; best-scaling setting)"}
 
 
-def dense_roofline(dev, n_s: int, n_r: int, reps: int):
-    """Second roofline object: the wide dense blocks (about half of the step), MFMA-bound.  The six
+def dense_roofline(dev, n_s: int, n_r: int, reps: int, graphs=None):
+    """Second roofline object: the wide dense blocks (about 40 % of the step), MFMA-bound.  The six
     layer-2 launches of a step (forward, dX - a second forward-shaped block -, dW for the soft and
-    the rigid branch; F = 256, K = 4 x 256) interleaved on cold buffers, HIP events.  `achieved`
-    counts the MFMA FLOPs actually executed (products x algorithmic); `fp32_equivalent` is
+    the rigid branch; F = 256, K = 4 x 256), timed with HIP events AS A STEP LAUNCHES THEM: inside the
+    layer-2 op sequence of each branch (3 hops that write the slab -> forward block -> gradient mask ->
+    3 transposed hops on the gradient slab -> dX block -> dW block + its slab reduce), so that the
+    operands are in the cache state a step leaves them in (the same rule as for the hop's `roofline`).
+    The same six launches interleaved on cold, rotating buffers are kept as `cold_us_per_6_launches`.
+    `achieved` counts the MFMA FLOPs actually executed (products x algorithmic); `fp32_equivalent` is
     algorithmic FLOPs / time."""
     from deformcontact_amd import _lib, ops
     from deformcontact_amd.graph import current_stream_ptr
@@ -137,7 +141,8 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
     nseg = 4
     launches, flops = [], 0.0
     keep = []
-    for n in (n_s, n_r):
+    branches = []
+    for bi, n in enumerate((n_s, n_r)):
         slab = ops._alloc_slab(n, nseg * fi, dev).normal_()      # the product's (row-padded) slab layout
         lds = slab.stride(0)
         xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
@@ -183,7 +188,7 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
             pa_wt = _ptr_array(wts)
             gx = torch.empty(n, fi, device=dev)
             growmax = gslab.normal_().abs().amax(1).contiguous()
-            g0max = ops.rowabsmax(g)
+            g0max = growmax.clone()                   # row maxima of the masked gradient (block 0): any upper bound
             keep += [rowmax, wmax, wt, wts, wtmax, pa_wt, gx, growmax, g0max]
 
             wimg, wtimg = torch.empty(fo, nseg * fi, device=dev), torch.empty(fi, nseg * fo, device=dev)
@@ -200,11 +205,15 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
                 L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gslab.stride(0), wtimg.data_ptr(), None, 0, gx.data_ptr(),
                                         fi, n, nseg * fo, fi, growmax.data_ptr(), wtmax.data_ptr(), None, 0, st)
 
-            def dw(n=n, g=g, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb,
+            def dw(n=n, gslab=gslab, pa_x=pa_x, pa_ld=pa_ld, pa_gw=pa_gw, gb=gb, scratch=scratch, nb=nb,
                    g0max=g0max, rowmax=rowmax):
-                L.dc_tag_linear_bwd_dw_h2(g.data_ptr(), fo, None, fo, pa_x, pa_ld, nseg, pa_gw, nseg, fi,
-                                          gb.data_ptr(), 0, scratch.data_ptr(), nb, n, fi, fo,
+                # as the backward launches it: the masked gradient is block 0 of the gradient slab
+                L.dc_tag_linear_bwd_dw_h2(gslab.data_ptr(), gslab.stride(0), None, fo, pa_x, pa_ld, nseg, pa_gw,
+                                          nseg, fi, gb.data_ptr(), 0, scratch.data_ptr(), nb, n, fi, fo,
                                           g0max.data_ptr(), rowmax.data_ptr(), st)
+
+            branches.append({"n": n, "slab": slab, "gslab": gslab, "rowmax": rowmax, "growmax": growmax,
+                             "g0max": g0max, "out": out, "gout": g, "fwd": fwd, "dx": dx, "dw": dw})
 
         launches += [fwd, dx, dw]
         flops += 3 * 2.0 * n * fi * nseg * fo
@@ -217,21 +226,75 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int):
             f()
     ev1.record()
     torch.cuda.synchronize()
-    ms = ev0.elapsed_time(ev1) / reps
+    cold_ms = ev0.elapsed_time(ev1) / reps
+    ms, in_seq = cold_ms, None
+    if graphs is not None and len(branches) == 2:
+        # the layer-2 op sequence of a step, eager (the host runs ahead of the device: ~15 launches of
+        # >= 15 us each per branch), HIP events on this stream around the three dense launches
+        evs = []
+
+        def sequence(record):
+            for b, g in zip(branches, graphs):
+                ops.chained_hops(g, b["slab"], fi, 3, backward=False, rowmax=b["rowmax"])
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+                if record:
+                    e[0].record()
+                b["fwd"]()
+                if record:
+                    e[1].record()
+                L.dc_tag_mask_grad(b["gout"].data_ptr(), fo, b["out"].data_ptr(), fo, b["gslab"].data_ptr(),
+                                   b["gslab"].stride(0), b["n"], fo, b["g0max"].data_ptr(),
+                                   b["growmax"].data_ptr(), st)
+                ops.chained_hops(g, b["gslab"], fo, 3, backward=False, rowmax=b["growmax"], transposed=True,
+                                 rowmax_has_block0=True)
+                if record:
+                    e[2].record()
+                b["dx"]()
+                if record:
+                    e[3].record()
+                b["dw"]()
+                if record:
+                    e[4].record()
+                    evs.append(e)
+        for _ in range(2):
+            sequence(False)
+        for _ in range(max(reps, 5)):
+            sequence(True)
+        torch.cuda.synchronize()
+        t = {"fwd": [], "dX": [], "dW_incl_reduce": []}
+        for e in evs:
+            t["fwd"].append(e[0].elapsed_time(e[1]))
+            t["dX"].append(e[2].elapsed_time(e[3]))
+            t["dW_incl_reduce"].append(e[3].elapsed_time(e[4]))
+        nrep = len(evs) // 2
+        ms = sum(sum(v) for v in t.values()) / nrep
+        in_seq = {k: {"soft_us": round(sum(v[0::2]) / nrep * 1e3, 1), "rigid_us": round(sum(v[1::2]) / nrep * 1e3, 1)}
+                  for k, v in t.items()}
     h2 = ops.DENSE_SPLIT_BF16 and ops.DENSE_F16X2
     prod = (3 if h2 else ops.DENSE_PRODUCTS) if ops.DENSE_SPLIT_BF16 else 1
     peak = 2500.0 if ops.DENSE_SPLIT_BF16 else 157.3
     achieved = prod * flops / ms / 1e9
-    return {"bound": "mfma", "kernel": ("dc::k_fwd_split<*,2> x2 (forward, dX in forward shape) / k_dw_split<*,2> "
-                                        "(layer-2 dense block, fp16x2)" if h2 else
-                                        "dc::k_fwd_split / k_dx_split / k_dw_split (layer-2 dense block)")
-            if ops.DENSE_SPLIT_BF16 else "dc::k_fwd_fast / k_dx_fast / k_dw_fast",
-            "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "executed": (f"{prod} {'fp16' if h2 else 'bf16'} MFMA products per fp32 product tile"
-                         if ops.DENSE_SPLIT_BF16 else "fp32 MFMA"),
-            "fp32_equivalent_TFLOPs": round(flops / ms / 1e9, 1), "fp32_mfma_peak": 157.3,
-            "algorithmic_flop_per_step_l2": flops, "us_per_6_launches": round(ms * 1e3, 1),
-            "sustained_bf16_peak_measured": "1.5-1.86 PF/s under DVFS (tools/mfma_peak_bf16.hip)"}
+    res = {"bound": "mfma", "kernel": ("dc::k_fwd_h2w x2 (forward, dX in forward shape) / k_dw_h2w "
+                                       "(layer-2 dense block, fp16x2, 128 x 256 tiles)" if h2 else
+                                       "dc::k_fwd_split / k_dx_split / k_dw_split (layer-2 dense block)")
+           if ops.DENSE_SPLIT_BF16 else "dc::k_fwd_fast / k_dx_fast / k_dw_fast",
+           "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+           "executed": (f"{prod} {'fp16' if h2 else 'bf16'} MFMA products per fp32 product tile"
+                        if ops.DENSE_SPLIT_BF16 else "fp32 MFMA"),
+           "fp32_equivalent_TFLOPs": round(flops / ms / 1e9, 1), "fp32_mfma_peak": 157.3,
+           "algorithmic_flop_per_step_l2": flops, "us_per_6_launches": round(ms * 1e3, 1),
+           "cold_us_per_6_launches": round(cold_ms * 1e3, 1),
+           "cold_frac": round(prod * flops / cold_ms / 1e9 / peak, 4),
+           "sustained_bf16_peak_measured": "1.5-1.86 PF/s under DVFS (tools/mfma_peak_bf16.hip)"}
+    if in_seq is not None:
+        res["measured"] = ("the six launches inside the layer-2 op sequence of a step (hops -> forward -> mask -> "
+                           "transposed hops -> dX -> dW + slab reduce, both branches), eager, HIP events on the "
+                           "launch stream around each dense launch; `cold_*`: the same launches interleaved on "
+                           "cold rotating buffers")
+        res["in_sequence_us"] = in_seq
+    else:
+        res["measured"] = "six launches interleaved on cold rotating buffers, HIP events"
+    return res
 
 
 def full_step_b4(dev, steps: int = 20, batch: int = 4):
@@ -795,7 +858,7 @@ def main():
             "cases_isolated": {"soft_fwd": per_case[0], "soft_bwd": per_case[1],
                                "rigid_fwd": per_case[2], "rigid_bwd": per_case[3]},
         }
-        out["roofline_mfma"] = dense_roofline(dev, n_s, n_r, args.kernel_reps // 4 or 1)
+        out["roofline_mfma"] = dense_roofline(dev, n_s, n_r, args.kernel_reps // 4 or 1, graphs=(gs, gr))
         if world == 1 and not args.no_strict_fp32:
             # auditable line: the headline step with every dense block on the fp32 matrix cores
             # (v_mfma_f32_32x32x2_f32, exact fp32 products) instead of the split fp16 / bf16 forms
