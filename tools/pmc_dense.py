@@ -33,7 +33,7 @@ def parse(dirs):
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            if not any(t in name for t in ("k_fwd_h2", "k_dw_split", "k_fwd_split", "k_fwd_bf16")):
+            if not any(t in name for t in ("k_fwd_h2", "k_dw_h2w", "k_dw_split", "k_fwd_split", "k_fwd_bf16")):
                 continue
             key = (name.split("(")[0].replace("void ", ""), int(r["Grid_Size"]))
             e = per.setdefault(key, {})
