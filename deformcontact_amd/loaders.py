@@ -48,6 +48,21 @@ class SyntheticEverydayDataset:
         return self.OBJECTS[idx % len(self.OBJECTS)], rest, deff, meta, rig
 
 
+class InMemoryDataset:
+    """Samples of ``dataset`` materialised once (the reference's ``EverydayDeformDataset`` likewise keeps its
+    pre-processed graphs and only indexes them per step, ``loaders/everyday_deform.py``): ``__getitem__`` is a
+    list lookup, so a training loop measures the loader + step, not the mesh synthesiser."""
+
+    def __init__(self, dataset):
+        self.samples = [dataset[i] for i in range(len(dataset))]
+
+    def __len__(self) -> int:
+        return len(self.samples)
+
+    def __getitem__(self, i: int):
+        return self.samples[i]
+
+
 def iterate_batches(dataset, batch_size: int, shuffle: bool = False, seed: int = 0,
                     drop_last: bool = False) -> Iterator[tuple]:
     """Minimal ``DataLoader(dataset, batch_size, shuffle, collate_fn=collate_fn)``."""

@@ -188,6 +188,15 @@ def test_prefetch_loader_matches_plain_iteration_cpu():
                 assert torch.equal(x.x, y.x) and torch.equal(x.edge_index, y.edge_index)
                 assert torch.equal(x.pos, y.pos) and torch.equal(x.batch, y.batch)
 
+    # the same samples held in memory: identical batches, __getitem__ a lookup
+    from deformcontact_amd.loaders import InMemoryDataset
+    mem = InMemoryDataset(ds)
+    assert len(mem) == len(ds)
+    for (c0, b0), c1 in zip(plain, iterate_batches(mem, 2, shuffle=True, seed=7)):
+        assert c0[0] == c1[0]
+        for x, y in zip(b0, to_batches(c1, None)):
+            assert torch.equal(x.x, y.x) and torch.equal(x.edge_index, y.edge_index)
+
     class Broken(SyntheticEverydayDataset):
         def __getitem__(self, i):
             if i == 3:

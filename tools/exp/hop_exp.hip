@@ -246,6 +246,79 @@ k_hop_rec(const int32_t *__restrict__ ptr, const Rec *__restrict__ rec,
 
 #define LAUNCH(K, grid, threads) hipLaunchKernelGGL(K, dim3(grid), dim3(threads), 0, (hipStream_t)stream, ptr, other, w, x, ldx, y, ldy, N)
 
+// ---- windowed: a 1024-thread workgroup owns R destination rows x ONE column half (128 floats = 512 B per row)
+// and first stages the rows [r0 - H, r0 + R + H) of that half into LDS by LDS-DMA (1 KiB per wave instruction =
+// two staged half rows); neighbours inside the window are then read from LDS (ds_read_b64), the others from
+// global memory as before.  Meshes whose numbering is local (|src - dst| <= H for most edges) turn E x 1 KiB of
+// L2 gathers per launch into (R + 2H) / R staged rows.  Wave-uniform neighbour ids -> the hit test is scalar.
+static __device__ __forceinline__ void axpy2(float2 &a, float w, const float2 &v) {
+    const float mx = w * v.x, my = w * v.y;
+    a.x = a.x + mx; a.y = a.y + my;
+}
+
+template <int U>
+__global__ void __launch_bounds__(1024)
+k_hop_win(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other, const float *__restrict__ w,
+          const float *__restrict__ x, int64_t ldx, float *y, int64_t ldy, int64_t N, int R, int H) {
+    extern __shared__ __attribute__((aligned(16))) char win[];
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int ch = (int)(lb & 1u);                                   // column half
+    const int64_t r0 = (int64_t)(lb >> 1) * R;
+    if (r0 >= N) return;
+    const int64_t r1 = r0 + R < N ? r0 + R : N;
+    const int64_t w0 = r0 - H > 0 ? r0 - H : 0, w1 = r1 + H < N ? r1 + H : N;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const float *xc = x + ch * 128;
+    // stage: DMA instruction j moves window rows 2j, 2j+1 (this half) to win + 1024 j
+    const int npair = (int)((w1 - w0 + 1) >> 1);
+    for (int j = wave; j < npair; j += 16) {
+        int64_t row = w0 + 2 * j + (lane >> 5);
+        row = row < w1 ? row : w1 - 1;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(xc + row * ldx + (lane & 31) * 4),
+                                         (void __attribute__((address_space(3))) *)(win + 1024 * j), 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xF70 | 0);                            // vmcnt(0)
+    __syncthreads();
+    const int iw0 = (int)w0, iw1 = (int)w1;
+    for (int64_t row = r0 + wave; row < r1; row += 16) {
+        const int beg = ptr[row], end = ptr[row + 1];
+        float2 acc = make_float2(0.f, 0.f);
+        for (int p = beg; p < end; p += U) {
+            const int n = end - p;
+            int s[U]; float ww[U]; float2 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) if (j < n) { s[j] = other[p + j]; ww[j] = w[p + j]; }
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+                if (j < n) {
+                    if (s[j] >= iw0 && s[j] < iw1)
+                        v[j] = *reinterpret_cast<const float2 *>(win + (s[j] - iw0) * 512 + lane * 8);
+                    else
+                        v[j] = *reinterpret_cast<const float2 *>(xc + (int64_t)s[j] * ldx + lane * 2);
+                }
+#pragma unroll
+            for (int j = 0; j < U; ++j) if (j < n) axpy2(acc, ww[j], v[j]);
+        }
+        *reinterpret_cast<float2 *>(y + row * ldy + ch * 128 + lane * 2) = acc;
+    }
+}
+
+extern "C" int hopexp_run_win(int R, int H, const int32_t *ptr, const int32_t *other, const float *w,
+                              const float *x, int64_t ldx, float *y, int64_t ldy, int64_t N, void *stream) {
+    const size_t lds = (size_t)((R + 2 * H + 1) / 2) * 1024;
+    static size_t set = 0;
+    if (lds > set) {
+        if (hipFuncSetAttribute((const void *)k_hop_win<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return 2;
+        set = lds;
+    }
+    const unsigned grid = (unsigned)(2 * ((N + R - 1) / R));
+    hipLaunchKernelGGL((k_hop_win<8>), dim3(grid), dim3(1024), lds, (hipStream_t)stream, ptr, other, w, x, ldx, y,
+                       ldy, N, R, H);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 extern "C" int hopexp_run_rec(int variant, const int32_t *ptr, const void *rec, const int32_t *other,
                               const float *w, const float *x, int64_t ldx, float *y, int64_t ldy,
                               int64_t N, void *stream) {

@@ -159,6 +159,32 @@ def main():
             t = timeit(gr.replay, 20) / (3 * len(cslabs))
             label = kind if isinstance(kind, str) else f"v{kind:02d} {NAMES.get(kind, 'rec variant')}"
             print(f"{name:5s} rotating CONTIGUOUS blocks (> Infinity Cache), graph-replayed chains, {label:32s}: {t * 1e3:7.2f} us per hop  frac {comp / t / 1e6 / 8000:.3f}")
+        # windowed variants (R destination rows, halo H) in the same regime, checked bit for bit first
+        L.hopexp_run_win.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, i64, vp, i64, i64, vp]
+        for R_, H_ in ((64, 40), (60, 48), (64, 56), (96, 56), (128, 56), (128, 40), (32, 56)):
+            def rot_win():
+                for sl in slabs:
+                    for j in range(3):
+                        xs, ys = sl[:, j * f:(j + 1) * f], sl[:, (j + 1) * f:(j + 2) * f]
+                        rc = L.hopexp_run_win(R_, H_, g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(),
+                                              xs.data_ptr(), xs.stride(0), ys.data_ptr(), ys.stride(0), n,
+                                              current_stream_ptr(dev))
+                        assert rc == 0, rc
+            xs, ys = slabs[0][:, :f], slabs[0][:, f:2 * f]
+            ref = ops.hop(g.fwd, xs).clone()
+            ys.zero_()
+            L.hopexp_run_win(R_, H_, g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(), xs.data_ptr(),
+                             xs.stride(0), ys.data_ptr(), ys.stride(0), n, current_stream_ptr(dev))
+            torch.cuda.synchronize()
+            okk = "exact" if torch.equal(ys, ref) else "MISMATCH"
+            rot_win()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                rot_win()
+            t = timeit(gr.replay, 20) / (3 * len(slabs))
+            print(f"{name:5s} rotating slabs (> Infinity Cache), graph-replayed chains, windowed R={R_:3d} H={H_:2d} "
+                  f"({(R_ + 2 * H_ + 1) // 2} KB LDS): {t * 1e3:7.2f} us per hop  frac {comp / t / 1e6 / 8000:.3f}  {okk}")
         for kind in ("plain", "rowmax", 0, 1, 24):
             rot(kind)
             torch.cuda.synchronize()
