@@ -59,6 +59,23 @@ __device__ __forceinline__ float vabsmax(const float4 &v) {
 // MI355X_MICROARCH.md "Residency"); the row-maxima variant needed 85 and ran with one block per CU
 // fewer - the whole +1.3 us it cost over the plain hop (r02 hop_exp).  The attribute caps the
 // allocation (the few extra scalars live in VGPR lanes).
+// max over the 64 lanes of a wave of non-negative values (every lane gets it; DPP + readlane, no LDS)
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    const int i = __float_as_int(v);
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false)));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = dpp_max<0xB1>(v);                    // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E>(v);                    // quad_perm [2,3,0,1]
+    v = dpp_max<0x141>(v);                   // row_half_mirror
+    v = dpp_max<0x140>(v);                   // row_mirror: every lane = max of its 16-lane row
+    const int i = __float_as_int(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(i, 0)), b = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(i, 32)), d = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
 template <int VEC, int U, bool RM = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
@@ -105,8 +122,10 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
         if (RM) rmax = fmaxf(rmax, fmaxf(vabsmax(acc), vabsmax(self)));
     }
     if (RM) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+        // wave maximum without the LDS pipe: four DPP steps give every lane the maximum of its 16-lane row, the
+        // four row values are read as scalars.  (__shfl_xor compiles to six dependent ds_bpermute_b32, each
+        // behind an lgkmcnt(0) wait: ~0.5 us at the end of every row's wave, +1.3 us per launch - r02 hop_exp.)
+        rmax = wave_max_nonneg(rmax);
         if (lane == 0) rowmax[row] = rmax;
     }
 }
