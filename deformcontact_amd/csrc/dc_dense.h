@@ -176,8 +176,6 @@ bool dw_split_launch(const DwParams &p, int mb, int products, hipStream_t hs);
 bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs);
 // 128 x 256 tiles, BK = 32, for the wide layers (dc_dense_h2w.hip); tried first by fwd_h2_launch
 bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs);
-// 256 x 256 tiles, one wave per SIMD (dc_dense_h2x.hip); DC_H2_WIDE=2
-bool fwd_h2x_launch(const FwdParams &p, hipStream_t hs);
 // wt[s][f][o] = ws[s][o][f]
 void transpose_weights_launch(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *wt,
                               hipStream_t hs);

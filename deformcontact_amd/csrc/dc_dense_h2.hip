@@ -247,7 +247,6 @@ static inline bool h2_al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
 
 bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs) {
     if (!p.h2.a_rowmax || !p.h2.b_rowmax || p.nseg != 1) return false;
-    if (fwd_h2x_launch(p, hs)) return true;
     if (fwd_h2w_launch(p, hs)) return true;
     if (p.Fi % BK != 0 || p.Fi < BK) return false;
     // 32-bit per-thread offsets: a block touches 128 rows of each operand

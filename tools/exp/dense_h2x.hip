@@ -1,4 +1,5 @@
-// dc_dense_h2x.hip -- forward-shaped fp16x2 dense block, 256 x 256 tiles, one wave per SIMD (gfx950).
+// tools/exp/dense_h2x.hip -- EXPERIMENT (not part of the product library): the forward-shaped fp16x2 dense block
+// with 256 x 256 tiles, one wave per SIMD (gfx950).  Built into tools/exp/libdenseh2x.so by tools/exp/dense_h2x.py.
 //
 // Same arithmetic and operand formats as k_fwd_h2 / k_fwd_h2w (results bit-identical).  Why a third shape
 // (r02 ablations of k_fwd_h2w, tools/exp/dense_abl.py + astream.py): with 128-row tiles every workgroup
@@ -10,7 +11,7 @@
 // branch of the everyday batch (128 + 96 tiles), so this shape pays when the soft and the rigid branch run
 // side by side on their two streams (224 tiles), and costs nothing when they do not (the tile does twice the
 // work of a 128-row tile in about the time two of them take today).
-#include "dc_dense.h"
+#include "../../deformcontact_amd/csrc/dc_dense.h"
 
 namespace dc {
 
@@ -224,29 +225,25 @@ k_fwd_h2x(FwdParams p) {
     }
 }
 
-static inline bool hx_al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
-static inline int hx_env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
-// DC_H2_WIDE=2 selects this shape (fwd_h2_launch tries it before the 128 x 256 kernel)
-bool fwd_h2x_launch(const FwdParams &p, hipStream_t hs) {
-    static const int wide = hx_env_int("DC_H2_WIDE", 1);
-    if (wide != 2 || !p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1 || p.ksplit > 1)
-        return false;
-    if (p.Fi % kXBK != 0 || p.Fi < kXBK) return false;
-    if (p.x[0].ld * kXBM >= ((int64_t)1 << 30) || p.Fi * kXBN >= ((int64_t)1 << 30)) return false;
-    if (!hx_al16(p.x[0].p) || !hx_al16(p.w[0].p) || p.x[0].ld % 4 != 0) return false;
-    const int64_t tiles = ((p.N + kXBM - 1) / kXBM) * ((p.Fo + kXBN - 1) / kXBN);
-    static const int min_tiles = hx_env_int("DC_H2_WIDE_MIN_TILES", 64);
-    if (tiles < min_tiles || tiles >= (int64_t)INT32_MAX) return false;
-    const dim3 gd((unsigned)tiles), bd(256);
-    if (p.N % kXBM == 0 && p.Fo % kXBN == 0)
-        hipLaunchKernelGGL((k_fwd_h2x<true>), gd, bd, 0, hs, p);
-    else
-        hipLaunchKernelGGL((k_fwd_h2x<false>), gd, bd, 0, hs, p);
-    return true;
-}
-
 }  // namespace dc
+
+// out[N,Fo] = act(x[N,K] . W^T + b) with W as dc_tag_weight_prep's image; same contract as dc_tag_linear_fwd_h2p
+extern "C" int h2x_run(const float *x, int64_t ldx, const void *w_image, const float *bias, int relu, float *out,
+                       int64_t ldo, int64_t N, int64_t K, int64_t Fo, const float *x_rowmax, const float *w_rowmax,
+                       void *stream) {
+    using namespace dc;
+    if (K % kXBK != 0 || K < kXBK || ldx % 4 != 0 || ldx * kXBM >= ((int64_t)1 << 30) || K * kXBN >= ((int64_t)1 << 30))
+        return 1;
+    FwdParams p{};
+    p.x[0] = Mat{x, ldx};
+    p.w[0] = Mat{(const float *)w_image, K};
+    p.bias = bias, p.out = out, p.ldo = ldo, p.N = N, p.Fi = K, p.Fo = Fo, p.nseg = 1, p.relu = relu;
+    p.h2.a_rowmax = x_rowmax, p.h2.b_rowmax = w_rowmax, p.h2.b_presplit = 1;
+    const int64_t tiles = ((N + kXBM - 1) / kXBM) * ((Fo + kXBN - 1) / kXBN);
+    const dim3 gd((unsigned)tiles), bd(256);
+    if (N % kXBM == 0 && Fo % kXBN == 0)
+        hipLaunchKernelGGL((k_fwd_h2x<true>), gd, bd, 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((k_fwd_h2x<false>), gd, bd, 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
