@@ -12,15 +12,19 @@
 //     per-stage vmcnt(0) drains - 16 KB in flight per CU, i.e. a latency-bound 2 TB/s stream of x;
 //   * the loop itself: 12 MFMAs (384 cycles) per wave between barriers against ~600 cycles of fragment-read
 //     latency and barrier skew.
+// A third cause remains after both are fixed (profiles/r02/l_dense_ablation.txt): every 128-row tile streams the
+// whole 1 MB weight image from L2 - 390 MB of L2 -> CU traffic per launch, 39 us when the loop only loads.
 // Here: BK = 32 (x rows move as full 128-byte lines, 24 MFMAs per wave and barrier), one 128 x 256 tile
 // per 512-thread workgroup (x is staged and split ONCE for all 256 output columns instead of once per
-// 128), both operands staged through registers with the loads of stage it+2 issued at the top of stage it
-// and written to LDS at the end of stage it+1 (two register sets: ~2 stages = 64 KB of x in flight per
-// CU, counted vmcnt - no LDS-DMA in the kernel, so hipcc's waits stay counted and __syncthreads() is a
-// bare s_barrier).  LDS rows are 128 bytes = 8 pieces of 16 bytes (piece q = 4*kstep + 2*plane + half);
-// piece q of row r sits at position q ^ F(r), F(r) = ((r >> 1) & 7) ^ 2*(r & 1): conflict-free
-// ds_read_b128 fragment reads (each 16-lane group sees 8 even and 8 odd rows with 8 distinct F each) and
-// conflict-free ds_write_b64 of the split x (two adjacent rows per 16-lane group land on disjoint pieces).
+// 128), both operands staged through REGISTERS - no LDS-DMA in the kernel, so hipcc's waits stay counted
+// and __syncthreads() is a bare s_barrier: the loads of stage it+3 are issued at the top of stage it (two
+// register sets) and written during stage it+1 into a ring of three LDS stage buffers, so that stage it+1 is
+// complete one barrier before it is computed and its first fragments can be read under the last MFMAs of
+// stage it (two fragment register sets).  LDS rows are 128 bytes = 8 pieces of 16 bytes (piece q = 4*kstep
+// + 2*plane + half); piece q of row r sits at position q ^ F(r), F(r) = ((r >> 1) & 7) ^ 2*(r & 1):
+// conflict-free ds_read_b128 fragment reads (each 16-lane group sees 8 even and 8 odd rows with 8 distinct
+// F each) and conflict-free ds_write_b64 of the split x (two adjacent rows per 16-lane group land on
+// disjoint pieces).
 #include "dc_dense.h"
 
 namespace dc {
@@ -36,7 +40,7 @@ constexpr int kWSzA = kWBM * kWRow, kWSzB = kWBN * kWRow;
 
 __device__ __forceinline__ int hw_swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 1); }
 
-template <bool FULL, bool kNtA = false>
+template <bool FULL>
 __global__ void __launch_bounds__(512)
 k_fwd_h2w(FwdParams p) {
     __shared__ __attribute__((aligned(16))) char sA[3 * kWSzA];      // ring of three stages: 144 KB
@@ -87,8 +91,7 @@ k_fwd_h2w(FwdParams p) {
     auto gload_set = [&](hw_f32x4 (&va)[2], hw_u32x4 (&vb)[4]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            va[j] = kNtA ? __builtin_nontemporal_load(reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]))
-                         : *reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]);
+            va[j] = *reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) vb[j] = *reinterpret_cast<const hw_u32x4 *>(baseB + offB[j]);
         baseA += kWBK;
@@ -263,10 +266,7 @@ bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
     if (tiles < min_tiles || tiles >= (int64_t)INT32_MAX) return false;
     const dim3 gd((unsigned)tiles), bd(512);
-    static const int nt = hw_env_int("DC_H2_WIDE_NT", 0);
-    if (nt && p.N % kWBM == 0 && p.Fo % kWBN == 0)
-        hipLaunchKernelGGL((k_fwd_h2w<true, true>), gd, bd, 0, hs, p);
-    else if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
+    if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
         hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);
     else
         hipLaunchKernelGGL((k_fwd_h2w<false>), gd, bd, 0, hs, p);
