@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import dp
 from .graphnet import EVERYDAY_NETWORK, gradient_consistency_loss, load_model
-from .loaders import PrefetchLoader, SyntheticEverydayDataset, iterate_batches, to_batches
+from .loaders import InMemoryDataset, PrefetchLoader, SyntheticEverydayDataset, iterate_batches, to_batches
 
 
 #: both losses (and their gradients) in ONE node pass of the library (``ops.contact_losses``) when the
@@ -173,8 +173,9 @@ def train(network_cfg=None, *, device="cuda", epochs: int = 2, num_train: int = 
         bucket = dp.GradBucket(model.parameters()) if dp.world_size() > 1 else None
         graphed = None
     rank = torch.distributed.get_rank() if dp.world_size() > 1 else 0
-    train_ds = SyntheticEverydayDataset(num_train, rank * num_train, soft_vertices, sphere_resolution)
-    val_ds = SyntheticEverydayDataset(num_val, 10_000_000, soft_vertices, sphere_resolution)
+    # graphs built once, before the loop (the reference's dataset object likewise holds its processed meshes)
+    train_ds = InMemoryDataset(SyntheticEverydayDataset(num_train, rank * num_train, soft_vertices, sphere_resolution))
+    val_ds = InMemoryDataset(SyntheticEverydayDataset(num_val, 10_000_000, soft_vertices, sphere_resolution))
     os.makedirs(out_dir, exist_ok=True)
     log = open(os.path.join(out_dir, f"log_rank{rank}.jsonl"), "a")
     best, step = float("inf"), 0
