@@ -524,6 +524,10 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     DC_REQUIRE(products != 2, "dc_tag_linear_fwd_h2: needs Fi %% 16 == 0, 16-byte aligned operands, "
                               "equal leading dimensions (Fi=%lld)", (long long)Fi);
     if (use_fast() && vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
+    static const int trace = env_int("DC_DENSE_TRACE", 0);
+    if (trace)
+        fprintf(stderr, "[dc] generic fwd dense kernel: N=%lld Fi=%lld Fo=%lld nseg=%d vec=%d ldx=%lld ldo=%lld products=%d\n",
+                (long long)N, (long long)Fi, (long long)Fo, nseg, (int)vec, (long long)ldxs[0], (long long)ldo, products);
     if (mb == 2 && vec)
         hipLaunchKernelGGL((k_tag_linear_fwd<2, true>), gd, bd, 0, hs, p);
     else if (mb == 2)

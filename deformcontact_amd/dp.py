@@ -34,6 +34,17 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
             dist.broadcast(t, src=src, group=group)
 
 
+def flat_offsets(params, align: int = 4) -> List[int]:
+    """Element offsets of ``params`` in a flat buffer, each rounded up to ``align`` elements (16 bytes of fp32);
+    the last entry is the buffer length."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + align - 1) // align * align
+    offs.append(off)
+    return offs
+
+
 class GradBucket:
     """``direct=True`` opts the parameters into direct gradient writes by the library's dW
     kernels (``ops.DIRECT_PARAM_GRAD``): those kernels then accumulate into this bucket's views
@@ -48,15 +59,18 @@ class GradBucket:
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("GradBucket: parameters must share device and dtype")
         self.group = group
-        self.numel = sum(p.numel() for p in self.params)
+        # every view starts on a 16-byte boundary (one odd-sized parameter - the decoder's 3-element bias -
+        # otherwise leaves everything behind it misaligned, and the dense kernels fall back to their scalar-load
+        # forms for those operands: the attention heads of the reference network ran 2 x slower that way); the
+        # padding elements stay zero in the gradients, the parameters and both Adam moments
+        self.offsets = flat_offsets(self.params)
+        self.numel = self.offsets[-1]
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
         self._views: List[torch.Tensor] = []
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             v = self.flat[off:off + p.numel()].view_as(p)
             p.grad = v
             self._views.append(v)
-            off += p.numel()
         self.direct = bool(direct)
         self._view_of = {id(p): v for p, v in zip(self.params, self._views)}
         self._pending = []          # (event, recorded under stream capture?) of direct writes
@@ -132,15 +146,12 @@ class FlatAdam:
         self.bucket, self.lr, self.betas, self.eps = bucket, float(lr), betas, float(eps)
         _require_cuda(bucket.flat, "FlatAdam parameters")
         dev = bucket.flat.device
-        self.flat_param = torch.empty_like(bucket.flat)
-        off = 0
+        self.flat_param = torch.zeros_like(bucket.flat)
         with torch.no_grad():
-            for p in bucket.params:
-                n = p.numel()
-                view = self.flat_param[off:off + n].view_as(p)
+            for p, off in zip(bucket.params, bucket.offsets):      # same (16-byte aligned) layout as the gradients
+                view = self.flat_param[off:off + p.numel()].view_as(p)
                 view.copy_(p)
                 p.data = view                      # parameter storage now lives in the bucket
-                off += n
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.zero_grad_in_step = bool(zero_grad_in_step)

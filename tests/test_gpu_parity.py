@@ -1235,3 +1235,38 @@ def test_two_layer_bf16_stack_slab_handoff_and_fp32_head():
     with torch.no_grad():
         ref = torch.relu(r2.double()(torch.relu(r1.double()(x.double().cpu(), ei.cpu())), ei.cpu()))
     assert rel_err(_np(y), ref.numpy()) < 3e-2
+@pytest.mark.gpu
+def test_flat_adam_keeps_every_parameter_16_byte_aligned():
+    """`dp.FlatAdam` re-points the parameters into one flat buffer: with the reference network (whose decoder
+    ends in a 3-element bias, defined BEFORE the attention heads) every parameter and gradient view must still
+    start on a 16-byte boundary, the padding must stay zero through Adam steps, and the result must equal
+    torch.optim.Adam's."""
+    from deformcontact_amd import dp
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
+    torch.manual_seed(0)
+    model = load_model(EVERYDAY_NETWORK).to(DEV)
+    ref = load_model(EVERYDAY_NETWORK).to(DEV)
+    ref.load_state_dict(model.state_dict())
+    ref_opt = torch.optim.Adam(ref.parameters(), lr=4e-4)
+    bucket = dp.GradBucket(model.parameters(), direct=True)
+    opt = dp.FlatAdam(bucket, lr=4e-4)
+    assert any(p.numel() % 4 for p in bucket.params)             # the network does have an odd-sized parameter
+    for p in bucket.params:
+        assert p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0
+    pad = torch.ones(bucket.numel, dtype=torch.bool, device=DEV)
+    for p, off in zip(bucket.params, bucket.offsets):
+        pad[off:off + p.numel()] = False
+    assert int(pad.sum()) == bucket.numel - sum(p.numel() for p in bucket.params) > 0
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for _ in range(3):
+        for p, q in zip(bucket.params, [q for q in ref.parameters() if q.requires_grad]):
+            g = torch.randn(p.shape, generator=gen).to(DEV)
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        opt.step()
+        ref_opt.step()
+        assert not opt.flat_param[pad].any() and not opt.exp_avg[pad].any() and not bucket.flat[pad].any()
+    for p, q in zip(bucket.params, [q for q in ref.parameters() if q.requires_grad]):
+        assert rel_err(_np(p), _np(q)) < TOL          # 1e-5: three fp32 Adam steps, different op order
+
+

@@ -205,3 +205,23 @@ def test_prefetch_loader_matches_plain_iteration_cpu():
     import pytest
     with pytest.raises(RuntimeError, match="boom"):
         list(PrefetchLoader(Broken(5, soft_vertices=64, sphere_resolution=4), 2, None))
+
+
+def test_grad_bucket_views_are_16_byte_aligned():
+    """An odd-sized parameter (the decoder's 3-element bias) must not misalign the gradient views behind it:
+    the dense kernels need 16-byte aligned operands for their vector forms."""
+    import torch
+    from deformcontact_amd import dp
+    params = [torch.nn.Parameter(torch.randn(*s)) for s in ((256, 3), (3,), (256, 256), (7,), (5, 5), (256,))]
+    bucket = dp.GradBucket(params)
+    offs = dp.flat_offsets(params)
+    assert offs == [0, 768, 772, 772 + 65536, 772 + 65536 + 8, 772 + 65536 + 8 + 28, 772 + 65536 + 8 + 28 + 256]
+    assert bucket.numel == offs[-1] and all(o % 4 == 0 for o in offs)
+    for p, off in zip(params, offs):
+        assert p.grad.shape == p.shape and p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
+        assert p.grad.data_ptr() % 16 == bucket.flat.data_ptr() % 16
+        p.grad.fill_(1.0)
+    used = sum(p.numel() for p in params)
+    assert float(bucket.flat.sum()) == used          # the padding elements stay zero
+    bucket.zero()
+    assert not bucket.flat.any() and all(bucket.owns(p, p.grad) for p in params)
