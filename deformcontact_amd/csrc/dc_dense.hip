@@ -650,7 +650,8 @@ extern "C" int64_t dc_tag_linear_bwd_dw_workspace_bytes(int64_t N, int64_t Fi, i
     int64_t rows;
     int nchunks;
     dw_plan(N, Fi, Fo, nseg, &rows, &nchunks);
-    return (int64_t)sizeof(float) * nchunks * (nseg * Fo * Fi + Fo) + 16;
+    // + 1 slot: the < 16 trailing rows of an N that is not a multiple of the 16-row stage get their own partial
+    return (int64_t)sizeof(float) * (nchunks + 1) * (nseg * Fo * Fi + Fo) + 16;
 }
 
 static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64_t ldo,
@@ -688,13 +689,40 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     p.N = N, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg;
     p.h2 = h2;
     p.partial = (float *)partials;
-    p.bias_partial = gbias ? p.partial + (int64_t)p.nchunks * nseg * Fo * Fi : nullptr;
+    // The split / fp16x2 / lean kernels walk the nodes in whole 16-row stages.  An N that is not a multiple of 16
+    // (the reference's shipped batch of 4 rigid spheres: 3,048 rows) used to send the whole block to the generic
+    // kernel; now the first N - N % 16 rows take the fast kernels and the < 16 trailing rows go through the generic
+    // one into a partial slot of their own (slot nchunks), summed with the others by the slab reduce.
+    const int64_t tail = (products || use_fast()) && vec ? N % BK : 0;
+    const bool ragged = tail != 0 && N > tail;
+    const int nslots = p.nchunks + (ragged ? 1 : 0);
+    p.bias_partial = gbias ? p.partial + (int64_t)nslots * nseg * Fo * Fi : nullptr;
     const int mb = dw_mb(Fo);
     const int64_t tiles = ((Fo + 64 * mb - 1) / (64 * mb)) * ((Fi + BN - 1) / BN);
     const int64_t grid = tiles * nseg * p.nchunks;
     if (!p.has_mask) p.mask = p.g;
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
+    if (ragged) {
+        DwParams t = p;                                  // the trailing rows: one chunk of the generic kernel
+        const int64_t n0 = N - tail;
+        t.g.p += n0 * t.g.ld;
+        t.mask.p += n0 * t.mask.ld;
+        for (int s = 0; s < nseg; ++s) t.x[s].p += n0 * t.x[s].ld;
+        t.N = tail, t.chunk_rows = BK, t.nchunks = 1;
+        t.partial = p.partial + (int64_t)p.nchunks * nseg * Fo * Fi;
+        t.bias_partial = p.bias_partial ? p.bias_partial + (int64_t)p.nchunks * Fo : nullptr;
+        t.h2 = H2Scales{};
+        const dim3 gt((unsigned)(tiles * nseg));
+        if (mb == 2) {
+            if (p.has_mask) hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, true>), gt, bd, 0, hs, t);
+            else hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, false>), gt, bd, 0, hs, t);
+        } else {
+            if (p.has_mask) hipLaunchKernelGGL((k_tag_linear_bwd_dw<1, true, true>), gt, bd, 0, hs, t);
+            else hipLaunchKernelGGL((k_tag_linear_bwd_dw<1, true, false>), gt, bd, 0, hs, t);
+        }
+        p.N = n0;                                        // chunks past n0 become empty (zero partials)
+    }
     bool fast_done = products && vec && dw_split_launch(p, mb, products, hs);
     DC_REQUIRE(fast_done || products != 2, "dc_tag_linear_bwd_dw_h2: needs N %% 16 == 0, Fi %% 4 == 0, "
                "Fo %% 4 == 0 and 16-byte aligned operands (N=%lld)", (long long)N);
@@ -715,7 +743,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     }
 #undef DC_DW
     r.partial = p.partial, r.bias_partial = p.bias_partial, r.gbias = gbias;
-    r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = p.nchunks;
+    r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = nslots;
     r.cols = gw_cols, r.ngw = ngw, r.bps = ngw / nseg, r.accumulate = accumulate;
     const int64_t total = (int64_t)ngw * Fo * gw_cols + (gbias ? Fo : 0);
     hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

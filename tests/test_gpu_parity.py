@@ -1236,6 +1236,45 @@ def test_two_layer_bf16_stack_slab_handoff_and_fp32_head():
         ref = torch.relu(r2.double()(torch.relu(r1.double()(x.double().cpu(), ei.cpu())), ei.cpu()))
     assert rel_err(_np(y), ref.numpy()) < 3e-2
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,fi,fo,nseg,mask", [(3048, 256, 256, 4, False), (3048, 96, 256, 1, True),
+                                               (1003, 64, 48, 2, True), (31, 32, 32, 1, False), (7, 32, 32, 1, True)])
+def test_dw_ragged_node_count(n, fi, fo, nseg, mask):
+    """dW over a node count that is not a multiple of the 16-row stage (the shipped batch of 4 rigid spheres has
+    3,048 rows): the whole stages run on the split / fp16x2 kernels, the trailing rows through the generic kernel
+    into a partial slot of their own - same result, same bound vs float64 as the aligned case."""
+    from deformcontact_amd import _lib
+    from deformcontact_amd.graph import current_stream_ptr
+    from deformcontact_amd.ops import _i64_array, _ptr_array
+    L = _lib.lib()
+    st = current_stream_ptr(torch.device(DEV))
+    slab = torch.from_numpy(hashed_uniform((n, nseg * fi), 11, 2.0)).to(DEV)
+    g = torch.from_numpy(hashed_uniform((n, fo), 12, 2.0)).to(DEV)
+    out = torch.from_numpy(hashed_uniform((n, fo), 13, 1.0)).to(DEV)            # relu mask source
+    xs = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+    gm = g.double().cpu() * ((out.double().cpu() > 0).double() if mask else 1.0)
+    refs = [gm.t() @ x.double().cpu() for x in xs]
+    refb = gm.sum(0)
+    nb = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi, fo, nseg)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    mptr = out.data_ptr() if mask else None
+
+    def check(name, launch):
+        gws = [torch.full((fo, fi), float("nan"), device=DEV) for _ in range(nseg)]
+        gb = torch.full((fo,), float("nan"), device=DEV)
+        args = (g.data_ptr(), fo, mptr, fo, _ptr_array(xs), _i64_array([nseg * fi] * nseg), nseg, _ptr_array(gws), nseg,
+                fi, gb.data_ptr(), 0, scratch.data_ptr(), nb, n, fi, fo)
+        _lib.check(launch(args), name)
+        for s in range(nseg):
+            assert rel_err(_np(gws[s]), refs[s].numpy()) < 2e-6, (name, s)
+        assert rel_err(_np(gb), refb.numpy()) < 2e-6, name
+    check("split6", lambda a: L.dc_tag_linear_bwd_dw_split(*a, 6, st))
+    check("fp32", lambda a: L.dc_tag_linear_bwd_dw(*a, st))
+    if not mask:                                         # the fp16x2 form takes a pre-masked gradient
+        gmax, xmax = ops.rowabsmax(g), slab.abs().amax(1).contiguous()
+        check("h2", lambda a: L.dc_tag_linear_bwd_dw_h2(*a, gmax.data_ptr(), xmax.data_ptr(), st))
+
+
+@pytest.mark.gpu
 def test_flat_adam_keeps_every_parameter_16_byte_aligned():
     """`dp.FlatAdam` re-points the parameters into one flat buffer: with the reference network (whose decoder
     ends in a 3-element bias, defined BEFORE the attention heads) every parameter and gradient view must still
