@@ -188,11 +188,13 @@ class PrefetchLoader:
         return lay, off
 
     def _produce(self, q):
+        threads = torch.get_num_threads()
         try:
             pin = self.device is not None and torch.device(self.device).type == "cuda"
             if pin:
                 # batches are a few hundred KB of small tensors: on a many-core host the intra-op thread pool costs
-                # more than it saves (measured on a 256-thread box: 10.4 ms per batch of 4 vs 2.5 ms single-threaded)
+                # more than it saves (measured on a 256-thread box: 10.4 ms per batch of 4 vs 2.5 ms single-threaded);
+                # process-wide while this loader runs, restored when its worker ends
                 torch.set_num_threads(1)
                 slots = [{"buf": None, "event": None} for _ in range(self.depth + self._EXTRA_SLOTS)]
             for i, collated in enumerate(iterate_batches(self.dataset, self.batch_size, self.shuffle, self.seed,
@@ -217,6 +219,8 @@ class PrefetchLoader:
             q.put(None)
         except BaseException as e:          # surface worker errors in the consumer
             q.put(e)
+        finally:
+            torch.set_num_threads(threads)      # the setting is process-wide: give it back when the epoch is over
 
     def __iter__(self):
         import queue
