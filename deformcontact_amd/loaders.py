@@ -187,8 +187,18 @@ class PrefetchLoader:
                     off += (nb + 255) // 256 * 256
         return lay, off
 
-    def _produce(self, q):
+    def _produce(self, q, stop):
+        import queue
         threads = torch.get_num_threads()
+
+        def put(item) -> bool:                  # False: the consumer has gone away (early break / close)
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
         try:
             pin = self.device is not None and torch.device(self.device).type == "cuda"
             if pin:
@@ -215,10 +225,11 @@ class PrefetchLoader:
                         if nb:
                             slot["buf"][off:off + nb].view(dtype).view(shape).copy_(host[bi].__dict__[k])
                     pack = (slot, lay, total)
-                q.put((collated, host, pack))
-            q.put(None)
+                if not put((collated, host, pack)):
+                    return
+            put(None)
         except BaseException as e:          # surface worker errors in the consumer
-            q.put(e)
+            put(e)
         finally:
             torch.set_num_threads(threads)      # the setting is process-wide: give it back when the epoch is over
 
@@ -226,7 +237,8 @@ class PrefetchLoader:
         import queue
         import threading
         q = queue.Queue(maxsize=self.depth)
-        worker = threading.Thread(target=self._produce, args=(q,), daemon=True)
+        stop = threading.Event()
+        worker = threading.Thread(target=self._produce, args=(q, stop), daemon=True)
         worker.start()
         cuda = self.device is not None and torch.device(self.device).type == "cuda"
         side = torch.cuda.Stream(device=self.device) if cuda else None
@@ -258,21 +270,24 @@ class PrefetchLoader:
                 raise item
             return item
 
-        nxt = get()
-        pending = upload(nxt) if nxt is not None else None
-        while pending is not None:
-            collated, dev, ev = pending
+        try:
             nxt = get()
-            pending = upload(nxt) if nxt is not None else None      # next upload overlaps this step
-            if ev is not None:
-                ev, built = ev
-                torch.cuda.current_stream(self.device).wait_event(ev)
-                for g in built or []:
-                    g.record_stream(torch.cuda.current_stream(self.device))
-                for b in dev:                                    # all views of one buffer: one record is enough
-                    for t in b.__dict__.values():
-                        if isinstance(t, torch.Tensor) and t.is_cuda:
-                            t.record_stream(torch.cuda.current_stream(self.device))
-                            break
-            yield collated, dev
-        worker.join()
+            pending = upload(nxt) if nxt is not None else None
+            while pending is not None:
+                collated, dev, ev = pending
+                nxt = get()
+                pending = upload(nxt) if nxt is not None else None      # next upload overlaps this step
+                if ev is not None:
+                    ev, built = ev
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    for g in built or []:
+                        g.record_stream(torch.cuda.current_stream(self.device))
+                    for b in dev:                                    # all views of one buffer: one record is enough
+                        for t in b.__dict__.values():
+                            if isinstance(t, torch.Tensor) and t.is_cuda:
+                                t.record_stream(torch.cuda.current_stream(self.device))
+                                break
+                yield collated, dev
+        finally:                               # also on an early `break` / close of the generator: no worker left behind
+            stop.set()
+            worker.join()

@@ -197,6 +197,19 @@ def test_prefetch_loader_matches_plain_iteration_cpu():
         for x, y in zip(b0, to_batches(c1, None)):
             assert torch.equal(x.x, y.x) and torch.equal(x.edge_index, y.edge_index)
 
+    # a consumer that stops early leaves no worker thread behind (it would sit in queue.put forever)
+    import threading
+    import time
+    before = threading.active_count()
+    for i, _ in enumerate(PrefetchLoader(mem, 1, None, depth=1)):
+        if i == 1:
+            break
+    for _ in range(50):
+        if threading.active_count() == before:
+            break
+        time.sleep(0.02)
+    assert threading.active_count() == before
+
     class Broken(SyntheticEverydayDataset):
         def __getitem__(self, i):
             if i == 3:
