@@ -76,6 +76,8 @@ _SIGNATURES = {
     "dc_tag_linear_fwd_h2p_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "dc_tag_linear_fwd_h2p": (c_int, [_vp, c_int64, _vp, _vp, c_int, _vp, c_int64, c_int64, c_int64, c_int64,
                                       _vp, _vp, _vp, c_int64, _vp]),
+    "dc_tag_linear_fwd_h2p_exp": (c_int, [_vp, c_int64, _vp, _vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp, _vp,
+                                          c_int64, _vp]),
     "dc_tag_weight_prep": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp, _vp, _vp, _vp]),
     "dc_rowabsmax_f32": (c_int, [_vp, c_int64, c_int64, c_int64, _vp, _vp]),
     "dc_tag_weight_rowmax": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp]),

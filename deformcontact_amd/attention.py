@@ -66,6 +66,11 @@ def _rowabsmax(L, t: torch.Tensor, st) -> torch.Tensor:
     return out
 
 
+#: recompute of a block's weights in the backward: exp(s - lse) in the score GEMM's epilogue (``DC_ATTN_FUSED_EXP=0``:
+#: separate ``dc_attn_exp_rows`` pass; bit-identical)
+FUSED_EXP = os.environ.get("DC_ATTN_FUSED_EXP", "1") != "0"
+
+
 def _gemm(L, x, ldx, rows, k, img, fo, out, ldo, xmax, wmax, st, ws=None):
     """out[rows, fo] = x[rows, k] . W^T with W given as its pre-split image (fp16x2, LDS-DMA);
     ``ws``: workspace that lets a long reduction with a small output be cut into ranges."""
@@ -187,11 +192,18 @@ class _AttnCoreFn(torch.autograd.Function):
             # recompute the block's weights
             if EXACT_SCORES:
                 _gemm_exact(L, qp[r0:].data_ptr(), d, rows, d, kp, nrp, p.data_ptr(), nrp, st)
-            else:
+                _lib.check(L.dc_attn_exp_rows(p.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
+                           "dc_attn_exp_rows")
+            elif not FUSED_EXP:
                 _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, p.data_ptr(), nrp, qmax[r0:].data_ptr(),
                       kmax, st)
-            _lib.check(L.dc_attn_exp_rows(p.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
-                       "dc_attn_exp_rows")
+                _lib.check(L.dc_attn_exp_rows(p.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
+                           "dc_attn_exp_rows")
+            else:
+                # scores + exp(s - lse) in the GEMM's epilogue: one pass over the 200 MB block less
+                _lib.check(L.dc_tag_linear_fwd_h2p_exp(qp[r0:].data_ptr(), d, kimg.data_ptr(), p.data_ptr(), nrp, rows,
+                                                       d, nrp, qmax[r0:].data_ptr(), kmax.data_ptr(),
+                                                       lse[r0:].data_ptr(), nr, st), "dc_tag_linear_fwd_h2p_exp")
             # dP = dO V^T, then dS = P * (dP - delta) in place
             if EXACT_SCORES:
                 _gemm_exact(L, gop[r0:].data_ptr(), dv, rows, dv, vp, nrp, ds.data_ptr(), nrp, st)

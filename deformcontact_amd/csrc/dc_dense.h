@@ -138,6 +138,9 @@ struct FwdParams {
     H2Scales h2;
     int ksplit;              // k_fwd_h2: > 1 = the reduction is cut into ksplit ranges, each block
     float *kpartial;         //   writes its [N, Fo] partial to kpartial[z] (no bias / relu), summed later
+    // attention recompute (dc_tag_linear_fwd_h2p_exp): out[i, j] = j < exp_ncols ? exp(acc - exp_lse[i]) : 0
+    const float *exp_lse;
+    int64_t exp_ncols;
 };
 
 struct DxParams {

@@ -469,7 +469,8 @@ using namespace dc;
 static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *const *ws, int nseg,
                     const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t Fi,
                     int64_t Fo, dc_stream_t stream, int products, H2Scales h2 = H2Scales{},
-                    float *ksplit_ws = nullptr, int64_t ksplit_ws_bytes = 0) {
+                    float *ksplit_ws = nullptr, int64_t ksplit_ws_bytes = 0, const float *exp_lse = nullptr,
+                    int64_t exp_ncols = 0) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_fwd: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_fwd: bad sizes");
     if (N == 0) return DC_OK;
@@ -484,6 +485,8 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     p.bias = bias, p.out = out, p.ldo = ldo, p.N = N, p.Fi = Fi, p.Fo = Fo;
     p.nseg = nseg, p.relu = relu;
     p.h2 = h2;
+    p.exp_lse = exp_lse, p.exp_ncols = exp_ncols;
+    DC_REQUIRE(!exp_lse || h2.b_presplit, "dc_tag_linear_fwd: the exp epilogue exists on the pre-split h2 kernels only");
     const int64_t ntn = (Fo + BN - 1) / BN;
     const int mb = pick_mb(N, ntn);
     const int64_t grid = ((N + 64 * mb - 1) / (64 * mb)) * ntn;
@@ -811,6 +814,22 @@ extern "C" int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_
     DC_REQUIRE(!workspace || (((uintptr_t)workspace) & 15) == 0, "dc_tag_linear_fwd_h2p: workspace misaligned");
     return fwd_impl(xs, ld, ws, 1, bias, relu, out, ldo, N, K, Fo, stream, 2, h, (float *)workspace,
                     workspace ? workspace_bytes : 0);
+}
+
+extern "C" int dc_tag_linear_fwd_h2p_exp(const float *x, int64_t ldx, const void *w_image, float *out,
+                                         int64_t ldo, int64_t N, int64_t K, int64_t Fo, const float *x_rowmax,
+                                         const float *w_rowmax, const float *row_lse, int64_t ncols_valid,
+                                         dc_stream_t stream) {
+    DC_REQUIRE(x && w_image && x_rowmax && w_rowmax && row_lse, "dc_tag_linear_fwd_h2p_exp: null pointer");
+    DC_REQUIRE(K >= 16 && K % 16 == 0 && ldx >= K && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
+                   (((uintptr_t)w_image) & 15) == 0 && ncols_valid >= 0 && ncols_valid <= Fo,
+               "dc_tag_linear_fwd_h2p_exp: K %% 16 == 0, 16-byte aligned operands, 0 <= ncols_valid <= Fo required");
+    H2Scales h{};
+    h.a_rowmax = x_rowmax, h.b_rowmax = w_rowmax, h.b_presplit = 1;
+    const float *xs[1] = {x};
+    const float *ws[1] = {(const float *)w_image};
+    const int64_t ld[1] = {ldx};
+    return fwd_impl(xs, ld, ws, 1, nullptr, 0, out, ldo, N, K, Fo, stream, 2, h, nullptr, 0, row_lse, ncols_valid);
 }
 
 extern "C" int dc_tag_linear_bwd_dx_h2(const float *g, int64_t ldg, const float *out_for_mask,

@@ -236,6 +236,7 @@ k_fwd_h2(FwdParams p) {
             v = (v * s_inv[rr]) * icol[(c >> 5) & 1];
             v += bcol[(c >> 5) & 1];
             if (relu) v = fmaxf(v, 0.f);
+            if (p.exp_lse) v = col < p.exp_ncols ? expf(v - p.exp_lse[row]) : 0.f;
             p.out[row * p.ldo + col] = v;
         }
     });

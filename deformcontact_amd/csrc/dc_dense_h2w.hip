@@ -241,6 +241,8 @@ k_fwd_h2w(FwdParams p) {
                     float v = (acc[mb][nb][4 * g + i] * sv[i]) * icol;
                     v += bcol;
                     if (relu) v = fmaxf(v, 0.f);
+                    if (p.exp_lse)                  // attention recompute: the block's weights from the saved row lse
+                        v = col < p.exp_ncols ? expf(v - p.exp_lse[(FULL || row < p.N) ? row : p.N - 1]) : 0.f;
                     if (FULL || (cok && row < p.N)) p.out[row * p.ldo + col] = v;
                 }
             }

@@ -319,6 +319,13 @@ int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_image, cons
                           float *out, int64_t ldo, int64_t N, int64_t K, int64_t Fo,
                           const float *x_rowmax, const float *w_rowmax, void *workspace,
                           int64_t workspace_bytes, dc_stream_t stream);
+/* The attention backward's recompute of a block's softmax weights in ONE launch (models/model.py:15-17 as the
+ * blocked form evaluates it): out[i, j] = exp(x[i,:] . W[j,:] - row_lse[i]) for j < ncols_valid, 0 for the padded
+ * columns ncols_valid <= j < Fo - dc_tag_linear_fwd_h2p (no bias, no relu) with dc_attn_exp_rows applied in the
+ * epilogue; bit-identical to the two launches. */
+int dc_tag_linear_fwd_h2p_exp(const float *x, int64_t ldx, const void *w_image, float *out, int64_t ldo,
+                              int64_t N, int64_t K, int64_t Fo, const float *x_rowmax, const float *w_rowmax,
+                              const float *row_lse, int64_t ncols_valid, dc_stream_t stream);
 /* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
 int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                      dc_stream_t stream);

@@ -1275,6 +1275,39 @@ def test_dw_ragged_node_count(n, fi, fo, nseg, mask):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,d,nr", [(2048, 256, 3048), (200, 64, 333), (96, 32, 40)])
+def test_scores_exp_epilogue_bit_identical_to_gemm_plus_exp_rows(rows, d, nr):
+    """`dc_tag_linear_fwd_h2p_exp` (the attention backward's recompute: scores and exp(s - lse) in one launch) against
+    `dc_tag_linear_fwd_h2p` + `dc_attn_exp_rows`: bit-identical, padded key columns exactly zero - on the 128 x 256
+    tiles (first shape) and on the 64/128 x 128 kernel (the small ones)."""
+    from deformcontact_amd import _lib
+    from deformcontact_amd.graph import current_stream_ptr
+    from deformcontact_amd.ops import _ptr_array
+    L = _lib.lib()
+    st = current_stream_ptr(torch.device(DEV))
+    nrp = (nr + 15) // 16 * 16
+    q = torch.from_numpy(hashed_uniform((rows, d), 3, 1.0)).to(DEV)
+    k = torch.zeros(nrp, d, device=DEV)
+    k[:nr] = torch.from_numpy(hashed_uniform((nr, d), 4, 1.0)).to(DEV)
+    qmax = ops.rowabsmax(q)
+    kmax = torch.empty(nrp, device=DEV)
+    kimg = torch.empty(nrp, d, device=DEV)
+    _lib.check(L.dc_tag_weight_prep(_ptr_array([k]), 1, nrp, d, kmax.data_ptr(), kimg.data_ptr(), None, None, st), "prep")
+    s = torch.empty(rows, nrp, device=DEV)
+    _lib.check(L.dc_tag_linear_fwd_h2p(q.data_ptr(), d, kimg.data_ptr(), None, 0, s.data_ptr(), nrp, rows, d, nrp,
+                                       qmax.data_ptr(), kmax.data_ptr(), None, 0, st), "scores")
+    lse = torch.logsumexp(s[:, :nr].double(), dim=1).float().contiguous()
+    ref = s.clone()
+    _lib.check(L.dc_attn_exp_rows(ref.data_ptr(), nrp, rows, nr, nrp, lse.data_ptr(), st), "exp_rows")
+    out = torch.full((rows, nrp), float("nan"), device=DEV)
+    _lib.check(L.dc_tag_linear_fwd_h2p_exp(q.data_ptr(), d, kimg.data_ptr(), out.data_ptr(), nrp, rows, d, nrp,
+                                           qmax.data_ptr(), kmax.data_ptr(), lse.data_ptr(), nr, st), "scores_exp")
+    assert torch.equal(out, ref)
+    assert not out[:, nr:].any()
+    assert float((out[:, :nr].double().sum(1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
 def test_flat_adam_keeps_every_parameter_16_byte_aligned():
     """`dp.FlatAdam` re-points the parameters into one flat buffer: with the reference network (whose decoder
     ends in a 3-element bias, defined BEFORE the attention heads) every parameter and gradient view must still
