@@ -47,7 +47,11 @@ k_fwd_h2w(FwdParams p) {
     __shared__ __attribute__((aligned(16))) char sB[3 * kWSzB];
     __shared__ __attribute__((aligned(16))) float s_inv[kWBM];
     const unsigned ntn = (unsigned)((p.Fo + kWBN - 1) / kWBN);
-    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    // split reduction (p.ksplit > 1: a long K with too few output tiles for the chip, e.g. attention weights x
+    // values): block = (tile, range kz); every range writes its own partial, summed in range order afterwards
+    const unsigned ks = p.ksplit > 1 ? (unsigned)p.ksplit : 1u, ntiles = gridDim.x / ks;
+    const unsigned lbb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned lb = lbb % ntiles, kz = lbb / ntiles;
     const int64_t row0 = (int64_t)(lb / ntn) * kWBM, col0 = (int64_t)(lb % ntn) * kWBN;
     const int wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
     const int lane = threadIdx.x & 63;
@@ -82,9 +86,11 @@ k_fwd_h2w(FwdParams p) {
 
     f32x16 acc[2][2];
     zero_acc<2>(acc);
-    const int nst = (int)(p.Fi / kWBK);
-    const float *baseA = p.x[0].p + row0 * lda;                       // wave-uniform running bases
-    const float *baseB = p.w[0].p + col0 * p.Fi;
+    const int nst_all = (int)(p.Fi / kWBK), per = (nst_all + (int)ks - 1) / (int)ks;
+    const int st_beg = (int)kz * per;
+    const int nst = st_beg >= nst_all ? 0 : (nst_all - st_beg < per ? nst_all - st_beg : per);
+    const float *baseA = p.x[0].p + row0 * lda + (int64_t)st_beg * kWBK;      // wave-uniform running bases
+    const float *baseB = p.w[0].p + col0 * p.Fi + (int64_t)st_beg * kWBK;
     hw_f32x4 va0[2], va1[2];                                          // two register sets, named: no runtime index
     hw_u32x4 vb0[4], vb1[4];
 
@@ -166,7 +172,7 @@ k_fwd_h2w(FwdParams p) {
     // it & 1 ... see below), stage it+2 is written to LDS (its loads were issued at the top of stage it-1),
     // the barrier at the end of stage it makes it readable from the end of stage it+1 on.
     //   register set of stage s: s & 1; loads(s) at the top of stage s-3, store(s) at the end of stage s-2
-    gload(0);                                          // stage 0
+    if (nst > 0) gload(0);                             // stage 0 (nst == 0: an empty range of a split reduction)
     if (nst > 1) gload(1);                             // stage 1
     lstore(0, 0);
     if (nst > 2) gload(0);                             // stage 2
@@ -221,6 +227,28 @@ k_fwd_h2w(FwdParams p) {
     // epilogue: C/D fragment (reg, lane) -> row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col lane & 31
     const bool relu = p.relu != 0;
     const int c = lane & 31, h = lane >> 5;
+    if (ks > 1) {                                       // split reduction: plain partial of this range
+        float *part = p.kpartial + (int64_t)kz * p.N * p.Fo;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int64_t col = col0 + wn * 64 + nb * 32 + c;
+            const bool cok = FULL || col < p.Fo;
+            const float icol = h2_unscale(p.h2.b_rowmax[cok ? col : p.Fo - 1]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rl = wm * 64 + mb * 32 + 8 * g + 4 * h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t row = row0 + rl + i;
+                        if (FULL || (cok && row < p.N))
+                            part[row * p.Fo + col] = (acc[mb][nb][4 * g + i] * s_inv[rl + i]) * icol;
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int64_t col = col0 + wn * 64 + nb * 32 + c;
@@ -259,15 +287,16 @@ static inline int hw_env_int(const char *name, int dflt) {
 // every CU one (a 128 x 256 tile is a whole CU's work: small N stays with the 64/128 x 128 kernel)
 bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     static const int wide = hw_env_int("DC_H2_WIDE", 1);
-    if (!wide || !p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1 || p.ksplit > 1)
-        return false;
+    if (!wide || !p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1) return false;
+    const int64_t ks = p.ksplit > 1 ? p.ksplit : 1;
+    if (ks > 1 && (!p.kpartial || p.bias || p.relu || p.exp_lse)) return false;
     if (p.Fi % kWBK != 0 || p.Fi < kWBK) return false;
     if (p.x[0].ld * kWBM >= ((int64_t)1 << 30) || p.Fi * kWBN >= ((int64_t)1 << 30)) return false;
     if (!hw_al16(p.x[0].p) || !hw_al16(p.w[0].p) || p.x[0].ld % 4 != 0) return false;
     const int64_t tiles = ((p.N + kWBM - 1) / kWBM) * ((p.Fo + kWBN - 1) / kWBN);
     static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
-    if (tiles < min_tiles || tiles >= (int64_t)INT32_MAX) return false;
-    const dim3 gd((unsigned)tiles), bd(512);
+    if (tiles * ks < min_tiles || tiles * ks >= (int64_t)INT32_MAX) return false;
+    const dim3 gd((unsigned)(tiles * ks)), bd(512);
     if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
         hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);
     else

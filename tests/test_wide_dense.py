@@ -58,6 +58,25 @@ for n, k, fo, relu, bias_on, ldpad in ((1000, 96, 256, True, True, 0), (4112, 10
     err = float(((out.double().cpu() - ref).abs() / den).max())
     assert err < 2e-6, (err, n, k, fo)
     worst = max(worst, err)
+# split reduction on the wide tiles: a long K with few output tiles (attention weights x values)
+for n, k, fo in ((256, 4096, 256), (200, 2080, 192)):
+    st = current_stream_ptr(dev)
+    x = (torch.rand(n, k, generator=gen) * 2 - 1).to(dev)
+    w = ((torch.rand(fo, k, generator=gen) * 2 - 1) / k ** 0.5).to(dev)
+    rowmax, wmax = x.abs().amax(1).contiguous(), ops.weight_rowmax([w])
+    wimg = torch.empty(fo, k, device=dev)
+    _lib.check(L.dc_tag_weight_prep(_ptr_array([w]), 1, fo, k, wmax.data_ptr(), wimg.data_ptr(), None, None, st), "prep")
+    nb = L.dc_tag_linear_fwd_h2p_workspace_bytes(n, k, fo)
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out = torch.full((n, fo), float("nan"), device=dev)
+    _lib.check(L.dc_tag_linear_fwd_h2p(x.data_ptr(), k, wimg.data_ptr(), None, 0, out.data_ptr(), fo, n, k, fo,
+                                       rowmax.data_ptr(), wmax.data_ptr(), ws.data_ptr(), nb, st), "fwd_h2p split-K")
+    torch.cuda.synchronize()
+    ref = x.double().cpu() @ w.double().cpu().t()
+    err = float(((out.double().cpu() - ref).abs() / ref.abs().amax(1, keepdim=True)).max())
+    assert err < 2e-6, (err, n, k, fo)
+    worst = max(worst, err)
 print("OK", worst)
 """
 
