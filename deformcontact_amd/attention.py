@@ -36,6 +36,12 @@ def _ceil16(n: int) -> int:
     return (n + 15) // 16 * 16
 
 
+def _ceil_keys(n: int) -> int:
+    """Padded key count: a multiple of 16 (one MFMA k-step); of 128 once there are enough keys, so that the dW-shaped
+    products of the backward (dK, dV: [keys, d]) tile into the 128 x 256 blocks of ``k_dw_h2w``."""
+    return (n + 127) // 128 * 128 if n >= 1024 else _ceil16(n)
+
+
 def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
     if t.size(0) == rows and t.is_contiguous():
         return t
@@ -125,7 +131,7 @@ class _AttnCoreFn(torch.autograd.Function):
         dev = q.device
         L = _lib.lib()
         st = current_stream_ptr(dev)
-        nsp, nrp = _ceil16(ns), _ceil16(nr)
+        nsp, nrp = _ceil16(ns), _ceil_keys(nr)
         bq = max(16, min(_ceil16(block_rows), nsp))
         # softmax over the keys is invariant to adding one vector c to every key (every score of a
         # row shifts by q.c): the whole computation runs on keys centred at their mean.  Same function,

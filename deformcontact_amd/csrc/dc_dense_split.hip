@@ -567,11 +567,12 @@ k_dw_h2w(DwParams p) {
     using IB = TrImage32<256>;
     constexpr int kStage = IA::BYTES + IB::BYTES, kOffB = IA::BYTES;      // 20,480 + 36,864 B
     __shared__ __attribute__((aligned(16))) char lds[2 * kStage];
-    const unsigned per_chunk = 2u * (unsigned)p.nseg;                     // (Fo half, segment) tiles
+    const unsigned nto = (unsigned)(p.Fo / 128);                          // 128-row blocks of Fo
+    const unsigned per_chunk = nto * (unsigned)p.nseg;                    // (Fo block, segment) tiles
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);                 // a chunk's tiles share one L2
     const unsigned chunk = lb / per_chunk, rem = lb % per_chunk;
-    const int s = (int)(rem >> 1);
-    const int64_t o0 = (int64_t)(rem & 1) * 128;
+    const int s = (int)(rem / nto);
+    const int64_t o0 = (int64_t)(rem % nto) * 128;
     const int64_t n_beg = (int64_t)chunk * p.chunk_rows;
     const int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
     const int wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
@@ -721,15 +722,18 @@ k_dw_h2w(DwParams p) {
     }
 }
 
-// eligible: fp16x2, pre-masked g, Fo = 256, every segment 256 wide, node chunks that are whole stages
+// eligible: fp16x2, pre-masked g, Fo a multiple of 128, every segment 256 wide, node chunks that are whole stages
 static bool dw_h2w_launch(const DwParams &p, hipStream_t hs) {
     static const int wide = getenv("DC_DW_WIDE") ? atoi(getenv("DC_DW_WIDE")) : 1;
-    if (!wide || p.has_mask || p.Fo != 256 || p.Fi != 256 || p.N % kDwK != 0 || p.chunk_rows % kDwK != 0)
+    if (!wide || p.has_mask || p.Fo % 128 != 0 || p.Fo < 128 || p.Fi != 256 || p.N % kDwK != 0 ||
+        p.chunk_rows % kDwK != 0)
         return false;
     if (p.g.ld * kDwK >= ((int64_t)1 << 30)) return false;
     for (int s = 0; s < p.nseg; ++s)
         if (p.x[s].ld * kDwK >= ((int64_t)1 << 30)) return false;
-    const dim3 gd((unsigned)(2 * p.nseg * p.nchunks)), bd(512);
+    const int64_t grid = (p.Fo / 128) * p.nseg * p.nchunks;
+    if (grid >= (int64_t)INT32_MAX) return false;
+    const dim3 gd((unsigned)grid), bd(512);
     hipLaunchKernelGGL(k_dw_h2w, gd, bd, 0, hs, p);
     return true;
 }

@@ -1097,7 +1097,10 @@ def test_multihop_falls_back_on_large_components():
 # blocked cross-attention vs the reference's formula in float64
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("ns,nr,d,dv,block", [(300, 130, 256, 256, 128), (64, 48, 32, 64, 2048),
-                                              (1000, 777, 256, 256, 512), (17, 5, 16, 16, 16)])
+                                              (1000, 777, 256, 256, 512), (17, 5, 16, 16, 16),
+                                              # >= 1024 keys: padded to a multiple of 128, dK / dV on the 128 x 256
+                                              # dW tiles, the two long reductions split over ranges on the wide tiles
+                                              (4096, 3048, 256, 256, 2048)])
 def test_blocked_attention_core_vs_float64(ns, nr, d, dv, block):
     from deformcontact_amd.attention import attention_core
     torch.manual_seed(ns + nr)
