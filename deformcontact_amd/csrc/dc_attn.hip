@@ -10,7 +10,8 @@
 //   dc_attn_softmax_rows : S[i, 0:n] <- softmax(S[i, 0:n]),  S[i, n:npad] <- 0,  lse[i] = log sum exp
 //   dc_attn_exp_rows     : S[i, 0:n] <- exp(S[i, 0:n] - lse[i]),  S[i, n:npad] <- 0      (recompute)
 //   dc_attn_ds_rows      : dP[i, j] <- P[i, j] * (dP[i, j] - delta[i]),  rowmax[i] = max_j |.|
-// One 256-thread workgroup per row; a row (up to ~100 KB) is read from L2 on the second pass.
+// One 256-thread workgroup per row; rows of up to 32 K (softmax) / 24 K (ds) floats are held in registers (one global
+// read per input row), longer ones are re-read from L2 on the later passes.
 #include "dc_common.h"
 
 namespace dc {
@@ -95,9 +96,109 @@ k_attn_ds_rows(const float *__restrict__ p, float *__restrict__ dp, int64_t ld, 
     if (threadIdx.x == 0) rowmax[blockIdx.x] = m;
 }
 
+// ---- register-resident rows ---------------------------------------------------------------------------
+// The kernels above read a row two or three times (the later passes from L2).  For rows of up to NV x 1024
+// floats a 256-thread workgroup can hold the whole row in registers (NV float4 per thread): ONE global read per
+// input row, one write.  Same formulas; the partition of a row over the threads differs from the strided
+// kernels, so sums agree to rounding, not bit for bit.
+using af32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int NV>
+__global__ void __launch_bounds__(256)
+k_attn_softmax_rows_reg(float *__restrict__ s, int64_t ld, int64_t n, int64_t npad, float *__restrict__ lse) {
+    __shared__ float red[4];
+    float *row = s + (int64_t)blockIdx.x * ld;
+    af32x4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
+        if (i < npad) {
+            v[j] = *reinterpret_cast<const af32x4 *>(row + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i + e < n) m = fmaxf(m, v[j][e]);
+        }
+    }
+    m = block_reduce_max(m, red);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
+        if (i < npad) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i + e < n) acc += expf(v[j][e] - m);
+        }
+    }
+    acc = block_reduce_sum(acc, red);
+    const float l = m + logf(acc);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
+        if (i < npad) {
+            af32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = i + e < n ? expf(v[j][e] - l) : 0.f;
+            *reinterpret_cast<af32x4 *>(row + i) = o;
+        }
+    }
+    if (threadIdx.x == 0) lse[blockIdx.x] = l;
+}
+
+// dS = P * (dP - delta_i) in place of dP with delta_i = sum_j P dP / sum_j P formed in the kernel (see
+// k_attn_ds_rows), + the row maximum of |dS|; P and dP rows held in registers
+template <int NV>
+__global__ void __launch_bounds__(256)
+k_attn_ds_rows_reg(const float *__restrict__ p, float *__restrict__ dp, int64_t ld, int64_t npad,
+                   float *__restrict__ rowmax) {
+    __shared__ float red[4];
+    const float *pr = p + (int64_t)blockIdx.x * ld;
+    float *dr = dp + (int64_t)blockIdx.x * ld;
+    af32x4 vp[NV], vd[NV];
+    float acc = 0.f, sp = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
+        if (i < npad) {
+            vp[j] = *reinterpret_cast<const af32x4 *>(pr + i);
+            vd[j] = *reinterpret_cast<const af32x4 *>(dr + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc += vp[j][e] * vd[j][e];
+                sp += vp[j][e];
+            }
+        }
+    }
+    acc = block_reduce_sum(acc, red);
+    sp = block_reduce_sum(sp, red);
+    const float d = sp > 0.f ? acc / sp : acc;
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
+        if (i < npad) {
+            af32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = vp[j][e] * (vd[j][e] - d);
+                m = fmaxf(m, fabsf(o[e]));
+            }
+            *reinterpret_cast<af32x4 *>(dr + i) = o;
+        }
+    }
+    m = block_reduce_max(m, red);
+    if (threadIdx.x == 0) rowmax[blockIdx.x] = m;
+}
+
 }  // namespace dc
 
 using namespace dc;
+
+static inline bool attn_vec_ok(const void *a, const void *b, int64_t ld, int64_t npad) {
+    static const int reg = getenv("DC_ATTN_REG_ROWS") ? atoi(getenv("DC_ATTN_REG_ROWS")) : 1;
+    return reg && npad % 4 == 0 && ld % 4 == 0 && (((uintptr_t)a) & 15) == 0 && (!b || (((uintptr_t)b) & 15) == 0);
+}
 
 static int attn_check(const char *what, const void *s, int64_t ld, int64_t rows, int64_t n, int64_t npad) {
     DC_REQUIRE(rows >= 0 && n >= 1 && npad >= n && ld >= npad, "%s: bad sizes (rows=%lld n=%lld npad=%lld ld=%lld)",
@@ -112,6 +213,15 @@ extern "C" int dc_attn_softmax_rows(float *s, int64_t ld, int64_t rows, int64_t 
     if (int rc = attn_check("dc_attn_softmax_rows", s, ld, rows, n, npad)) return rc;
     if (rows == 0) return DC_OK;
     DC_REQUIRE(lse, "dc_attn_softmax_rows: null lse");
+    const dim3 gr((unsigned)rows), bl(256);
+    hipStream_t hs = (hipStream_t)stream;
+    if (attn_vec_ok(s, nullptr, ld, npad) && npad <= 32 * 1024) {
+        if (npad <= 8 * 1024) hipLaunchKernelGGL((k_attn_softmax_rows_reg<8>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        else if (npad <= 16 * 1024) hipLaunchKernelGGL((k_attn_softmax_rows_reg<16>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        else if (npad <= 24 * 1024) hipLaunchKernelGGL((k_attn_softmax_rows_reg<24>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        else hipLaunchKernelGGL((k_attn_softmax_rows_reg<32>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        return check_launch("dc_attn_softmax_rows");
+    }
     hipLaunchKernelGGL(k_attn_softmax_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld,
                        n, npad, lse);
     return check_launch("dc_attn_softmax_rows");
@@ -132,6 +242,14 @@ extern "C" int dc_attn_ds_rows(const float *p, float *dp, int64_t ld, int64_t ro
     if (int rc = attn_check("dc_attn_ds_rows", p, ld, rows, npad, npad)) return rc;
     if (rows == 0) return DC_OK;
     DC_REQUIRE(dp && rowmax, "dc_attn_ds_rows: null pointer");
+    if (!delta && attn_vec_ok(p, dp, ld, npad) && npad <= 24 * 1024) {
+        const dim3 gr((unsigned)rows), bl(256);
+        hipStream_t hs = (hipStream_t)stream;
+        if (npad <= 8 * 1024) hipLaunchKernelGGL((k_attn_ds_rows_reg<8>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
+        else if (npad <= 16 * 1024) hipLaunchKernelGGL((k_attn_ds_rows_reg<16>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
+        else hipLaunchKernelGGL((k_attn_ds_rows_reg<24>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
+        return check_launch("dc_attn_ds_rows");
+    }
     hipLaunchKernelGGL(k_attn_ds_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, ld,
                        npad, delta, rowmax);
     return check_launch("dc_attn_ds_rows");
