@@ -105,41 +105,43 @@ using af32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <int NV>
 __global__ void __launch_bounds__(256)
-k_attn_softmax_rows_reg(float *__restrict__ s, int64_t ld, int64_t n, int64_t npad, float *__restrict__ lse) {
+k_attn_softmax_rows_reg(float *__restrict__ s, int64_t ld, int64_t n64, int64_t npad64, float *__restrict__ lse) {
     __shared__ float red[4];
     float *row = s + (int64_t)blockIdx.x * ld;
+    const int n = (int)n64, npad = (int)npad64;
     af32x4 v[NV];
+    // columns >= n (key padding) are loaded as -inf: they drop out of the maximum, add exp(-inf) = 0 to the
+    // sum and come out of the last pass as exactly 0 - no per-element tests after the load
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
+        const int i = (j * 256 + (int)threadIdx.x) * 4;
         if (i < npad) {
             v[j] = *reinterpret_cast<const af32x4 *>(row + i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (i + e < n) m = fmaxf(m, v[j][e]);
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] = i + e < n ? v[j][e] : -INFINITY;
+                m = fmaxf(m, v[j][e]);
+            }
+        } else {
+            v[j] = af32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
     }
     m = block_reduce_max(m, red);
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
-        if (i < npad) {
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (i + e < n) acc += expf(v[j][e] - m);
-        }
-    }
+        for (int e = 0; e < 4; ++e) acc += expf(v[j][e] - m);
     acc = block_reduce_sum(acc, red);
     const float l = m + logf(acc);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int64_t i = ((int64_t)j * 256 + threadIdx.x) * 4;
+        const int i = (j * 256 + (int)threadIdx.x) * 4;
         if (i < npad) {
             af32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = i + e < n ? expf(v[j][e] - l) : 0.f;
+            for (int e = 0; e < 4; ++e) o[e] = expf(v[j][e] - l);
             *reinterpret_cast<af32x4 *>(row + i) = o;
         }
     }
