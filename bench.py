@@ -297,6 +297,114 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int, graphs=None):
     return res
 
 
+def dense_roofline_grouped(dev, parts, reps: int):
+    """`roofline_mfma` for the merged encoder path: the THREE grouped layer-2 dense launches of a step
+    (forward, dX - a second forward-shaped block -, dW + its slab reduce; both branches per launch,
+    F = 256, K = 4 x 256), timed with HIP events inside the layer-2 op sequence a step runs (3 merged hops
+    -> grouped forward -> grouped gradient mask -> 3 transposed merged hops -> grouped dX -> grouped dW),
+    so the operands are in the cache state a step leaves them in.  `achieved` = MFMA FLOPs executed
+    (3 fp16 products x algorithmic FLOPs of the REAL rows; padding rows are not counted) / time."""
+    from deformcontact_amd import _lib, ops
+    from deformcontact_amd.graph import GraphIndex, current_stream_ptr
+    from deformcontact_amd.ops import _i64_array, _ptr_array, _vp_array
+    L = _lib.lib()
+    st = current_stream_ptr(dev)
+    fi = fo = 256
+    nseg, ng = 4, len(parts)
+    mg = GraphIndex.from_parts(parts)
+    n = mg.num_nodes
+    n_real = sum(r for r in mg.rows)
+    slab = ops._alloc_slab(n, nseg * fi, dev).normal_()
+    gslab = ops._alloc_slab(n, nseg * fo, dev).normal_()
+    for t in (slab, gslab):                      # padding rows are zero rows
+        ends = list(mg.row_beg[1:]) + [n]
+        for r0, r, r1 in zip(mg.row_beg, mg.rows, ends):
+            t[r0 + r:r1].zero_()
+    ws = [[torch.randn(fo, fi, device=dev) / 16 for _ in range(nseg)] for _ in range(ng)]
+    bias = [torch.randn(fo, device=dev) for _ in range(ng)]
+    out = torch.empty(n, fo, device=dev)
+    gouts = [torch.randn(r, fo, device=dev) for r in mg.rows]
+    gx = torch.empty(n, fi, device=dev)
+    gws = [[torch.empty(fo, fi, device=dev) for _ in range(nseg)] for _ in range(ng)]
+    gbs = [torch.empty(fo, device=dev) for _ in range(ng)]
+    rowmax, g0max, growmax = (torch.zeros(n, device=dev) for _ in range(3))
+    wmax, wtmax = torch.empty(ng, fo, device=dev), torch.empty(ng, fi, device=dev)
+    wimg, wtimg = torch.empty(ng, fo, nseg * fi, device=dev), torch.empty(ng, fi, nseg * fo, device=dev)
+    row_beg, rows = _i64_array(mg.row_beg), _i64_array(mg.rows)
+    nb = L.dc_tag_grouped_bwd_dw_workspace_bytes(rows, ng, fi, fo, nseg)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    pv = lambda ts: _vp_array([t.data_ptr() for t in ts])
+    xblocks = [slab[:, s * fi:(s + 1) * fi] for s in range(nseg)]
+    pa_x, pa_ld = _ptr_array(xblocks), _i64_array([slab.stride(0)] * nseg)
+
+    def prep():
+        _lib.check(L.dc_tag_grouped_weight_prep(pv([w for g in ws for w in g]), ng, nseg, fo, fi, pv(list(wmax)),
+                                                pv(list(wimg)), pv(list(wtimg)), pv(list(wtmax)), st), "prep")
+
+    def fwd():
+        _lib.check(L.dc_tag_grouped_fwd_h2p(slab.data_ptr(), slab.stride(0), ng, row_beg, rows, n, pv(list(wimg)),
+                                            pv(bias), 1, out.data_ptr(), fo, nseg * fi, fo, rowmax.data_ptr(),
+                                            pv(list(wmax)), st), "fwd")
+
+    def mask():
+        _lib.check(L.dc_tag_grouped_mask_grad(pv(gouts), _i64_array([fo] * ng), ng, row_beg, rows, n, out.data_ptr(),
+                                              fo, gslab.data_ptr(), gslab.stride(0), fo, g0max.data_ptr(),
+                                              growmax.data_ptr(), st), "mask")
+
+    def dx():
+        _lib.check(L.dc_tag_grouped_fwd_h2p(gslab.data_ptr(), gslab.stride(0), ng, row_beg, rows, n, pv(list(wtimg)),
+                                            None, 0, gx.data_ptr(), fi, nseg * fo, fi, growmax.data_ptr(),
+                                            pv(list(wtmax)), st), "dx")
+
+    def dw():
+        _lib.check(L.dc_tag_grouped_bwd_dw_h2(gslab.data_ptr(), gslab.stride(0), pa_x, pa_ld, nseg, ng, row_beg, rows,
+                                              n, pv([w for g in gws for w in g]), pv(gbs), 0, scratch.data_ptr(), nb,
+                                              fi, fo, g0max.data_ptr(), rowmax.data_ptr(), st), "dw")
+    prep()
+    evs = []
+
+    def sequence(record):
+        ops.chained_hops(mg, slab, fi, 3, backward=False, rowmax=rowmax)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+        if record:
+            e[0].record()
+        fwd()
+        if record:
+            e[1].record()
+        mask()
+        ops.chained_hops(mg, gslab, fo, 3, backward=False, rowmax=growmax, transposed=True, rowmax_has_block0=True)
+        if record:
+            e[2].record()
+        dx()
+        if record:
+            e[3].record()
+        dw()
+        if record:
+            e[4].record()
+            evs.append(e)
+    for _ in range(2):
+        sequence(False)
+    for _ in range(max(reps, 5)):
+        sequence(True)
+    torch.cuda.synchronize()
+    t = {"fwd": [e[0].elapsed_time(e[1]) for e in evs], "dX": [e[2].elapsed_time(e[3]) for e in evs],
+         "dW_incl_reduce": [e[3].elapsed_time(e[4]) for e in evs]}
+    ms = sum(sum(v) for v in t.values()) / len(evs)
+    flops = 3 * 2.0 * n_real * fi * nseg * fo
+    achieved = 3 * flops / ms / 1e9
+    return {"bound": "mfma", "kernel": "dc::k_fwd_h2w x2 (grouped forward, grouped dX in forward shape) / k_dw_h2w "
+                                       "(grouped layer-2 dense blocks of BOTH branches, fp16x2, 128 x 256 tiles)",
+            "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+            "executed": "3 fp16 MFMA products per fp32 product tile",
+            "fp32_equivalent_TFLOPs": round(flops / ms / 1e9, 1), "fp32_mfma_peak": 157.3,
+            "algorithmic_flop_per_step_l2": flops, "us_per_3_launches": round(ms * 1e3, 1),
+            "sustained_bf16_peak_measured": "1.5-1.86 PF/s under DVFS (tools/mfma_peak_bf16.hip)",
+            "measured": "the three grouped launches inside the layer-2 op sequence of a step (merged hops -> forward "
+                        "-> mask -> transposed merged hops -> dX -> dW + slab reduce), eager, HIP events on the "
+                        "launch stream around each dense launch; FLOPs of the real rows only",
+            "in_sequence_us": {k: round(sum(v) / len(v) * 1e3, 1) for k, v in t.items()}}
+
+
 def full_step_b4(dev, steps: int = 20, batch: int = 4):
     """Extra, not the headline: the reference's whole train step (train.py:46-58,71-73) at its
     shipped batch size 4 (configs/everyday.json:26) and at the benchmark batch 32 - encoder on the
@@ -631,14 +739,25 @@ def main():
         a, b = enc(*slots[slot])
         torch.autograd.backward([a, b], [g_rest, g_rig])
 
+    ar_events = []                                     # HIP events around the gradient all-reduce (N > 1)
+
     def tail():
-        bucket.all_reduce_mean()
+        if world > 1 and len(ar_events) < 4096:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bucket.all_reduce_mean()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            bucket.all_reduce_mean()
         if opt is not None:
             opt.step()
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    captured = []
 
     def capture(body):
         """`body()` as one hipGraph (None with --no-graph or if capture fails)."""
@@ -648,6 +767,7 @@ def main():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 body()
+            captured.append(g)
             return g
         except Exception as e:  # pragma: no cover
             if rank == 0:
@@ -678,8 +798,8 @@ def main():
         dc_graph.clear_cache()
         if mode == "cached":
             load(0, 0)
-            for b_, n_ in zip(slots[0], (n_s, n_r)):
-                dc_graph.graph_index(b_.edge_index, n_)._static_ok = True   # constant for the graph's life
+            for g_ in enc.topology(*slots[0]):
+                g_._static_ok = True                                        # constant for the graph's life
 
             def body():
                 fwd_bwd(0)
@@ -743,7 +863,7 @@ def main():
     value = edges_per_rank * world * args.steps / elapsed / 1e6
     # ---- secondary: the per-batch topology work left out of the loop (round-1 headline definition) ----
     elapsed_c = timed(make_mode("cached"), args.steps, warmup)
-    graph_used = not args.no_graph
+    graph_used = len(captured) >= 2             # both modes really replay a captured graph
 
     out = {
         "metric": "M edges/sec fwd+bwd, everyday-deform batch=32 per GPU (encoder hot path)",
@@ -771,23 +891,31 @@ def main():
             "value_cached_topology": "one fixed batch replayed, adjacency and first-layer hops built once "
                                      "outside the loop (round-1 headline definition)",
             "hipgraph": graph_used, "two_stream_branches": not args.serial_branches,
+            "merged_branches": bool(enc._mergeable(rest.x, rig.x)),
             "parallelism": f"dp{world}",
         },
     }
 
+    if world > 1:
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in ar_events[-max(args.steps, 1):])
+        out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "allreduce_bytes": int(bucket.flat.numel() * bucket.flat.element_size()),
+                       "allreduce_us": round(us[len(us) // 2], 1) if us else None,
+                       "allreduce_us_max": round(us[-1], 1) if us else None,
+                       "collective": "one all_reduce(AVG) per step over the flat fp32 gradient bucket "
+                                     "(dp.GradBucket.all_reduce_mean), issued after the captured fwd+bwd; HIP events "
+                                     "on rank 0's stream around the call, median / max over the timed steps"}
     if rank == 0:
         # ---- roofline of the dominant kernel: the F=256 hop as a step launches it
         # (k_spmm_wave<4,8,true>: the hop + the row maxima the dense block scales by; forward over
         # the sorted adjacency, backward - on the masked gradient - over the transposed one) ----
-        gs, gr = graph_index(rest.edge_index, n_s), graph_index(rig.edge_index, n_r)
+        from tools import pmc_hop
+        from deformcontact_amd.graph import GraphIndex
         f = 256
-        cases = []
-        for g, n, e in ((gs, n_s, e_s), (gr, n_r, e_r)):
-            slab = ops._alloc_slab(n, 4 * f, dev).normal_()  # a hop slab: K+1 column blocks, product layout
-            rm = torch.zeros(n, device=dev)
-            nbytes = (hop_bytes_compulsory(n, e, f, False), hop_bytes(n, e, f, False))
-            cases.append((g.fwd, slab[:, :f], slab[:, f:2 * f], rm, nbytes))            # fwd hop
-            cases.append((g.bwd, slab[:, 2 * f:3 * f], slab[:, 3 * f:], rm, nbytes))    # bwd hop
+        merged = enc._mergeable(rest.x, rig.x)
+        parts = [(rest.edge_index, n_s), (rig.edge_index, n_r)]
+
         def graph_time(fn, launches_per_call: int, calls: int = 20):
             """Device time per launch of `fn` (which enqueues `launches_per_call` kernels), replayed from
             a hipGraph `calls` x per replay so that the host (ctypes + Python, ~15 us per launch - as
@@ -810,57 +938,54 @@ def main():
             torch.cuda.synchronize()
             return ev0.elapsed_time(ev1) / (reps * calls * launches_per_call)
 
-        per_case = []
-        for adj, x, o, rm, nbytes in cases:                # isolated, same launch back to back
-            ms = graph_time(lambda: ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2), 1)
-            per_case.append({"compulsory_bytes": nbytes[0], "us": round(ms * 1e3, 2),
-                             "GBps": round(nbytes[0] / ms / 1e6, 1),
-                             "frac": round(nbytes[0] / ms / 1e6 / HBM_PEAK_GBS, 4)})
-        # the roofline figure: the 12 F=256 hop launches of a step IN THE ORDER AND ON THE BUFFERS a
-        # step uses - per branch the forward chain block0 -> 1 -> 2 -> 3 of the layer-2 slab (each hop
-        # reads what the previous one wrote) and the same chain over the transposed adjacency on the
-        # gradient slab, all with the row-maxima side output - HIP events on this stream
-        seq = []
-        for g, n, e in ((gs, n_s, e_s), (gr, n_r, e_r)):
-            slab_f, slab_b = ops._alloc_slab(n, 4 * f, dev).normal_(), ops._alloc_slab(n, 4 * f, dev).normal_()
-            rm_f, rm_b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-            nbytes = (hop_bytes_compulsory(n, e, f, False), hop_bytes(n, e, f, False))
-            seq.append((g, slab_f, rm_f, False, nbytes))
-            seq.append((g, slab_b, rm_b, True, nbytes))
-
-        def in_step_sequence():
-            for g, slab, rm, bwd, _ in seq:
-                if bwd:       # backward: transposed hops on the masked gradient (block 0 maxima known)
-                    ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm, transposed=True,
-                                     rowmax_has_block0=True)
-                else:
-                    ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm)
-        nlaunch = 3 * len(seq)
+        # isolated launches (same launch back to back): the adjacency a step hops over, both directions
+        per_case = {}
+        iso = [("merged", GraphIndex.from_parts(parts), n_s + n_r, e_s + e_r)] if merged else \
+            [("soft", GraphIndex(rest.edge_index, n_s), n_s, e_s), ("rigid", GraphIndex(rig.edge_index, n_r), n_r, e_r)]
+        for name, g, n, e in iso:
+            slab = ops._alloc_slab(g.num_nodes, 4 * f, dev).normal_()
+            rm = torch.zeros(g.num_nodes, device=dev)
+            for tag, adj, x, o in (("fwd", g.fwd, slab[:, :f], slab[:, f:2 * f]),
+                                   ("bwd", g.bwd, slab[:, 2 * f:3 * f], slab[:, 3 * f:])):
+                ms = graph_time(lambda: ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2), 1)
+                nb = hop_bytes_compulsory(n, e, f, False)
+                per_case[f"{name}_{tag}"] = {"compulsory_bytes": nb, "us": round(ms * 1e3, 2),
+                                             "GBps": round(nb / ms / 1e6, 1),
+                                             "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        # the roofline figure: the F=256 hop launches of a step IN THE ORDER AND ON THE BUFFERS a step uses -
+        # the forward chain block0 -> 1 -> 2 -> 3 of the layer-2 slab (each hop reads what the previous one
+        # wrote) and the same chain over the transposed adjacency on the gradient slab, all with the row-maxima
+        # side output; merged encoder path: 6 launches over the merged adjacency of both branches, else 12
+        in_step_sequence, nlaunch, comp_bytes, gath_bytes = pmc_hop.hop_sequence(dev, parts, merged, f)
         tot_ms = graph_time(in_step_sequence, nlaunch, calls=5) * nlaunch
-        comp_bytes = float(sum(3 * c[4][0] for c in seq))
-        gath_bytes = float(sum(3 * c[4][1] for c in seq))
         achieved = comp_bytes / tot_ms / 1e6                     # GB/s of compulsory bytes
-        cases = [None] * nlaunch
         out["roofline"] = {
-            "bound": "hbm", "kernel": "dc::k_spmm_wave<4,8,true> (F=256 hop + row maxima, as launched in a step)",
+            "bound": "hbm", "kernel": "dc::k_spmm_wave<4,8,true> (F=256 hop + row maxima, as launched in a step" +
+                                      (": ONE launch for both branches over the merged adjacency)" if merged else ")"),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
             "bytes_model": "compulsory: E*8 + N*(2*4F + 4) per launch (each index / weight once, each "
-                           "feature row in once and out once; SURVEY.md 8(d) strict lower bound)",
-            "compulsory_bytes_per_launch": int(comp_bytes / len(cases)),
-            "avg_launch_us": round(tot_ms / len(cases) * 1e3, 2),
+                           "feature row in once and out once; SURVEY.md 8(d) strict lower bound; N, E = real "
+                           "nodes / edges of the batch, padding rows of the merged node space not counted)",
+            "launches_per_step": nlaunch,
+            "compulsory_bytes_per_launch": int(comp_bytes / nlaunch),
+            "avg_launch_us": round(tot_ms / nlaunch * 1e3, 2),
             "frac_of_measured_copy_peak_6290GBps": round(achieved / 6290.0, 4),
             "l2_served_algorithmic_GBps": round(gath_bytes / tot_ms / 1e6, 1),
-            "l2_served_algorithmic_bytes_per_launch": int(gath_bytes / len(cases)),
+            "l2_served_algorithmic_bytes_per_launch": int(gath_bytes / nlaunch),
             "l2_served_note": "SURVEY.md 8(d) gather model (every neighbour row counted per edge); most of "
                               "these reads are L2 hits, so this figure is NOT an HBM fraction",
-            "measured": "the 12 F=256 hop launches of a step in step order on step-shaped slabs (forward chains "
-                        "and transposed chains of both branches), replayed from a hipGraph as the step is "
-                        "(no host launch cost), HIP events on the launch stream, launch gaps included",
-            "cases_isolated": {"soft_fwd": per_case[0], "soft_bwd": per_case[1],
-                               "rigid_fwd": per_case[2], "rigid_bwd": per_case[3]},
+            "measured": f"the {nlaunch} F=256 hop launches of a step in step order on step-shaped slabs (forward "
+                        "chain and transposed chain" + (" over the merged adjacency" if merged else "s of both branches") +
+                        "), replayed from a hipGraph as the step is (no host launch cost), HIP events on the launch "
+                        "stream, launch gaps included",
+            "cases_isolated": per_case,
         }
-        out["roofline_mfma"] = dense_roofline(dev, n_s, n_r, args.kernel_reps // 4 or 1, graphs=(gs, gr))
+        gs, gr = GraphIndex(rest.edge_index, n_s), GraphIndex(rig.edge_index, n_r)
+        if merged and ops.DENSE_SPLIT_BF16 and ops.DENSE_F16X2:
+            out["roofline_mfma"] = dense_roofline_grouped(dev, parts, args.kernel_reps // 4 or 1)
+        else:
+            out["roofline_mfma"] = dense_roofline(dev, n_s, n_r, args.kernel_reps // 4 or 1, graphs=(gs, gr))
         if world == 1 and not args.no_strict_fp32:
             # auditable line: the headline step with every dense block on the fp32 matrix cores
             # (v_mfma_f32_32x32x2_f32, exact fp32 products) instead of the split fp16 / bf16 forms

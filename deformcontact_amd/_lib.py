@@ -26,6 +26,24 @@ _SIGNATURES = {
     "dc_graph_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "dc_graph_build": (c_int, [_vp, c_int64, c_int64, c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, c_int64, _vp]),
+    "dc_graph_build_parts": (c_int, [POINTER(_vp), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int,
+                                     c_int64, c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, c_int64,
+                                     _vp]),
+    "dc_spmm_f32_window": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
+                                   c_int64, c_int64, _vp]),
+    "dc_tag_grouped_weight_prep": (c_int, [POINTER(_vp), c_int, c_int, c_int64, c_int64, POINTER(_vp),
+                                           POINTER(_vp), POINTER(_vp), POINTER(_vp), _vp]),
+    "dc_tag_grouped_fwd_h2p": (c_int, [_vp, c_int64, c_int, POINTER(c_int64), POINTER(c_int64), c_int64,
+                                       POINTER(_vp), POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp,
+                                       POINTER(_vp), _vp]),
+    "dc_tag_grouped_mask_grad": (c_int, [POINTER(_vp), POINTER(c_int64), c_int, POINTER(c_int64),
+                                         POINTER(c_int64), c_int64, _vp, c_int64, _vp, c_int64, c_int64, _vp,
+                                         _vp, _vp]),
+    "dc_tag_grouped_bwd_dw_workspace_bytes": (c_int64, [POINTER(c_int64), c_int, c_int64, c_int64, c_int]),
+    "dc_tag_grouped_bwd_dw_h2": (c_int, [_vp, c_int64, POINTER(_vp), POINTER(c_int64), c_int, c_int,
+                                         POINTER(c_int64), POINTER(c_int64), c_int64, POINTER(_vp),
+                                         POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp, _vp, _vp]),
+    "dc_generic_dense_launches": (c_int64, [c_int]),
     "dc_hash_i64": (c_int, [_vp, c_int64, _vp, _vp]),
     "dc_morton_codes": (c_int, [_vp, c_int64, c_int64, POINTER(c_float), POINTER(c_float), _vp, _vp]),
     "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),

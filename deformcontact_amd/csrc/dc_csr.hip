@@ -32,9 +32,32 @@ constexpr int kRankLoop = 48;        // groups up to this length rank by countin
 constexpr int kBigBlocks = 64;       // extra workgroups of k_emit that sort listed groups
 constexpr int kSortLds = 4096;       // ids sorted in LDS (16 KiB); longer groups in place
 
+// The edge set: up to kMaxParts edge_index arrays read as ONE concatenated edge list (edge ids run
+// through the parts in order) over ONE node space (part p's node ids are shifted by node_off[p]): a
+// block-diagonal union - e.g. the soft and the rigid graph of a batch - without materialising the
+// merged [2, E] array.  One part with offset 0 is the plain edge_index.
+constexpr int kMaxParts = DC_MAX_PARTS;
+struct Edges {
+    const int64_t *src[kMaxParts], *dst[kMaxParts];   // rows 0 / 1 of each part's edge_index
+    int64_t e_beg[kMaxParts + 1];                      // first edge id of each part (e_beg[nparts] = E)
+    int64_t node_off[kMaxParts], nodes[kMaxParts];     // id shift and node count (range check) of each part
+    int nparts;
+};
+
+// endpoints of edge e in the merged node space; false when either lies outside its part's [0, nodes)
+__device__ __forceinline__ bool load_edge(const Edges &ed, int64_t e, int64_t &s, int64_t &d) {
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxParts; ++q)
+        if (q < ed.nparts && e >= ed.e_beg[q]) p = q;
+    const int64_t l = e - ed.e_beg[p];
+    s = ed.src[p][l], d = ed.dst[p][l];
+    const bool ok = s >= 0 && s < ed.nodes[p] && d >= 0 && d < ed.nodes[p];
+    s += ed.node_off[p], d += ed.node_off[p];
+    return ok;
+}
+
 struct Side {
-    const int64_t *key;    // edge_index row that groups this side
-    const int64_t *oth;    // the other row
     int32_t *cnt;          // [N]   counters (workspace)
     int32_t *cur;          // [N]   fill cursors (workspace; a separate array so the scan's loads of
                            //       cnt are independent of its stores)
@@ -51,6 +74,7 @@ struct Side {
 
 struct Build {
     Side s[2];
+    Edges ed;
     int64_t E, N;
     int self_loops;
     int32_t *status;
@@ -71,11 +95,12 @@ __global__ void __launch_bounds__(256)
 k_count(Build b, int nsides) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= b.E) return;
-    const int64_t k = b.s[0].key[e], o = b.s[0].oth[e];
-    if (k < 0 || k >= b.N || o < 0 || o >= b.N) {
+    int64_t src, dst;
+    if (!load_edge(b.ed, e, src, dst)) {
         atomicOr(b.status, 1);
         return;
     }
+    const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
     if (b.self_loops && k == o) return;
     atomicAdd(&b.s[0].cnt[k], 1);
     if (nsides == 2) atomicAdd(&b.s[1].cnt[o], 1);   // side 1 groups by side 0's other row
@@ -237,8 +262,9 @@ __global__ void __launch_bounds__(256)
 k_fill(Build b, int nsides) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < b.E) {
-        const int64_t k = b.s[0].key[t], o = b.s[0].oth[t];
-        if (k < 0 || k >= b.N || o < 0 || o >= b.N) return;
+        int64_t src, dst;
+        if (!load_edge(b.ed, t, src, dst)) return;
+        const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
         if (b.self_loops && k == o) return;
         b.s[0].tmp[atomicAdd(&b.s[0].cur[k], 1)] = (int32_t)t;
         if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cur[o], 1)] = (int32_t)t;
@@ -256,7 +282,12 @@ __device__ __forceinline__ float inv_sqrt_deg(const int32_t *deg_ptr, int64_t v)
 
 __device__ __forceinline__ void emit_one(const Build &b, const Side &sd, int32_t eid, int64_t k,
                                          int32_t out) {
-    const int64_t o = eid < b.E ? sd.oth[eid] : k;
+    int64_t o = k;
+    if (eid < b.E) {
+        int64_t src, dst;
+        load_edge(b.ed, eid, src, dst);
+        o = sd.key_is_dst ? src : dst;
+    }
     sd.perm[out] = eid;
     sd.other[out] = (int32_t)o;
     if (sd.w) {
@@ -329,7 +360,12 @@ k_emit(Build b, unsigned slot_blocks) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= sd.ptr[b.N]) return;
     const int32_t eid = sd.tmp[p];
-    const int64_t k = eid < b.E ? sd.key[eid] : eid - b.E;
+    int64_t k = eid - b.E;
+    if (eid < b.E) {
+        int64_t src, dst;
+        load_edge(b.ed, eid, src, dst);
+        k = sd.key_is_dst ? dst : src;
+    }
     const int32_t beg = sd.ptr[k], end = sd.ptr[k + 1];
     if (end - beg > kRankLoop) return;          // a listed group: the sorting workgroups emit it
     int rank = 0;
@@ -474,8 +510,8 @@ extern "C" int dc_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int
     Build b{};
     b.E = E, b.N = N, b.self_loops = self_loops, b.status = status;
     Side &sd = b.s[0];
-    sd.key = edge_index + (key_row ? E : 0);
-    sd.oth = edge_index + (key_row ? 0 : E);
+    b.ed.nparts = 1, b.ed.src[0] = edge_index, b.ed.dst[0] = edge_index + E;
+    b.ed.e_beg[0] = 0, b.ed.e_beg[1] = E, b.ed.node_off[0] = 0, b.ed.nodes[0] = N;
     carve_side(sd, (char *)workspace, E, N);
     sd.ptr = ptr, sd.other = other, sd.perm = perm, sd.w = w;
     sd.deg_ptr = deg_ptr ? deg_ptr : ptr;
@@ -505,14 +541,58 @@ extern "C" int dc_graph_build(const int64_t *edge_index, int64_t E, int64_t N, i
     Build b{};
     b.E = E, b.N = N, b.self_loops = self_loops, b.status = status;
     char *ws = (char *)workspace;
-    Side &f = b.s[0], &t = b.s[1];
-    f.key = edge_index + E, f.oth = edge_index;          // by destination
-    t.key = edge_index, t.oth = edge_index + E;          // by source
+    Side &f = b.s[0], &t = b.s[1];                       // f: by destination, t: by source
+    b.ed.nparts = 1, b.ed.src[0] = edge_index, b.ed.dst[0] = edge_index + E;
+    b.ed.e_beg[0] = 0, b.ed.e_beg[1] = E, b.ed.node_off[0] = 0, b.ed.nodes[0] = N;
     ws = carve_side(f, ws, E, N);
     carve_side(t, ws, E, N);
     f.ptr = ptr_f, f.other = other_f, f.perm = perm_f, f.w = w_f, f.deg_ptr = ptr_f, f.key_is_dst = 1;
     t.ptr = ptr_b, t.other = other_b, t.perm = perm_b, t.w = w_b, t.deg_ptr = ptr_f, t.key_is_dst = 0;
     return run_build(b, 2, stream, "dc_graph_build");
+}
+
+extern "C" int dc_graph_build_parts(const int64_t *const *edge_index_parts, const int64_t *E_parts,
+                                    const int64_t *node_offset_parts, const int64_t *nodes_parts,
+                                    int nparts, int64_t N, int self_loops,
+                                    int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
+                                    int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
+                                    int32_t *status, void *workspace, int64_t workspace_bytes,
+                                    dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(nparts >= 1 && nparts <= kMaxParts && edge_index_parts && E_parts && node_offset_parts &&
+                   nodes_parts && N >= 0,
+               "dc_graph_build_parts: 1..%d parts with their sizes and offsets required", kMaxParts);
+    Build b{};
+    int64_t E = 0;
+    for (int p = 0; p < nparts; ++p) {
+        DC_REQUIRE(E_parts[p] >= 0 && nodes_parts[p] >= 0 && node_offset_parts[p] >= 0 &&
+                       node_offset_parts[p] + nodes_parts[p] <= N && (E_parts[p] == 0 || edge_index_parts[p]),
+                   "dc_graph_build_parts: part %d: bad size / offset / null edge_index", p);
+        DC_REQUIRE(p == 0 || node_offset_parts[p] >= node_offset_parts[p - 1] + nodes_parts[p - 1],
+                   "dc_graph_build_parts: part %d overlaps the previous one (offsets must ascend)", p);
+        b.ed.src[p] = edge_index_parts[p], b.ed.dst[p] = edge_index_parts[p] + E_parts[p];
+        b.ed.e_beg[p] = E, b.ed.node_off[p] = node_offset_parts[p], b.ed.nodes[p] = nodes_parts[p];
+        E += E_parts[p];
+    }
+    for (int p = nparts; p <= kMaxParts; ++p) b.ed.e_beg[p] = E;
+    b.ed.nparts = nparts;
+    DC_REQUIRE(E + N < (int64_t)INT32_MAX, "dc_graph_build_parts: E+N=%lld exceeds int32 indexing",
+               (long long)(E + N));
+    DC_REQUIRE(ptr_f && ptr_b && status && workspace, "dc_graph_build_parts: null ptr/status/workspace");
+    DC_REQUIRE(E == 0 || (other_f && perm_f && other_b && perm_b), "dc_graph_build_parts: null edge arrays");
+    DC_REQUIRE((w_f == nullptr) == (w_b == nullptr), "dc_graph_build_parts: w_f and w_b go together");
+    DC_REQUIRE(workspace_bytes >= dc_graph_workspace_bytes(E, N),
+               "dc_graph_build_parts: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+               (long long)dc_graph_workspace_bytes(E, N));
+    DC_REQUIRE(((uintptr_t)workspace & 15) == 0, "dc_graph_build_parts: workspace not 16-byte aligned");
+    b.E = E, b.N = N, b.self_loops = self_loops, b.status = status;
+    char *ws = (char *)workspace;
+    Side &f = b.s[0], &t = b.s[1];
+    ws = carve_side(f, ws, E, N);
+    carve_side(t, ws, E, N);
+    f.ptr = ptr_f, f.other = other_f, f.perm = perm_f, f.w = w_f, f.deg_ptr = ptr_f, f.key_is_dst = 1;
+    t.ptr = ptr_b, t.other = other_b, t.perm = perm_b, t.w = w_b, t.deg_ptr = ptr_f, t.key_is_dst = 0;
+    return run_build(b, 2, stream, "dc_graph_build_parts");
 }
 
 extern "C" int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last, int32_t *pos_of,

@@ -128,6 +128,26 @@ __device__ __forceinline__ float h2_block_max(const float *v, int64_t beg, int64
     return m;
 }
 
+// Row groups of a block-diagonal union (e.g. the soft and the rigid branch of the encoder in one node space,
+// models/model.py:69-78): rows [row_beg[g], row_beg[g+1]) use group g's weights.  Group starts are multiples
+// of kGroupAlign rows (the host pads every group with zero rows), so no tile / node chunk straddles two groups.
+constexpr int kMaxGroups = DC_MAX_GROUPS;
+constexpr int kGroupAlign = DC_GROUP_ALIGN;
+struct FwdGroups {
+    int n;                              // 0 = ungrouped (p.w[0] / p.bias / p.h2.b_rowmax apply to every row)
+    int64_t row_beg[kMaxGroups];
+    const float *w[kMaxGroups];         // pre-split weight image of group g
+    const float *bias[kMaxGroups];
+    const float *b_rowmax[kMaxGroups];
+};
+__device__ __forceinline__ int group_of_row(const int64_t (&row_beg)[kMaxGroups], int n, int64_t row) {
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxGroups; ++q)
+        if (q < n && row >= row_beg[q]) g = q;
+    return g;
+}
+
 struct FwdParams {
     Mat x[kMaxSeg];
     Mat w[kMaxSeg];
@@ -141,6 +161,7 @@ struct FwdParams {
     // attention recompute (dc_tag_linear_fwd_h2p_exp): out[i, j] = j < exp_ncols ? exp(acc - exp_lse[i]) : 0
     const float *exp_lse;
     int64_t exp_ncols;
+    FwdGroups grp;
 };
 
 struct DxParams {
@@ -154,6 +175,15 @@ struct DxParams {
     H2Scales h2;
 };
 
+// node chunks of a grouped dW: group g owns chunks [chunk_beg[g], chunk_beg[g+1]) of chunk_rows[g] nodes each
+// over rows [row_beg[g], row_end[g]) - the plan a separate launch over that group alone would use, so the
+// partial slabs (and their sums) are bit-identical to it
+struct DwGroups {
+    int n;                              // 0 = ungrouped
+    int chunk_beg[kMaxGroups + 1];
+    int64_t row_beg[kMaxGroups], row_end[kMaxGroups], chunk_rows[kMaxGroups];
+};
+
 struct DwParams {
     Mat g, mask;
     int has_mask;
@@ -163,6 +193,7 @@ struct DwParams {
     int64_t N, Fi, Fo, chunk_rows;
     int nseg, nchunks;
     H2Scales h2;
+    DwGroups grp;
 };
 
 
@@ -175,6 +206,8 @@ bool dw_fast_launch(const DwParams &p, int mb, hipStream_t hs);
 bool fwd_split_launch(const FwdParams &p, int mb, int products, hipStream_t hs);
 bool dx_split_launch(DxParams p, float *wt, int mb, int products, hipStream_t hs);
 bool dw_split_launch(const DwParams &p, int mb, int products, hipStream_t hs);
+// dW, fp16x2, 128 x 256 tiles over node chunks (dc_dense_split.hip); the only dW kernel that takes p.grp
+bool dw_h2w_launch(const DwParams &p, hipStream_t hs);
 // tuned forward-shaped fp16x2 kernel (dc_dense_h2.hip)
 bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs);
 // 128 x 256 tiles, BK = 32, for the wide layers (dc_dense_h2w.hip); tried first by fwd_h2_launch

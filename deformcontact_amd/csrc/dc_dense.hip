@@ -23,6 +23,11 @@
 
 #include "dc_dense.h"
 
+#include <atomic>
+// launches of the GENERIC (bounds-checked, scalar-load) dense kernels since the library was loaded / the counter was
+// reset: the default step must never reach them (dc_generic_dense_launches; tests pin that)
+static std::atomic<long long> g_generic_dense_launches{0};
+
 namespace dc {
 
 // Loads are UNCONDITIONAL with clamped (always in-bounds) addresses and the out-of-range /
@@ -370,8 +375,7 @@ struct ReduceParams {
     int nseg, nchunks, ngw, bps, accumulate;
 };
 
-__global__ void __launch_bounds__(256)
-k_dw_reduce(ReduceParams p) {
+__device__ __forceinline__ void dw_reduce_body(const ReduceParams &p) {
     const int64_t per_out = p.Fo * p.cols, total = per_out * p.ngw;
     const int64_t seg_elems = p.Fo * p.Fi, slab = seg_elems * p.nseg;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,6 +407,16 @@ k_dw_reduce(ReduceParams p) {
     for (; c < p.nchunks; ++c) s += src[(int64_t)c * stride];
     *dst = p.accumulate ? *dst + s : s;
 }
+
+__global__ void __launch_bounds__(256)
+k_dw_reduce(ReduceParams p) { dw_reduce_body(p); }
+
+// one launch for the groups of a grouped dW (blockIdx.y = group): each group sums its own chunk range
+struct ReduceGroups {
+    ReduceParams g[kMaxGroups];
+};
+__global__ void __launch_bounds__(256)
+k_dw_reduce_grouped(ReduceGroups rg) { dw_reduce_body(rg.g[blockIdx.y]); }
 
 static inline Mat make_mat(const float *p, int64_t ld, bool *vec) {
     if (((uintptr_t)p & 15) != 0 || (ld % 4) != 0) *vec = false;
@@ -528,6 +542,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
                               "equal leading dimensions (Fi=%lld)", (long long)Fi);
     if (use_fast() && vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
     static const int trace = env_int("DC_DENSE_TRACE", 0);
+    ++g_generic_dense_launches;
     if (trace)
         fprintf(stderr, "[dc] generic fwd dense kernel: N=%lld Fi=%lld Fo=%lld nseg=%d vec=%d ldx=%lld ldo=%lld products=%d\n",
                 (long long)N, (long long)Fi, (long long)Fo, nseg, (int)vec, (long long)ldxs[0], (long long)ldo, products);
@@ -576,6 +591,7 @@ static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     DC_REQUIRE(products != 2, "dc_tag_linear_bwd_dx_h2: needs Fo %% 16 == 0, Fi %% 4 == 0 and 16-byte "
                               "aligned operands (Fi=%lld Fo=%lld)", (long long)Fi, (long long)Fo);
     if (use_fast() && vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
+    ++g_generic_dense_launches;
 #define DC_DX(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) {
         if (vec && p.has_mask) DC_DX(2, true, true);
@@ -717,6 +733,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
         t.bias_partial = p.bias_partial ? p.bias_partial + (int64_t)p.nchunks * Fo : nullptr;
         t.h2 = H2Scales{};
         const dim3 gt((unsigned)(tiles * nseg));
+        ++g_generic_dense_launches;                      // (only the < 16 trailing rows)
         if (mb == 2) {
             if (p.has_mask) hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, true>), gt, bd, 0, hs, t);
             else hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, false>), gt, bd, 0, hs, t);
@@ -731,6 +748,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
                "Fo %% 4 == 0 and 16-byte aligned operands (N=%lld)", (long long)N);
     fast_done = fast_done || (use_fast() && vec && dw_fast_launch(p, mb, hs));
 #define DC_DW(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
+    if (!fast_done) ++g_generic_dense_launches;
     if (fast_done) {
     } else
     if (mb == 2) {
@@ -987,7 +1005,7 @@ __device__ __forceinline__ void wprep_put(_Float16 *img_row, int64_t k, float v,
     rec[0] = h;
     rec[16] = (_Float16)(x - (float)h);
 }
-__global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
+__device__ __forceinline__ void weight_prep_body(const WPrepParams &p) {
     const int lane = threadIdx.x & 63;
     const int64_t rb = (p.Fo + 3) / 4;
     float m = 0.f;
@@ -1027,6 +1045,7 @@ __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) {
         }
     }
 }
+__global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) { weight_prep_body(p); }
 }  // namespace dc
 
 extern "C" int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,
@@ -1084,4 +1103,246 @@ extern "C" int dc_tag_weight_rowmax(const float *const *ws, int nseg, int64_t Fo
     p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.out = w_rowmax;
     hipLaunchKernelGGL(k_w_rowmax, dim3((unsigned)((Fo + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_tag_weight_rowmax");
+}
+
+
+// ======================================================================================================
+// Grouped launches: the layer-2 blocks of BOTH encoder branches (models/model.py:69-78) as one launch over
+// a merged, block-diagonal node space.  Group g = rows [row_beg[g], row_beg[g] + rows[g]) with its own
+// weights; row_beg[g] is a multiple of DC_GROUP_ALIGN and the rows between the groups (and behind the last
+// one, up to N_total - itself a multiple of DC_GROUP_ALIGN) are ZERO rows the host pads with (isolated nodes
+// of the merged adjacency: the hops keep them zero).  Per row the arithmetic is that of the ungrouped
+// entry points on that group alone - outputs and gradients are bit-identical to separate launches.
+// ======================================================================================================
+namespace dc {
+static int check_groups(const char *what, int ngroups, const int64_t *row_beg, const int64_t *rows,
+                        int64_t N_total) {
+    DC_REQUIRE(ngroups >= 1 && ngroups <= kMaxGroups && row_beg && rows, "%s: 1..%d groups required", what,
+               kMaxGroups);
+    DC_REQUIRE(N_total >= 0 && N_total % kGroupAlign == 0, "%s: N_total must be a multiple of %d", what,
+               kGroupAlign);
+    for (int g = 0; g < ngroups; ++g) {
+        DC_REQUIRE(row_beg[g] >= 0 && row_beg[g] % kGroupAlign == 0 && rows[g] >= 0,
+                   "%s: group %d must start at a multiple of %d rows", what, g, kGroupAlign);
+        const int64_t next = g + 1 < ngroups ? row_beg[g + 1] : N_total;
+        DC_REQUIRE(row_beg[g] + rows[g] <= next, "%s: group %d overlaps the next one", what, g);
+    }
+    return DC_OK;
+}
+
+struct MaskGradGroups {
+    const float *g[kMaxGroups];
+    int64_t ldg[kMaxGroups], row_beg[kMaxGroups], rows[kMaxGroups];
+    int n;
+};
+// gm[i,:] = g_group(i)[i - row_beg,:] * (out[i,:] > 0) for the rows of a group, 0 for padding rows;
+// rowmax[i] = max |gm[i,:]| : one wave per merged row (k_mask_grad over a merged node space)
+__global__ void __launch_bounds__(256)
+k_mask_grad_grouped(MaskGradGroups q, const float *__restrict__ mask, int64_t ldm, float *__restrict__ gm,
+                    int64_t ldgm, int64_t N, int F, float *__restrict__ rowmax_a, float *__restrict__ rowmax_b) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int grp = group_of_row(q.row_beg, q.n, row);
+    const int64_t local = row - q.row_beg[grp];
+    const bool live = local < q.rows[grp];
+    const float *gr = q.g[grp] + (live ? local : 0) * q.ldg[grp], *mr = mask ? mask + row * ldm : nullptr;
+    float *o = gm + row * ldgm;
+    float m = 0.f;
+    for (int c = lane * 4; c < F; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            v = *reinterpret_cast<const float4 *>(gr + c);
+            if (mr) {
+                const float4 k = *reinterpret_cast<const float4 *>(mr + c);
+                v = make_float4(k.x > 0.f ? v.x : 0.f, k.y > 0.f ? v.y : 0.f, k.z > 0.f ? v.z : 0.f,
+                                k.w > 0.f ? v.w : 0.f);
+            }
+        }
+        *reinterpret_cast<float4 *>(o + c) = v;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if (lane == 0) {
+        rowmax_a[row] = m;
+        if (rowmax_b) rowmax_b[row] = m;
+    }
+}
+
+struct WPrepGroups {
+    WPrepParams g[kMaxGroups];
+};
+__global__ void __launch_bounds__(256) k_weight_prep_grouped(WPrepGroups q) { weight_prep_body(q.g[blockIdx.y]); }
+}  // namespace dc
+
+extern "C" int dc_tag_grouped_weight_prep(const float *const *ws, int ngroups, int nseg, int64_t Fo, int64_t Fi,
+                                          float *const *w_rowmax, void *const *w_image, void *const *wt_image,
+                                          float *const *wt_rowmax, dc_stream_t stream) {
+    DC_REQUIRE(ngroups >= 1 && ngroups <= kMaxGroups && nseg >= 1 && nseg <= kMaxSeg && Fo >= 1 && Fi >= 1 && ws &&
+                   w_rowmax && w_image,
+               "dc_tag_grouped_weight_prep: bad arguments");
+    DC_REQUIRE((nseg * Fi) % 16 == 0 && (!wt_image || (nseg * Fo) % 16 == 0),
+               "dc_tag_grouped_weight_prep: images need a reduction extent that is a multiple of 16");
+    DC_REQUIRE((wt_image == nullptr) == (wt_rowmax == nullptr),
+               "dc_tag_grouped_weight_prep: wt_image and wt_rowmax go together");
+    WPrepGroups q{};
+    for (int g = 0; g < ngroups; ++g) {
+        WPrepParams &p = q.g[g];
+        for (int s = 0; s < nseg; ++s) {
+            DC_REQUIRE(ws[g * nseg + s], "dc_tag_grouped_weight_prep: null segment %d of group %d", s, g);
+            p.w[s] = ws[g * nseg + s];
+        }
+        DC_REQUIRE(w_rowmax[g] && w_image[g] && (((uintptr_t)w_image[g]) & 15) == 0 &&
+                       (!wt_image || (wt_image[g] && wt_rowmax[g] && (((uintptr_t)wt_image[g]) & 15) == 0)),
+                   "dc_tag_grouped_weight_prep: null / misaligned output of group %d", g);
+        p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax[g];
+        p.wt_rowmax = wt_rowmax ? wt_rowmax[g] : nullptr;
+        p.wimg = (_Float16 *)w_image[g], p.wtimg = wt_image ? (_Float16 *)wt_image[g] : nullptr;
+    }
+    const int64_t blocks = (Fo + 3) / 4 + (wt_image ? (Fi + 3) / 4 : 0);
+    hipLaunchKernelGGL(k_weight_prep_grouped, dim3((unsigned)blocks, (unsigned)ngroups), dim3(256), 0,
+                       (hipStream_t)stream, q);
+    return check_launch("dc_tag_grouped_weight_prep");
+}
+
+extern "C" int dc_tag_grouped_fwd_h2p(const float *x, int64_t ldx, int ngroups, const int64_t *row_beg,
+                                      const int64_t *rows, int64_t N_total, const void *const *w_images,
+                                      const float *const *biases, int relu, float *out, int64_t ldo, int64_t K,
+                                      int64_t Fo, const float *x_rowmax, const float *const *w_rowmaxes,
+                                      dc_stream_t stream) {
+    if (int rc = check_groups("dc_tag_grouped_fwd_h2p", ngroups, row_beg, rows, N_total)) return rc;
+    if (N_total == 0) return DC_OK;
+    DC_REQUIRE(x && w_images && out && x_rowmax && w_rowmaxes && ldo >= Fo, "dc_tag_grouped_fwd_h2p: null pointer");
+    DC_REQUIRE(K >= 32 && K % 32 == 0 && ldx >= K && ldx % 4 == 0 && (((uintptr_t)x) & 15) == 0,
+               "dc_tag_grouped_fwd_h2p: K %% 32 == 0 and a 16-byte aligned x required (K=%lld)", (long long)K);
+    FwdParams p{};
+    p.x[0] = Mat{x, ldx};
+    p.out = out, p.ldo = ldo, p.N = N_total, p.Fi = K, p.Fo = Fo, p.nseg = 1, p.relu = relu;
+    p.h2.a_rowmax = x_rowmax, p.h2.b_presplit = 1;
+    p.grp.n = ngroups;
+    for (int g = 0; g < ngroups; ++g) {
+        DC_REQUIRE(w_images[g] && w_rowmaxes[g] && (((uintptr_t)w_images[g]) & 15) == 0,
+                   "dc_tag_grouped_fwd_h2p: null / misaligned weights of group %d", g);
+        p.grp.row_beg[g] = row_beg[g], p.grp.w[g] = (const float *)w_images[g];
+        p.grp.bias[g] = biases ? biases[g] : nullptr, p.grp.b_rowmax[g] = w_rowmaxes[g];
+    }
+    // a single group is the ungrouped launch
+    p.w[0] = Mat{p.grp.w[0], K}, p.bias = p.grp.bias[0], p.h2.b_rowmax = p.grp.b_rowmax[0];
+    DC_REQUIRE(fwd_h2w_launch(p, (hipStream_t)stream),
+               "dc_tag_grouped_fwd_h2p: shape not eligible for the 128 x 256 tile kernel (K=%lld Fo=%lld)",
+               (long long)K, (long long)Fo);
+    return check_launch("dc_tag_grouped_fwd_h2p");
+}
+
+extern "C" int dc_tag_grouped_mask_grad(const float *const *g, const int64_t *ldg, int ngroups,
+                                        const int64_t *row_beg, const int64_t *rows, int64_t N_total,
+                                        const float *out_for_mask, int64_t ldo, float *gm, int64_t ldgm, int64_t F,
+                                        float *rowmax_a, float *rowmax_b, dc_stream_t stream) {
+    if (int rc = check_groups("dc_tag_grouped_mask_grad", ngroups, row_beg, rows, N_total)) return rc;
+    if (N_total == 0) return DC_OK;
+    DC_REQUIRE(g && ldg && gm && rowmax_a && F >= 4 && F % 4 == 0 && F < (1 << 24) && ldgm >= F && ldgm % 4 == 0 &&
+                   (((uintptr_t)gm) & 15) == 0,
+               "dc_tag_grouped_mask_grad: null pointer, F %% 4 != 0 or misaligned gm");
+    DC_REQUIRE(!out_for_mask || (ldo >= F && ldo % 4 == 0 && (((uintptr_t)out_for_mask) & 15) == 0),
+               "dc_tag_grouped_mask_grad: misaligned mask");
+    MaskGradGroups q{};
+    q.n = ngroups;
+    for (int k = 0; k < ngroups; ++k) {
+        DC_REQUIRE(rows[k] == 0 || (g[k] && ldg[k] >= F && ldg[k] % 4 == 0 && (((uintptr_t)g[k]) & 15) == 0),
+                   "dc_tag_grouped_mask_grad: null / misaligned gradient of group %d", k);
+        q.g[k] = g[k], q.ldg[k] = ldg[k], q.row_beg[k] = row_beg[k], q.rows[k] = rows[k];
+    }
+    hipLaunchKernelGGL(k_mask_grad_grouped, dim3((unsigned)((N_total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       q, out_for_mask, ldo, gm, ldgm, N_total, (int)F, rowmax_a, rowmax_b);
+    return check_launch("dc_tag_grouped_mask_grad");
+}
+
+static void grouped_dw_plan(const int64_t *rows, int ngroups, int64_t Fi, int64_t Fo, int nseg, DwGroups *dg) {
+    dg->n = ngroups;
+    int c = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        int64_t cr;
+        int nch;
+        dw_plan(rows[g], Fi, Fo, nseg, &cr, &nch);      // the plan of a separate launch over this group
+        cr = (cr + 31) / 32 * 32;
+        const int64_t padded = (rows[g] + 31) / 32 * 32;
+        nch = (int)((padded + cr - 1) / cr);
+        if (nch < 1) nch = 1;
+        dg->chunk_beg[g] = c, dg->chunk_rows[g] = cr;
+        c += nch;
+    }
+    for (int g = ngroups; g <= kMaxGroups; ++g) dg->chunk_beg[g] = c;
+}
+
+extern "C" int64_t dc_tag_grouped_bwd_dw_workspace_bytes(const int64_t *rows, int ngroups, int64_t Fi, int64_t Fo,
+                                                         int nseg) {
+    if (!rows || ngroups < 1 || ngroups > kMaxGroups || Fi < 1 || Fo < 1 || nseg < 1 || nseg > kMaxSeg) return DC_EINVAL;
+    DwGroups dg{};
+    grouped_dw_plan(rows, ngroups, Fi, Fo, nseg, &dg);
+    return (int64_t)sizeof(float) * dg.chunk_beg[ngroups] * (nseg * Fo * Fi + Fo) + 16;
+}
+
+extern "C" int dc_tag_grouped_bwd_dw_h2(const float *g, int64_t ldg, const float *const *xs, const int64_t *ldxs,
+                                        int nseg, int ngroups, const int64_t *row_beg, const int64_t *rows,
+                                        int64_t N_total, float *const *gws, float *const *gbias, int accumulate,
+                                        void *partials, int64_t partials_bytes, int64_t Fi, int64_t Fo,
+                                        const float *g_rowmax, const float *x_rowmax, dc_stream_t stream) {
+    if (int rc = check_groups("dc_tag_grouped_bwd_dw_h2", ngroups, row_beg, rows, N_total)) return rc;
+    DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && Fi == 256 && Fo >= 128 && Fo % 128 == 0,
+               "dc_tag_grouped_bwd_dw_h2: needs Fi == 256 and Fo %% 128 == 0 (Fi=%lld Fo=%lld)", (long long)Fi,
+               (long long)Fo);
+    DC_REQUIRE(g && xs && ldxs && gws && partials && g_rowmax && x_rowmax && ldg >= Fo && ldg % 4 == 0 &&
+                   (((uintptr_t)g) & 15) == 0 && (((uintptr_t)partials) & 15) == 0,
+               "dc_tag_grouped_bwd_dw_h2: null / misaligned pointer");
+    DC_REQUIRE(partials_bytes >= dc_tag_grouped_bwd_dw_workspace_bytes(rows, ngroups, Fi, Fo, nseg),
+               "dc_tag_grouped_bwd_dw_h2: workspace too small");
+    if (N_total == 0) return DC_OK;
+    DwParams p{};
+    p.g = Mat{g, ldg}, p.mask = p.g, p.has_mask = 0;
+    for (int s = 0; s < nseg; ++s) {
+        DC_REQUIRE(xs[s] && ldxs[s] >= Fi && ldxs[s] % 4 == 0 && (((uintptr_t)xs[s]) & 15) == 0,
+                   "dc_tag_grouped_bwd_dw_h2: bad segment %d", s);
+        p.x[s] = Mat{xs[s], ldxs[s]};
+    }
+    grouped_dw_plan(rows, ngroups, Fi, Fo, nseg, &p.grp);
+    for (int k = 0; k < ngroups; ++k) {
+        p.grp.row_beg[k] = row_beg[k];
+        p.grp.row_end[k] = row_beg[k] + (rows[k] + 31) / 32 * 32;     // zero rows behind the group's data
+    }
+    for (int k = 0; k < ngroups; ++k)
+        DC_REQUIRE(p.grp.row_end[k] <= (k + 1 < ngroups ? row_beg[k + 1] : N_total),
+                   "dc_tag_grouped_bwd_dw_h2: group %d has no room for its zero padding rows", k);
+    p.N = N_total, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg, p.chunk_rows = kGroupAlign;
+    p.nchunks = p.grp.chunk_beg[kMaxGroups];
+    p.h2.a_rowmax = g_rowmax, p.h2.b_rowmax = x_rowmax;
+    p.partial = (float *)partials;
+    bool any_bias = false;
+    for (int k = 0; k < ngroups; ++k) any_bias = any_bias || (gbias && gbias[k]);
+    p.bias_partial = any_bias ? p.partial + (int64_t)p.nchunks * nseg * Fo * Fi : nullptr;
+    hipStream_t hs = (hipStream_t)stream;
+    DC_REQUIRE(dw_h2w_launch(p, hs), "dc_tag_grouped_bwd_dw_h2: shape not eligible for the 128 x 256 tile kernel");
+    ReduceGroups rg{};
+    for (int k = 0; k < ngroups; ++k) {
+        ReduceParams &r = rg.g[k];
+        const int c0 = p.grp.chunk_beg[k];
+        r.partial = p.partial + (int64_t)c0 * nseg * Fo * Fi;
+        r.bias_partial = p.bias_partial ? p.bias_partial + (int64_t)c0 * Fo : nullptr;
+        r.gbias = (gbias && gbias[k]) ? gbias[k] : nullptr;
+        for (int s = 0; s < nseg; ++s) {
+            DC_REQUIRE(gws[k * nseg + s], "dc_tag_grouped_bwd_dw_h2: null output block %d of group %d", s, k);
+            r.gw[s] = gws[k * nseg + s];
+        }
+        r.Fi = Fi, r.Fo = Fo, r.cols = Fi, r.nseg = nseg, r.nchunks = p.grp.chunk_beg[k + 1] - c0;
+        r.ngw = nseg, r.bps = 1, r.accumulate = accumulate;
+    }
+    const int64_t total = (int64_t)nseg * Fo * Fi + (any_bias ? Fo : 0);
+    hipLaunchKernelGGL(k_dw_reduce_grouped, dim3((unsigned)((total + 255) / 256), (unsigned)ngroups), dim3(256), 0,
+                       hs, rg);
+    return check_launch("dc_tag_grouped_bwd_dw_h2");
+}
+
+
+extern "C" int64_t dc_generic_dense_launches(int reset) {
+    return reset ? (int64_t)g_generic_dense_launches.exchange(0) : (int64_t)g_generic_dense_launches.load();
 }

@@ -57,6 +57,12 @@ k_fwd_h2w(FwdParams p) {
     const int lane = threadIdx.x & 63;
     const int k8 = threadIdx.x & 7, r = threadIdx.x >> 3;          // staging: 8 threads per 128-byte row
     const int64_t lda = p.x[0].ld;
+    // grouped launch (block-diagonal union, dc_tag_grouped_fwd_h2p): the tile's group picks weights / bias / scales
+    const float *wimg = p.w[0].p, *bias = p.bias, *brm = p.h2.b_rowmax;
+    if (p.grp.n > 1) {
+        const int g = group_of_row(p.grp.row_beg, p.grp.n, row0);
+        wimg = p.grp.w[g], bias = p.grp.bias[g], brm = p.grp.b_rowmax[g];
+    }
 
     unsigned offA[2], offB[4];
     int ldsAh[2], ldsAl[2], ldsB[4];
@@ -90,7 +96,7 @@ k_fwd_h2w(FwdParams p) {
     const int st_beg = (int)kz * per;
     const int nst = st_beg >= nst_all ? 0 : (nst_all - st_beg < per ? nst_all - st_beg : per);
     const float *baseA = p.x[0].p + row0 * lda + (int64_t)st_beg * kWBK;      // wave-uniform running bases
-    const float *baseB = p.w[0].p + col0 * p.Fi + (int64_t)st_beg * kWBK;
+    const float *baseB = wimg + col0 * p.Fi + (int64_t)st_beg * kWBK;
     hw_f32x4 va0[2], va1[2];                                          // two register sets, named: no runtime index
     hw_u32x4 vb0[4], vb1[4];
 
@@ -233,7 +239,7 @@ k_fwd_h2w(FwdParams p) {
         for (int nb = 0; nb < 2; ++nb) {
             const int64_t col = col0 + wn * 64 + nb * 32 + c;
             const bool cok = FULL || col < p.Fo;
-            const float icol = h2_unscale(p.h2.b_rowmax[cok ? col : p.Fo - 1]);
+            const float icol = h2_unscale(brm[cok ? col : p.Fo - 1]);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -254,8 +260,8 @@ k_fwd_h2w(FwdParams p) {
         const int64_t col = col0 + wn * 64 + nb * 32 + c;
         const bool cok = FULL || col < p.Fo;
         const int64_t colc = cok ? col : p.Fo - 1;
-        const float bcol = p.bias ? p.bias[colc] : 0.f;
-        const float icol = h2_unscale(p.h2.b_rowmax[colc]);
+        const float bcol = bias ? bias[colc] : 0.f;
+        const float icol = h2_unscale(brm[colc]);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -287,7 +293,8 @@ static inline int hw_env_int(const char *name, int dflt) {
 // every CU one (a 128 x 256 tile is a whole CU's work: small N stays with the 64/128 x 128 kernel)
 bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     static const int wide = hw_env_int("DC_H2_WIDE", 1);
-    if (!wide || !p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1) return false;
+    if (!p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1) return false;
+    if (!wide && p.grp.n <= 1) return false;
     const int64_t ks = p.ksplit > 1 ? p.ksplit : 1;
     if (ks > 1 && (!p.kpartial || p.bias || p.relu || p.exp_lse)) return false;
     if (p.Fi % kWBK != 0 || p.Fi < kWBK) return false;
@@ -295,7 +302,7 @@ bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     if (!hw_al16(p.x[0].p) || !hw_al16(p.w[0].p) || p.x[0].ld % 4 != 0) return false;
     const int64_t tiles = ((p.N + kWBM - 1) / kWBM) * ((p.Fo + kWBN - 1) / kWBN);
     static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
-    if (tiles * ks < min_tiles || tiles * ks >= (int64_t)INT32_MAX) return false;
+    if ((tiles * ks < min_tiles && p.grp.n <= 1) || tiles * ks >= (int64_t)INT32_MAX) return false;
     const dim3 gd((unsigned)(tiles * ks)), bd(512);
     if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
         hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);

@@ -573,8 +573,17 @@ k_dw_h2w(DwParams p) {
     const unsigned chunk = lb / per_chunk, rem = lb % per_chunk;
     const int s = (int)(rem / nto);
     const int64_t o0 = (int64_t)(rem % nto) * 128;
-    const int64_t n_beg = (int64_t)chunk * p.chunk_rows;
-    const int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
+    int64_t n_beg = (int64_t)chunk * p.chunk_rows;
+    int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
+    if (p.grp.n >= 1) {                                                  // grouped: the chunk's group owns its rows
+        int g = 0;
+#pragma unroll
+        for (int q = 1; q < kMaxGroups; ++q)
+            if (q < p.grp.n && (int)chunk >= p.grp.chunk_beg[q]) g = q;
+        n_beg = p.grp.row_beg[g] + (int64_t)((int)chunk - p.grp.chunk_beg[g]) * p.grp.chunk_rows[g];
+        n_end = n_beg + p.grp.chunk_rows[g] < p.grp.row_end[g] ? n_beg + p.grp.chunk_rows[g] : p.grp.row_end[g];
+        if (n_end < n_beg) n_end = n_beg;
+    }
     const int wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
     const bool do_bias = p.bias_partial && s == 0;
 
@@ -723,9 +732,9 @@ k_dw_h2w(DwParams p) {
 }
 
 // eligible: fp16x2, pre-masked g, Fo a multiple of 128, every segment 256 wide, node chunks that are whole stages
-static bool dw_h2w_launch(const DwParams &p, hipStream_t hs) {
+bool dw_h2w_launch(const DwParams &p, hipStream_t hs) {
     static const int wide = getenv("DC_DW_WIDE") ? atoi(getenv("DC_DW_WIDE")) : 1;
-    if (!wide || p.has_mask || p.Fo % 128 != 0 || p.Fo < 128 || p.Fi != 256 || p.N % kDwK != 0 ||
+    if ((!wide && p.grp.n < 1) || p.has_mask || p.Fo % 128 != 0 || p.Fo < 128 || p.Fi != 256 || p.N % kDwK != 0 ||
         p.chunk_rows % kDwK != 0)
         return false;
     if (p.g.ld * kDwK >= ((int64_t)1 << 30)) return false;

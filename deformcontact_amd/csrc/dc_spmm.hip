@@ -81,7 +81,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
             const float *__restrict__ w, const float *__restrict__ x, int64_t ldx,
             const float *addend, int64_t ldadd, float *y, int64_t ldy,
-            int64_t N, int F, float *rowmax = nullptr, int rm_mode = 0) {
+            int64_t N, int F, float *rowmax = nullptr, int rm_mode = 0, int src_off = 0) {
+    // src_off: the adjacency is a ROW WINDOW of a larger (merged, block-diagonal) one - `ptr` points at the
+    // window's first row, neighbour ids are ids of the larger node space and x / y / addend / rowmax hold only
+    // the window's rows: neighbour row = other[p] - src_off
     using V = typename Vec<VEC>::T;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     // wave-uniform row: force into an SGPR so bounds / ids / weights use scalar loads
@@ -113,7 +116,7 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
                 }
 #pragma unroll
             for (int j = 0; j < U; ++j)
-                if (j < n) v[j] = *reinterpret_cast<const V *>(x + (int64_t)s[j] * ldx + c);
+                if (j < n) v[j] = *reinterpret_cast<const V *>(x + (int64_t)(s[j] - src_off) * ldx + c);
 #pragma unroll
             for (int j = 0; j < U; ++j)
                 if (j < n) vaxpy(acc, ww[j], v[j]);
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(256)
 k_spmm_sub(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
            const float *__restrict__ w, const float *__restrict__ x, int64_t ldx,
            const float *addend, int64_t ldadd, float *y, int64_t ldy,
-           int64_t N, int F) {
+           int64_t N, int F, int src_off) {
     using V = typename Vec<VEC>::T;
     constexpr int kRows = 256 / L;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -211,7 +214,7 @@ k_spmm_sub(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const bool ok = act && p + j < end;
-                v[j] = ok ? *reinterpret_cast<const V *>(x + (int64_t)s[j] * ldx + c) : vzero(V{});
+                v[j] = ok ? *reinterpret_cast<const V *>(x + (int64_t)(s[j] - src_off) * ldx + c) : vzero(V{});
             }
 #pragma unroll
             for (int j = 0; j < U; ++j)
@@ -224,11 +227,11 @@ k_spmm_sub(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
 template <int VEC, int L, int U>
 static void launch_sub(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
                        int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
-                       int64_t N, int F, hipStream_t stream) {
+                       int64_t N, int F, int src_off, hipStream_t stream) {
     constexpr int kRows = 256 / L;
     const unsigned grid = (unsigned)((N + kRows - 1) / kRows);
     hipLaunchKernelGGL((k_spmm_sub<VEC, L, U>), dim3(grid), dim3(256), 0, stream, ptr, other, w, x,
-                       ldx, addend, ldadd, y, ldy, N, F);
+                       ldx, addend, ldadd, y, ldy, N, F, src_off);
 }
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -514,9 +517,9 @@ static void dispatch_bf16(const int32_t *ptr, const int32_t *other, const float 
 
 using namespace dc;
 
-extern "C" int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w,
-                           const float *x, int64_t ldx, const float *addend, int64_t ldadd,
-                           float *y, int64_t ldy, int64_t N, int64_t F, dc_stream_t stream_) {
+static int spmm_f32_impl(const int32_t *ptr, const int32_t *other, const float *w,
+                         const float *x, int64_t ldx, const float *addend, int64_t ldadd,
+                         float *y, int64_t ldy, int64_t N, int64_t F, int src_off, dc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DC_REQUIRE(N >= 0 && F >= 0, "dc_spmm_f32: negative size N=%lld F=%lld", (long long)N,
                (long long)F);
@@ -535,30 +538,44 @@ extern "C" int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float
         if (v > 32) {
             const unsigned grid = (unsigned)((N + 3) / 4);
             hipLaunchKernelGGL((k_spmm_wave<4, 8>), dim3(grid), dim3(256), 0, stream, ptr, other,
-                               w, x, ldx, addend, ldadd, y, ldy, N, Fi);
+                               w, x, ldx, addend, ldadd, y, ldy, N, Fi, nullptr, 0, src_off);
         } else if (v > 16)
-            launch_sub<4, 32, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
+            launch_sub<4, 32, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
         else if (v > 8)
-            launch_sub<4, 16, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
+            launch_sub<4, 16, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
         else if (v > 4)
-            launch_sub<4, 8, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
+            launch_sub<4, 8, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
         else
-            launch_sub<4, 4, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
+            launch_sub<4, 4, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
     } else {
         if (F > 32) {
             const unsigned grid = (unsigned)((N + 3) / 4);
             hipLaunchKernelGGL((k_spmm_wave<1, 8>), dim3(grid), dim3(256), 0, stream, ptr, other,
-                               w, x, ldx, addend, ldadd, y, ldy, N, Fi);
+                               w, x, ldx, addend, ldadd, y, ldy, N, Fi, nullptr, 0, src_off);
         } else if (F > 16)
-            launch_sub<1, 32, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
+            launch_sub<1, 32, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
         else if (F > 8)
-            launch_sub<1, 16, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
+            launch_sub<1, 16, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
         else
-            launch_sub<1, 8, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, stream);
+            launch_sub<1, 8, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
     }
     return check_launch("dc_spmm_f32");
 }
 
+
+extern "C" int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w,
+                           const float *x, int64_t ldx, const float *addend, int64_t ldadd,
+                           float *y, int64_t ldy, int64_t N, int64_t F, dc_stream_t stream) {
+    return spmm_f32_impl(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, 0, stream);
+}
+
+extern "C" int dc_spmm_f32_window(const int32_t *ptr, const int32_t *other, const float *w,
+                                  const float *x, int64_t ldx, const float *addend, int64_t ldadd,
+                                  float *y, int64_t ldy, int64_t N, int64_t F, int64_t row_offset,
+                                  dc_stream_t stream) {
+    DC_REQUIRE(row_offset >= 0 && row_offset < (int64_t)INT32_MAX, "dc_spmm_f32_window: bad row_offset");
+    return spmm_f32_impl(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, (int)row_offset, stream);
+}
 
 extern "C" int dc_spmm_bf16(const int32_t *ptr, const int32_t *other, const float *w,
                             const uint16_t *x, int64_t ldx, const void *addend, int64_t ldadd,

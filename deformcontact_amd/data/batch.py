@@ -45,6 +45,10 @@ class Data:
         out.__dict__ = {k: (v.clone() if isinstance(v, Tensor) else
                             (list(v) if isinstance(v, list) else v))
                         for k, v in self.__dict__.items()}
+        if isinstance(self.edge_index, Tensor):
+            # provenance of the copy's edge set (tensor it was cloned from + its version): lets train.losses
+            # know, without reading device memory, that a prediction shares the rest batch's edges
+            out.__dict__["_dc_cloned_edges"] = (self.edge_index, self.edge_index._version)
         return out
 
     def to(self, device, non_blocking: bool = False):

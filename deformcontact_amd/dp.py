@@ -85,25 +85,36 @@ class GradBucket:
 
     def note_direct_write(self, stream) -> None:
         """A library kernel on ``stream`` has just accumulated into this bucket."""
+        from .graph import capture_id
         ev = torch.cuda.Event()
         ev.record(stream)
-        self._pending.append((ev, torch.cuda.is_current_stream_capturing()))
+        self._pending.append((ev, capture_id(self.flat.device)))
+        if len(self._pending) > 256:
+            # repeated backward passes without a consumer (gradient accumulation): keep the list short -
+            # eager events that have completed order nothing any more
+            self._pending = [(e, c) for e, c in self._pending if c != 0 or not e.query()]
 
     def wait_direct_writes(self) -> None:
-        """Order every reported direct write before later work on the current stream.  Events
-        recorded under a stream capture that has ended are dropped: ending the capture already
-        required their streams to be joined."""
+        """Order every reported direct write before later work on the current stream.  An event
+        recorded under the capture the current stream is part of (or eagerly, seen eagerly) becomes a
+        stream dependency; an event recorded under a capture that has ENDED is dropped (ending the
+        capture required its streams to be joined); an EAGER event seen while capturing cannot become
+        a graph dependency - the host waits for it instead, so the captured work starts behind it."""
         if not self._pending:
             return
+        from .graph import capture_id
         pending, self._pending = self._pending, []
-        capturing = torch.cuda.is_current_stream_capturing()
+        cid = capture_id(self.flat.device)
         cur = torch.cuda.current_stream(self.flat.device)
-        for ev, cap in pending:
-            if cap == capturing:
+        for ev, ecid in pending:
+            if ecid == cid:
                 cur.wait_event(ev)
+            elif ecid == 0:
+                ev.synchronize()
 
     def zero(self) -> None:
         """Zero all gradients in one memset and re-attach the views if something replaced them."""
+        self.wait_direct_writes()               # the memset must not overtake a direct write still in flight
         self.flat.zero_()
         for p, v in zip(self.params, self._views):
             if p.grad is not v:

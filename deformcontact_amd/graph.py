@@ -57,22 +57,61 @@ class SortedAdjacency:
     other: torch.Tensor             # int32 [cap]
     perm: torch.Tensor              # int32 [cap]
     w: Optional[torch.Tensor]       # fp32  [cap] or None
+    #: > 0: a ROW WINDOW of a merged adjacency (``GraphIndex.from_parts``): ``ptr`` is a slice of the merged
+    #: ``ptr`` and ``other`` holds ids of the merged node space - the feature matrices the hop sees hold only
+    #: the window's rows, neighbour row = ``other[p] - row_offset`` (``dc_spmm_f32_window``)
+    row_offset: int = 0
+
+
+#: every group of a merged node space starts at a multiple of this many rows (``DC_GROUP_ALIGN`` in
+#: include/deformcontact.h: no 128 / 256-row tile and no dW node chunk straddles two groups)
+GROUP_ALIGN = 256
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
 
 
 class GraphIndex:
     """CSR (by destination) + transposed (by source) views of one edge set."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = False,
-                 normalize: bool = True, validate: bool = False):
-        _require_cuda(edge_index, "edge_index")
-        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
-            raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
-        self.edge_index = edge_index.contiguous()
+    def __init__(self, edge_index: Optional[torch.Tensor], num_nodes: int, *, self_loops: bool = False,
+                 normalize: bool = True, validate: bool = False, parts=None):
+        #: merged (block-diagonal) adjacency: ``[(edge_index, num_nodes), ...]``; see ``from_parts``
+        self.parts = None
+        if parts is not None:
+            if not 1 <= len(parts) <= 4:
+                raise ValueError("GraphIndex.from_parts: 1..4 parts (DC_MAX_PARTS)")
+            eis = []
+            for ei, n in parts:
+                _require_cuda(ei, "edge_index")
+                if ei.dtype != torch.int64 or ei.dim() != 2 or ei.size(0) != 2:
+                    raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
+                eis.append(ei.contiguous())
+            self.parts = [(ei, int(n)) for ei, (_, n) in zip(eis, parts)]
+            self.rows = [n for _, n in self.parts]
+            self.row_beg, beg = [], 0
+            for n in self.rows:
+                self.row_beg.append(beg)
+                beg += _round_up(n, GROUP_ALIGN)
+            self.edge_beg = [0]
+            for ei, _ in self.parts:
+                self.edge_beg.append(self.edge_beg[-1] + int(ei.size(1)))
+            num_nodes = beg                                  # padded total (multiple of GROUP_ALIGN)
+            edge_index = None
+            self.edge_index = None
+            self.num_input_edges = self.edge_beg[-1]
+            self.device = eis[0].device
+        else:
+            _require_cuda(edge_index, "edge_index")
+            if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+                raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
+            self.edge_index = edge_index.contiguous()
+            self.num_input_edges = int(edge_index.size(1))
+            self.device = edge_index.device
         self.num_nodes = int(num_nodes)
-        self.num_input_edges = int(edge_index.size(1))
         self.self_loops = bool(self_loops)
         self.normalize = bool(normalize)
-        self.device = edge_index.device
         #: set by callers that guarantee the topology is constant for the life of a captured graph
         #: (bench.py's cached-topology mode): lets ``graph_index`` reuse this entry under capture
         self._static_ok = False
@@ -95,27 +134,63 @@ class GraphIndex:
         self._bwd_to_fwd = None
         self._num_edges = None if self_loops else self.num_input_edges
         self.rebuild()
-        if validate or VALIDATE:
+        if validate:
             self.validate()
+        elif VALIDATE:
+            if self._capture_id != 0:
+                # built under hipGraph capture: the build has not RUN and a host read-back would invalidate
+                # the capture - the status word is checked by the first validate_pending() after a replay
+                _PENDING_VALIDATION.append(self)
+            else:
+                self.validate()
 
     def rebuild(self) -> None:
         """(Re)run the build pipeline (``dc_graph_build``: both sides, 5-7 launches, no host sync)
         on the current stream into this object's buffers - e.g. after the ``edge_index`` buffer
         has been refilled with a new batch of the same shape.  Legal under hipGraph capture."""
         f, t = self.fwd, self.bwd
-        rc = _lib.lib().dc_graph_build(
-            self.edge_index.data_ptr(), self.num_input_edges, self.num_nodes, int(self.self_loops),
-            f.ptr.data_ptr(), f.other.data_ptr(), f.perm.data_ptr(),
-            f.w.data_ptr() if f.w is not None else None,
-            t.ptr.data_ptr(), t.other.data_ptr(), t.perm.data_ptr(),
-            t.w.data_ptr() if t.w is not None else None,
-            self._status.data_ptr(), self._workspace.data_ptr(), self._workspace.numel(),
-            current_stream_ptr(self.device))
-        _lib.check(rc, "dc_graph_build")
+        out = (f.ptr.data_ptr(), f.other.data_ptr(), f.perm.data_ptr(),
+               f.w.data_ptr() if f.w is not None else None,
+               t.ptr.data_ptr(), t.other.data_ptr(), t.perm.data_ptr(),
+               t.w.data_ptr() if t.w is not None else None,
+               self._status.data_ptr(), self._workspace.data_ptr(), self._workspace.numel(),
+               current_stream_ptr(self.device))
+        if self.parts is not None:
+            import ctypes
+            k = len(self.parts)
+            rc = _lib.lib().dc_graph_build_parts(
+                (ctypes.c_void_p * k)(*[ei.data_ptr() for ei, _ in self.parts]),
+                (ctypes.c_int64 * k)(*[int(ei.size(1)) for ei, _ in self.parts]),
+                (ctypes.c_int64 * k)(*self.row_beg), (ctypes.c_int64 * k)(*self.rows), k,
+                self.num_nodes, int(self.self_loops), *out)
+            _lib.check(rc, "dc_graph_build_parts")
+        else:
+            rc = _lib.lib().dc_graph_build(
+                self.edge_index.data_ptr(), self.num_input_edges, self.num_nodes, int(self.self_loops), *out)
+            _lib.check(rc, "dc_graph_build")
         self._pos_fwd = self._bwd_to_fwd = None
         self._segments = False
         if self.self_loops:
             self._num_edges = None
+
+    @classmethod
+    def from_parts(cls, parts, *, self_loops: bool = False, normalize: bool = True) -> "GraphIndex":
+        """ONE sorted adjacency over the block-diagonal union of several graphs - ``parts`` =
+        ``[(edge_index, num_nodes), ...]`` (e.g. the soft and the rigid graph of a batch,
+        ``train.py:36-38``) - built by ``dc_graph_build_parts`` without materialising the merged
+        ``edge_index``.  Part ``g`` owns rows ``[row_beg[g], row_beg[g] + rows[g])`` of the merged node
+        space; every part starts at a multiple of ``GROUP_ALIGN`` rows, the rows in between are
+        isolated padding nodes and ``num_nodes`` is the padded total.  Rows of a part come out exactly
+        as its own ``GraphIndex`` would hold them (same stable order, same ``gcn_norm`` weights), so a
+        hop over the merged adjacency is bit-identical, row by row, to the per-part hops - in one
+        launch.  ``window(g)`` is the per-part view for code that still works part by part."""
+        return cls(None, 0, self_loops=self_loops, normalize=normalize, parts=parts)
+
+    def window(self, g: int) -> "GraphWindow":
+        """Part ``g`` of a merged adjacency as a graph of its own (shares the merged arrays)."""
+        if self.parts is None:
+            raise ValueError("window(): not a merged adjacency")
+        return GraphWindow(self, g)
 
     # capacity of the per-edge arrays (upper bound on E' when loops are appended)
     @property
@@ -160,7 +235,7 @@ class GraphIndex:
         cap_n, cap_e = L.dc_multihop_max_segment_nodes(), L.dc_multihop_max_segment_edges()
         n, ei = self.num_nodes, self.edge_index
         self._segments = None
-        if n == 0:
+        if n == 0 or ei is None:
             return None
         idx = torch.arange(n, device=self.device)
         hi, lo = idx.clone(), idx.clone()
@@ -212,10 +287,77 @@ class GraphIndex:
         return self._bwd_to_fwd
 
 
+#: DC_VALIDATE=1 graphs built under capture, waiting for their first replay (``validate_pending``)
+_PENDING_VALIDATION: list = []
+
+
+def validate_pending() -> None:
+    """DC_VALIDATE=1: check (one device sync) the status words of the adjacencies that were built inside a
+    hipGraph capture - call it after the graph's first replay (``train.GraphedTrainStep`` does)."""
+    while _PENDING_VALIDATION:
+        _PENDING_VALIDATION.pop().validate()
+
+
+class GraphWindow:
+    """Part ``g`` of a merged ``GraphIndex`` seen as a graph of its own: ``fwd`` / ``bwd`` share the
+    merged arrays (``ptr`` sliced to the part's rows, ``row_offset`` = the part's first row), so hops
+    over the part's OWN feature matrix need no second adjacency.  Part 0 (offset 0) is a valid
+    stand-alone adjacency in every respect - its rows, ids and edge order equal those of its own
+    ``GraphIndex`` - which is what the fused loss (``ops.contact_losses``) relies on for the soft graph."""
+
+    def __init__(self, merged: GraphIndex, g: int):
+        ei, n = merged.parts[g]
+        self.merged, self.part = merged, g
+        self.edge_index, self.num_nodes, self.num_input_edges = ei, n, int(ei.size(1))
+        self.self_loops, self.normalize, self.device = merged.self_loops, merged.normalize, merged.device
+        r0 = merged.row_beg[g]
+        self.row_offset = r0
+
+        def side(a):
+            return SortedAdjacency(a.ptr[r0:r0 + n + 1], a.other, a.perm, a.w, row_offset=r0)
+        self.fwd, self.bwd = side(merged.fwd), side(merged.bwd)
+        self._static_ok = False
+        self._capture_id = merged._capture_id
+        self._status = merged._status
+
+    @property
+    def _static_ok(self):
+        return self.merged._static_ok or self.__dict__.get("_static", False)
+
+    @_static_ok.setter
+    def _static_ok(self, v):
+        self.__dict__["_static"] = bool(v)
+        if v:
+            self.merged._static_ok = True
+
+    @property
+    def capacity(self) -> int:
+        return self.merged.capacity
+
+    def segments(self):
+        return None
+
+    def validate(self) -> None:
+        self.merged.validate()
+
+    def rebuild(self) -> None:
+        self.merged.rebuild()
+
+    def tensors(self):
+        out = self.merged.tensors()
+        for entry in getattr(self, "_hop_cache", {}).values():
+            out += [t for t in entry[:2] if t is not None]
+        return out
+
+    def record_stream(self, stream) -> None:
+        for t in self.tensors():
+            t.record_stream(stream)
+
+
 # --------------------------------------------------------------------------- #
 # cache: one GraphIndex per (edge_index storage, version, shape, N, flags)
 # --------------------------------------------------------------------------- #
-_CACHE: "OrderedDict[tuple, GraphIndex]" = OrderedDict()
+_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()      # key -> (GraphIndex | GraphWindow, source tensors)
 _CACHE_MAX = 32
 
 
@@ -238,16 +380,50 @@ def graph_index(edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = 
     ``GraphIndex._static_ok`` on an eagerly built entry to keep the build out of the capture.
     """
     key = _key(edge_index, num_nodes, self_loops, normalize)
-    g = _CACHE.get(key)
-    cid = capture_id(edge_index.device) if edge_index.is_cuda else 0
-    if g is not None and (g._capture_id == cid or (cid != 0 and g._static_ok)):
-        _CACHE.move_to_end(key)
+    g = _cache_get(key, edge_index.device if edge_index.is_cuda else None)
+    if g is not None:
         return g
     g = GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize)
-    g._src_ref = edge_index          # keeps the storage (and its address) alive
-    _CACHE[key] = g
+    _cache_put(key, g, (edge_index,))
+    return g
+
+
+def _cache_get(key, device):
+    hit = _CACHE.get(key)
+    if hit is None:
+        return None
+    g = hit[0]
+    cid = capture_id(device) if device is not None else 0
+    if g._capture_id == cid or (cid != 0 and g._static_ok):
+        _CACHE.move_to_end(key)
+        return g
+    return None
+
+
+def _cache_put(key, g, sources) -> None:
+    # the entry holds the tensors whose addresses are part of its key: an address cannot be recycled
+    # (and matched by a different tensor) while the key is cached - also for aliases added by register()
+    _CACHE[key] = (g, tuple(sources))
+    _CACHE.move_to_end(key)
     while len(_CACHE) > _CACHE_MAX:
         _CACHE.popitem(last=False)
+
+
+def merged_graph_index(parts, *, self_loops: bool = False, normalize: bool = True) -> "GraphIndex":
+    """``GraphIndex.from_parts(parts)``, cached like ``graph_index`` (on every part's address + version +
+    shape and the capture that built it).  Also makes ``window(g)`` the cached adjacency of part ``g``'s
+    ``edge_index``, so per-part code (``conv(x, edge_index)`` of a first layer, the loss) finds it
+    instead of building a second adjacency."""
+    key = ("merged",) + tuple(_key(ei, n, self_loops, normalize) for ei, n in parts)
+    dev = parts[0][0].device if parts[0][0].is_cuda else None
+    g = _cache_get(key, dev)
+    if g is not None:
+        return g
+    g = GraphIndex.from_parts(parts, self_loops=self_loops, normalize=normalize)
+    _cache_put(key, g, [ei for ei, _ in parts])
+    for i, (ei, n) in enumerate(parts):
+        w = g.window(i)
+        _cache_put(_key(ei, n, self_loops, normalize), w, (ei,))
     return g
 
 
@@ -311,12 +487,10 @@ class NodeOrder:
 
 def register(edge_index: torch.Tensor, g: GraphIndex) -> None:
     """Make ``g`` (built elsewhere, e.g. by ``loaders.TopologyCache`` on the loader's stream) the
-    cached adjacency of ``edge_index``."""
-    g._src_ref = edge_index
+    cached adjacency of ``edge_index``.  Every alias keeps its own ``edge_index`` alive for as long as
+    its key is cached (one ``g`` may be registered for many tensors)."""
     g._capture_id = 0
-    _CACHE[_key(edge_index, g.num_nodes, g.self_loops, g.normalize)] = g
-    while len(_CACHE) > _CACHE_MAX:
-        _CACHE.popitem(last=False)
+    _cache_put(_key(edge_index, g.num_nodes, g.self_loops, g.normalize), g, (edge_index,))
 
 
 def clear_cache() -> None:

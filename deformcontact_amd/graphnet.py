@@ -75,9 +75,87 @@ class ContactEncoder(nn.Module):
             cls._side_streams[key] = torch.cuda.Stream(device=device)
         return cls._side_streams[key]
 
+    #: run both branches as ONE block-diagonal problem: one sorted adjacency over the
+    #: merged node space (``graph.merged_graph_index``), every layer after the first as single launches for
+    #: both branches (``ops.tag_conv_grouped``: merged hops, grouped dense blocks - same rows, same
+    #: arithmetic, bit-identical outputs and gradients), the narrow first layers per branch over row windows
+    #: of the merged adjacency, writing into the merged slab.  Applies to TAGConv encoders whose later
+    #: layers are 256 wide (the shipped config); ``DC_MERGE_BRANCHES=0`` keeps one launch per branch.
+    merge_branches = os.environ.get("DC_MERGE_BRANCHES", "1") != "0"
+
+    def _mergeable(self, x_s, x_r) -> bool:
+        if not (self.merge_branches and x_s.is_cuda and x_r.is_cuda and x_s.dtype == torch.float32
+                and x_r.dtype == torch.float32 and x_s.size(0) > 0 and x_r.size(0) > 0):
+            return False
+        if self.dropout_rate > 0.0 and self.training:
+            return False
+        ls, lr = self.conv_layers_resting, self.conv_layers_rigid
+        if len(ls) < 2 or len(ls) != len(lr):
+            return False
+        flags = None
+        for i, (a, b) in enumerate(zip(ls, lr)):
+            if type(a) is not dc_nn.TAGConv or type(b) is not dc_nn.TAGConv:
+                return False
+            for c in (a, b):
+                if flags is None:
+                    flags = c.graph_flags()
+                if c.graph_flags() != flags:
+                    return False
+            if i == 0:
+                # row windows of the merged adjacency carry no row maxima: narrow first layers only
+                if ops._tag_uses_h2(a.in_channels, a.K) or ops._tag_uses_h2(b.in_channels, b.K):
+                    return False
+            elif not ((a.in_channels, a.out_channels, a.K) == (b.in_channels, b.out_channels, b.K)
+                      and (a.bias is None) == (b.bias is None)
+                      and ops.grouped_eligible(a.in_channels, a.out_channels, a.K)):
+                return False
+        return ls[0].out_channels == ls[1].in_channels and lr[0].out_channels == lr[1].in_channels
+
+    def topology(self, graph_resting, graph_rigid):
+        """The sorted adjacency object(s) ``encode`` will use for these batches (built if needed): the
+        merged one, or one per branch.  For callers that prepare the topology ahead of the step or
+        mark it constant (``_static_ok``) for a captured graph."""
+        x_s, e_s, x_r, e_r = graph_resting.x, graph_resting.edge_index, graph_rigid.x, graph_rigid.edge_index
+        if self._mergeable(x_s, x_r):
+            from .graph import merged_graph_index
+            return [merged_graph_index([(e_s, x_s.size(0)), (e_r, x_r.size(0))],
+                                       **self.conv_layers_resting[0].graph_flags())]
+        return [c.graph(e, x.size(0)) for c, e, x in ((self.conv_layers_resting[0], e_s, x_s),
+                                                      (self.conv_layers_rigid[0], e_r, x_r))
+                if hasattr(c, "graph")]
+
+    def _encode_merged(self, x_s, e_s, x_r, e_r):
+        from .graph import merged_graph_index
+        ls, lr = self.conv_layers_resting, self.conv_layers_rigid
+        mg = merged_graph_index([(e_s, x_s.size(0)), (e_r, x_r.size(0))], **ls[0].graph_flags())
+        slab = ops.alloc_merged_slab(mg, ls[1].in_channels, ls[1].K, x_s.device)
+        fi = ls[1].in_channels
+        into_s, into_r = ops.merged_slab_part(slab, mg, 0, fi), ops.merged_slab_part(slab, mg, 1, fi)
+        if self.overlap_branches:
+            # the two narrow first layers side by side (each has its own small launches)
+            main = torch.cuda.current_stream(x_s.device)
+            side = self._side_stream(x_s.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                h_r = lr[0](x_r, e_r, relu=True, out_into=into_r)
+            h_s = ls[0](x_s, e_s, relu=True, out_into=into_s)
+            main.wait_stream(side)
+            h_r.record_stream(main)
+        else:
+            h_s = ls[0](x_s, e_s, relu=True, out_into=into_s)
+            h_r = lr[0](x_r, e_r, relu=True, out_into=into_r)
+        xs = (h_s, h_r)
+        for i in range(1, len(ls)):
+            nk = ls[i + 1].K if i + 1 < len(ls) else None
+            xs = ops.tag_conv_grouped(mg, xs, [[lin.weight for lin in c.lins] for c in (ls[i], lr[i])],
+                                      [ls[i].bias, lr[i].bias], relu=True, next_k=nk)
+        return xs[0], xs[1]
+
     def encode(self, graph_resting, graph_rigid) -> Tuple[torch.Tensor, torch.Tensor]:
         x_s, e_s = graph_resting.x, graph_resting.edge_index
         x_r, e_r = graph_rigid.x, graph_rigid.edge_index
+        if self._mergeable(x_s, x_r):
+            return self._encode_merged(x_s, e_s, x_r, e_r)
         if not (self.overlap_branches and x_s.is_cuda and x_r.is_cuda):
             return (self._branch(self.conv_layers_resting, x_s, e_s),
                     self._branch(self.conv_layers_rigid, x_r, e_r))

@@ -92,11 +92,12 @@ class TAGConv(nn.Module):
         return ops.tag_slab_geometry(self.in_channels, self.K)[2]
 
     def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False,
-                next_conv: "Optional[TAGConv]" = None) -> Tensor:
+                next_conv: "Optional[TAGConv]" = None, out_into: Optional[Tensor] = None) -> Tensor:
         """``conv(x, edge_index)`` as PyG.  Extensions: ``relu=True`` fuses the ReLU the reference
         applies right after (``models/model.py:71,77``) into the MFMA epilogue; ``next_conv`` (the
         TAGConv that consumes this output) lets the output be written straight into that
-        layer's hop slab."""
+        layer's hop slab; ``out_into`` (a ``[N, out]`` row-major view the caller owns, e.g. this
+        branch's rows of a merged slab - ``ops.merged_slab_part``) receives the output instead."""
         if x.dtype == torch.bfloat16:
             # bf16-STORED features (BASELINE.json configs[4]): bf16 hops with fp32 accumulation + the
             # bf16 MFMA dense block; forward only.  ``out_dtype`` of the last layer: self.bf16_out
@@ -112,7 +113,9 @@ class TAGConv(nn.Module):
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
         nxt = None
-        if isinstance(next_conv, TAGConv) and next_conv.in_channels == self.out_channels:
+        if out_into is not None:
+            nxt = ops.OutInto(out_into)
+        elif isinstance(next_conv, TAGConv) and next_conv.in_channels == self.out_channels:
             nxt = ops.tag_slab_geometry(next_conv.in_channels, next_conv.K)[1:]
         return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu,
                             next_geom=nxt)

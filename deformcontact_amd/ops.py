@@ -50,6 +50,16 @@ def hop(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = Non
             raise ValueError("hop: addend shape mismatch")
         lda = _rowmajor(addend, "addend")
     w = adj.w if weighted else None
+    if adj.row_offset:
+        # a row window of a merged adjacency: x / out / addend hold only the window's rows
+        if rowmax is not None:
+            raise NotImplementedError("hop: row maxima over a window of a merged adjacency")
+        rc = _lib.lib().dc_spmm_f32_window(
+            adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+            x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,
+            out.data_ptr(), ldy, n, f, int(adj.row_offset), current_stream_ptr(x.device))
+        _lib.check(rc, "dc_spmm_f32_window")
+        return out
     if rowmax is not None:
         if rowmax.dtype != torch.float32 or rowmax.numel() != n or not rowmax.is_contiguous():
             raise ValueError("hop: rowmax must be a contiguous float32 [N] tensor")
@@ -426,7 +436,13 @@ class _TagConvFn(torch.autograd.Function):
         else:
             ws = [w.contiguous() for w in weights]
             xs, ldxs, fi_eff = blocks, [slab.stride(0)] * (k + 1), fi
-        if next_geom is not None:
+        if isinstance(next_geom, OutInto):
+            # the output goes into rows of a buffer the caller owns (a part's rows of block 0 of a MERGED
+            # hop slab: both encoder branches feed one grouped layer)
+            out = next_geom.view
+            if out.shape != (n, fo) or out.stride(1) != 1 or out.dtype != torch.float32 or out.device != dev:
+                raise ValueError("tag_conv: out_into view has the wrong shape / layout")
+        elif next_geom is not None:
             # the output IS column block 0 of the next TAGConv layer's hop slab (no copy there)
             next_width, next_wpad = next_geom
             nxt = _alloc_slab(n, next_wpad, dev, tag=(n, fo, next_wpad))   # recognised by _as_slab_block0
@@ -578,6 +594,233 @@ class _TagConvFn(torch.autograd.Function):
             chained_hops(g, gslab, fi, k, backward=True)  # g_{j-1} = G_{j-1} + A^T g_j
             gx = gblocks[0]
         return (None, gx, gb, None, None, *gws)
+
+
+class OutInto:
+    """Destination of a layer's output chosen by the caller (``tag_conv(..., next_geom=OutInto(view))``):
+    a ``[N, Fo]`` row-major view, e.g. one part's rows of block 0 of a merged hop slab.  A plain object, so
+    autograd does not see the buffer as an input of the layer."""
+
+    def __init__(self, view: torch.Tensor):
+        self.view = view
+
+
+# --------------------------------------------------------------------------- #
+# grouped TAGConv layer: both encoder branches as ONE block-diagonal launch
+# --------------------------------------------------------------------------- #
+_MERGED_TAG = "_dc_merged_slab"
+
+
+def alloc_merged_slab(mg: GraphIndex, fi: int, k: int, dev) -> torch.Tensor:
+    """``[N_total, (K+1)*fi]`` hop slab over the merged node space of ``mg`` (``GraphIndex.from_parts``)
+    for a grouped TAGConv layer, tagged so that ``tag_conv_grouped`` recognises the parts' block-0 views
+    (``merged_slab_part``).  The padding rows of block 0 are zeroed here (their other blocks are written
+    - as zeros - by the hops: padding nodes are isolated)."""
+    concat, width, wpad = tag_slab_geometry(fi, k)
+    if concat:
+        raise ValueError("alloc_merged_slab: wide layers only (Fi a multiple of 16, (K+1)*Fi > 128)")
+    n = mg.num_nodes
+    slab = _alloc_slab(n, wpad, dev, tag=("merged", n, fi, wpad, tuple(mg.row_beg), tuple(mg.rows)))
+    base = slab._base if slab._base is not None else slab
+    setattr(base, _SLAB_TAG, ("merged", n, fi, wpad, tuple(mg.row_beg), tuple(mg.rows)))
+    ends = list(mg.row_beg[1:]) + [n]
+    for r0, rows, r1 in zip(mg.row_beg, mg.rows, ends):
+        if r0 + rows < r1:
+            slab[r0 + rows:r1, :fi].zero_()
+    return slab
+
+
+def merged_slab_part(slab: torch.Tensor, mg: GraphIndex, g: int, fi: int) -> torch.Tensor:
+    """Rows of part ``g`` in column block 0 of a merged slab: where that part's previous layer writes."""
+    r0 = mg.row_beg[g]
+    return slab[r0:r0 + mg.rows[g], :fi]
+
+
+def _as_merged_slab(xs, mg: GraphIndex, fi: int, wpad: int):
+    """The merged slab whose block 0 the tensors ``xs`` (one per part) are the part views of, or None."""
+    base = xs[0]._base
+    tag = ("merged", mg.num_nodes, fi, wpad, tuple(mg.row_beg), tuple(mg.rows))
+    if base is None or getattr(base, _SLAB_TAG, None) != tag or base.dim() != 2 or not base.is_contiguous():
+        return None
+    ld = base.size(1)
+    for g, x in enumerate(xs):
+        if (x._base is not base or x.shape != (mg.rows[g], fi) or x.stride() != (ld, 1)
+                or x.data_ptr() != base.data_ptr() + 4 * ld * mg.row_beg[g]):
+            return None
+    return base[:, :wpad] if ld > wpad else base
+
+
+def grouped_eligible(fi: int, fo: int, k: int) -> bool:
+    """Can ``tag_conv_grouped`` run a layer of these widths (the grouped kernels' shape limits)?"""
+    return (_tag_uses_h2(fi, k) and fi == 256 and fo % 128 == 0 and fo % 16 == 0
+            and ((k + 1) * fi) % 32 == 0 and ((k + 1) * fo) % 32 == 0)
+
+
+def _vp_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+class _TagConvGroupedFn(torch.autograd.Function):
+    """The same TAGConv layer (+ fused ReLU) of SEVERAL branches - same widths, each branch its own
+    weights - over the merged node space of ``mg``: K hops over the merged adjacency (one launch each for
+    all branches), ONE grouped forward block, and in backward one grouped mask kernel, K transposed merged
+    hops, one grouped forward-shaped dX block, one grouped dW block + slab reduce
+    (``dc_tag_grouped_*``).  Replaces the second ``conv(x, edge_index)`` call of both encoder loops of
+    ``models/model.py:69-78``.  Row by row the arithmetic is that of ``_TagConvFn`` on each branch alone:
+    outputs and gradients are bit-identical to it.
+
+    ``apply(mg, relu, next_geom, ngroups, x_0..x_{G-1}, bias_0, W_0,0..W_0,K, bias_1, W_1,0.., ...)``
+    returns one output per group (views of one merged buffer)."""
+
+    @staticmethod
+    def forward(ctx, mg: GraphIndex, relu: bool, next_geom, ngroups: int, *args):
+        xs = args[:ngroups]
+        per = (len(args) - ngroups) // ngroups
+        k = per - 2
+        biases = [args[ngroups + g * per] for g in range(ngroups)]
+        weights = [list(args[ngroups + g * per + 1: ngroups + (g + 1) * per]) for g in range(ngroups)]
+        fo, fi = weights[0][0].shape
+        dev = xs[0].device
+        n = mg.num_nodes
+        concat, width, wpad = tag_slab_geometry(fi, k)
+        if not _tag_uses_h2(fi, k) or width % 32 != 0 or any(b is None for b in biases) != all(b is None for b in biases):
+            raise NotImplementedError("tag_conv_grouped: wide fp16x2 layers only, bias on all groups or none")
+        L = _lib.lib()
+        st = current_stream_ptr(dev)
+        slab = _as_merged_slab(xs, mg, fi, wpad)
+        if slab is None:
+            slab = alloc_merged_slab(mg, fi, k, dev)
+            for g, x in enumerate(xs):
+                merged_slab_part(slab, mg, g, fi).copy_(x)
+        rowmax = torch.empty(n, dtype=torch.float32, device=dev)
+        chained_hops(mg, slab, fi, k, backward=False, rowmax=rowmax)
+        # weights of all groups: scaled fp16x2 images (+ transposed images for dX) in one launch
+        need_x = any(ctx.needs_input_grad[4:4 + ngroups])
+        wmax = torch.empty((ngroups, fo), dtype=torch.float32, device=dev)
+        wimg = torch.empty((ngroups, fo, width), dtype=torch.float32, device=dev)
+        wt = wt_rowmax = None
+        if need_x and fo % 16 == 0:
+            wt = torch.empty((ngroups, fi, (k + 1) * fo), dtype=torch.float32, device=dev)
+            wt_rowmax = torch.empty((ngroups, fi), dtype=torch.float32, device=dev)
+        wcs = [[w.contiguous() for w in ws] for ws in weights]
+        _lib.check(L.dc_tag_grouped_weight_prep(
+            _vp_array([w.data_ptr() for ws in wcs for w in ws]), ngroups, k + 1, fo, fi,
+            _vp_array([wmax[g].data_ptr() for g in range(ngroups)]),
+            _vp_array([wimg[g].data_ptr() for g in range(ngroups)]),
+            _vp_array([wt[g].data_ptr() for g in range(ngroups)]) if wt is not None else None,
+            _vp_array([wt_rowmax[g].data_ptr() for g in range(ngroups)]) if wt is not None else None, st),
+            "dc_tag_grouped_weight_prep")
+        if isinstance(next_geom, tuple):
+            nxt = alloc_merged_slab(mg, fo, next_geom[0], dev)      # next grouped layer's slab: (K_next,)
+            out = nxt[:, :fo]
+        else:
+            out = torch.empty((n, fo), dtype=torch.float32, device=dev)
+        bcs = [b.contiguous() if b is not None else None for b in biases]
+        row_beg, rows = _i64_array(mg.row_beg), _i64_array(mg.rows)
+        _lib.check(L.dc_tag_grouped_fwd_h2p(
+            slab.data_ptr(), slab.stride(0), ngroups, row_beg, rows, n,
+            _vp_array([wimg[g].data_ptr() for g in range(ngroups)]),
+            _vp_array([b.data_ptr() if b is not None else None for b in bcs]), int(relu),
+            out.data_ptr(), out.stride(0), width, fo, rowmax.data_ptr(),
+            _vp_array([wmax[g].data_ptr() for g in range(ngroups)]), st), "dc_tag_grouped_fwd_h2p")
+        ctx.mg, ctx.k, ctx.fi, ctx.fo, ctx.relu, ctx.ngroups = mg, k, fi, fo, relu, ngroups
+        ctx.params, ctx.bias_params = weights, biases
+        ctx.save_for_backward(slab, out if relu else None, rowmax, wt, wt_rowmax)
+        outs = tuple(out[r0:r0 + r] for r0, r in zip(mg.row_beg, mg.rows))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        slab, out, xrowmax, wt, wt_rowmax = ctx.saved_tensors
+        mg, k, fi, fo, ngroups = ctx.mg, ctx.k, ctx.fi, ctx.fo, ctx.ngroups
+        L = _lib.lib()
+        dev = slab.device
+        st = current_stream_ptr(dev)
+        n = mg.num_nodes
+        per = k + 2
+        need_x = any(ctx.needs_input_grad[4:4 + ngroups])
+        need_p = any(ctx.needs_input_grad[4 + ngroups:])
+        gs = []
+        for g, go in enumerate(gouts):
+            if go is None:
+                go = torch.zeros((mg.rows[g], fo), dtype=torch.float32, device=dev)
+            if go.stride(1) != 1 or go.stride(0) % 4 != 0 or go.data_ptr() % 16 != 0:
+                go = go.contiguous()
+            gs.append(go)
+        row_beg, rows = _i64_array(mg.row_beg), _i64_array(mg.rows)
+        gwid = (k + 1) * fo
+        gslab = _alloc_slab(n, gwid, dev)
+        g_rowmax = torch.empty(n, dtype=torch.float32, device=dev)
+        hop_rowmax = torch.empty(n, dtype=torch.float32, device=dev) if need_x else None
+        _lib.check(L.dc_tag_grouped_mask_grad(
+            _vp_array([t.data_ptr() for t in gs]), _i64_array([t.stride(0) for t in gs]), ngroups, row_beg, rows, n,
+            out.data_ptr() if out is not None else None, out.stride(0) if out is not None else fo,
+            gslab.data_ptr(), gslab.stride(0), fo, g_rowmax.data_ptr(),
+            hop_rowmax.data_ptr() if need_x else None, st), "dc_tag_grouped_mask_grad")
+        gxs = [None] * ngroups
+        if need_x:
+            if wt is None:
+                raise RuntimeError("tag_conv_grouped: input gradient requested but the forward ran without it")
+            chained_hops(mg, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
+                         rowmax_has_block0=True)
+            gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
+            _lib.check(L.dc_tag_grouped_fwd_h2p(
+                gslab.data_ptr(), gslab.stride(0), ngroups, row_beg, rows, n,
+                _vp_array([wt[g].data_ptr() for g in range(ngroups)]), None, 0, gx.data_ptr(), fi, gwid, fi,
+                hop_rowmax.data_ptr(), _vp_array([wt_rowmax[g].data_ptr() for g in range(ngroups)]), st),
+                "dc_tag_grouped_fwd_h2p (dX)")
+            gxs = [gx[r0:r0 + r] if ctx.needs_input_grad[4 + g] else None
+                   for g, (r0, r) in enumerate(zip(mg.row_beg, mg.rows))]
+        pgrads = [None] * (ngroups * per)
+        if need_p:
+            has_bias = ctx.bias_params[0] is not None
+            flat_params = [p for g in range(ngroups) for p in ([ctx.bias_params[g]] if has_bias else []) + ctx.params[g]]
+            sinks = [_grad_sink(p) for p in flat_params]
+            all_needed = all(ctx.needs_input_grad[4 + ngroups + g * per + j] for g in range(ngroups)
+                             for j in range(per) if (j > 0 or has_bias))
+            direct = (DIRECT_PARAM_GRAD and not torch.is_grad_enabled() and all_needed
+                      and sinks[0] is not None and all(b is sinks[0] for b in sinks))
+            if direct:
+                gw_out = [[p.grad for p in ctx.params[g]] for g in range(ngroups)]
+                gb_out = [ctx.bias_params[g].grad if has_bias else None for g in range(ngroups)]
+            else:
+                gw_out = [[torch.empty((fo, fi), dtype=torch.float32, device=dev) for _ in range(k + 1)]
+                          for _ in range(ngroups)]
+                gb_out = [torch.empty(fo, dtype=torch.float32, device=dev) if has_bias else None
+                          for _ in range(ngroups)]
+            nbytes = L.dc_tag_grouped_bwd_dw_workspace_bytes(rows, ngroups, fi, fo, k + 1)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            xblocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
+            _lib.check(L.dc_tag_grouped_bwd_dw_h2(
+                gslab.data_ptr(), gslab.stride(0), _ptr_array(xblocks), _i64_array([slab.stride(0)] * (k + 1)),
+                k + 1, ngroups, row_beg, rows, n,
+                _vp_array([t.data_ptr() for ws in gw_out for t in ws]),
+                _vp_array([t.data_ptr() if t is not None else None for t in gb_out]), int(direct),
+                scratch.data_ptr(), nbytes, fi, fo, g_rowmax.data_ptr(), xrowmax.data_ptr(), st),
+                "dc_tag_grouped_bwd_dw_h2")
+            if direct:
+                sinks[0].note_direct_write(torch.cuda.current_stream(dev))
+            else:
+                for g in range(ngroups):
+                    base = g * per
+                    if has_bias and ctx.needs_input_grad[4 + ngroups + base]:
+                        pgrads[base] = gb_out[g]
+                    for j in range(k + 1):
+                        if ctx.needs_input_grad[4 + ngroups + base + 1 + j]:
+                            pgrads[base + 1 + j] = gw_out[g][j]
+        return (None, None, None, None, *gxs, *pgrads)
+
+
+def tag_conv_grouped(mg: GraphIndex, xs, weights, biases, relu: bool = False, next_k=None):
+    """One TAGConv layer of ``len(xs)`` branches over the merged adjacency ``mg``: ``xs[g]`` ``[rows_g, Fi]``,
+    ``weights[g]`` = that branch's ``lins[0..K].weight``, ``biases[g]`` its bias.  Returns one output per
+    branch.  ``next_k``: K of a grouped layer that consumes the outputs - they are then written as the part
+    views of block 0 of that layer's merged slab."""
+    flat = []
+    for b, ws in zip(biases, weights):
+        flat += [b] + list(ws)
+    return _TagConvGroupedFn.apply(mg, bool(relu), (int(next_k),) if next_k is not None else None, len(xs),
+                                   *xs, *flat)
 
 
 def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,

@@ -106,9 +106,12 @@ def make_batch(batch_size: int = 32, first_idx: int = 0, soft_vertices: int = 10
     """Batched (soft_rest, soft_def, rigid) as ``train.py:36-38`` builds them."""
     triples = [make_sample(first_idx + i, soft_vertices, sphere_resolution)
                for i in range(batch_size)]
-    return (Batch.from_data_list([t[0] for t in triples]),
-            Batch.from_data_list([t[1] for t in triples]),
-            Batch.from_data_list([t[2] for t in triples]))
+    out = (Batch.from_data_list([t[0] for t in triples]),
+           Batch.from_data_list([t[1] for t in triples]),
+           Batch.from_data_list([t[2] for t in triples]))
+    from .loaders import mark_edge_equality
+    mark_edge_equality(out[0], out[1])                 # host-side: selects the fused loss (train.losses)
+    return out
 
 
 def radius_graph_points(num_points: int = 100_000, radius: float = 0.02,

@@ -25,14 +25,34 @@ from .loaders import InMemoryDataset, PrefetchLoader, SyntheticEverydayDataset, 
 
 
 #: both losses (and their gradients) in ONE node pass of the library (``ops.contact_losses``) when the
-#: batches live on a HIP device and prediction and target share their edge set (they do:
-#: ``train.py:36-37`` batches the rest and the deformed graph of the same meshes); ``DC_FUSED_LOSS=0``
-#: keeps the stock PyTorch formulation of ``models/losses.py``.
+#: batches live on a HIP device and prediction and target are KNOWN to share the rest batch's edge set.
+#: The reference pairs the deformed mesh's own edges with the prediction's (``models/losses.py:12-13``) and
+#: builds them from a separate mesh file (``loaders/everyday_deform.py``), so equality is a property of
+#: the data, not of the code: it is decided ONCE PER BATCH ON THE HOST, where the tensors still are
+#: (``loaders.mark_edge_equality``, called by ``to_batches`` / ``PrefetchLoader`` / ``synth.make_batch``),
+#: and carried on the batch object.  Unknown or unequal -> the stock formulation of ``models/losses.py``.
+#: ``DC_FUSED_LOSS=0`` keeps the stock formulation always; ``DC_LOSS_DEBUG=1`` adds a device-side
+#: comparison that poisons both losses with NaN on a mismatch (a debug assert, two E-sized launches).
 FUSED_LOSS = os.environ.get("DC_FUSED_LOSS", "1") != "0"
+LOSS_DEBUG = os.environ.get("DC_LOSS_DEBUG", "0") == "1"
 
 
 def _same_edges(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a is b or (a.shape == b.shape and a.data_ptr() == b.data_ptr())
+
+
+def _edges_known_equal(batch, ei: torch.Tensor) -> bool:
+    """Is ``batch.edge_index`` known - without looking at device memory - to equal ``ei``?  Same storage, a
+    ``clone()`` of the batch that owns ``ei`` (``GraphNet.forward`` returns ``graph_resting.clone()``,
+    ``models/model.py:91``), or marked equal on the host by the loader."""
+    other = batch.edge_index
+    if _same_edges(other, ei):
+        return True
+    src = getattr(batch, "_dc_cloned_edges", None)
+    if src is not None and src[0] is ei and src[1] == ei._version and other.shape == ei.shape:
+        return True
+    mark = getattr(batch, "_dc_edges_equal", None)
+    return bool(mark is not None and mark[0] and other.shape == ei.shape)
 
 
 def losses(model, rest, deff, rig, lambda_gradient: float = 1.0) -> Dict[str, torch.Tensor]:
@@ -41,23 +61,25 @@ def losses(model, rest, deff, rig, lambda_gradient: float = 1.0) -> Dict[str, to
     tgt_pos = deff.pos - rest.pos
     ei = rest.edge_index
     if (FUSED_LOSS and pred.pos.is_cuda and pred.pos.dtype == torch.float32 and pred.pos.size(0) > 0
-            and ei.size(1) > 0 and pred.edge_index.shape == ei.shape and deff.edge_index.shape == ei.shape):
+            and ei.size(1) > 0 and _edges_known_equal(pred, ei) and _edges_known_equal(deff, ei)):
         from . import ops
         from .graph import graph_index
-        # The loss runs over the adjacency the encoder built for rest.edge_index (a cache hit).  The
+        # The loss runs over the adjacency the encoder built for rest.edge_index (a cache hit): the
         # reference takes the edges from pred (a clone of the rest batch, model.py:91) and from the
-        # deformed batch (the same triangles, train.py:36-37): that they equal rest's is CHECKED on
-        # the device, without a host sync - a mismatch poisons both losses with NaN.
-        bad = None
-        for other in (pred.edge_index, deff.edge_index):
-            if not _same_edges(other, ei):
-                ne = (other != ei).any()
-                bad = ne if bad is None else (bad | ne)
+        # deformed batch; both are known to equal rest's here (decided on the host, see FUSED_LOSS).
         g = graph_index(ei, pred.pos.size(0))
+        if getattr(g, "row_offset", 0):
+            raise RuntimeError("losses: the soft graph must be the first part of a merged adjacency")
         l1, gcl = ops.contact_losses(g, pred.pos, tgt_pos)
-        if bad is not None:
-            nan = torch.full_like(l1, float("nan"))
-            l1, gcl = torch.where(bad, nan, l1), torch.where(bad, nan, gcl)
+        if LOSS_DEBUG:
+            bad = None
+            for other in (pred.edge_index, deff.edge_index):
+                if not _same_edges(other, ei):
+                    ne = (other != ei).any()
+                    bad = ne if bad is None else (bad | ne)
+            if bad is not None:
+                nan = torch.full_like(l1, float("nan"))
+                l1, gcl = torch.where(bad, nan, l1), torch.where(bad, nan, gcl)
     else:
         tgt = deff.clone()
         tgt.pos = tgt_pos
@@ -105,8 +127,11 @@ class GraphedTrainStep:
 
     @staticmethod
     def _signature(batches):
+        # shapes + the host-side edge-equality mark of every batch: it selects the loss formulation the
+        # captured graph contains, so a batch with a different mark must not replay it
         return tuple((k, tuple(getattr(b, k).shape)) for b in batches for k in _BATCH_TENSORS
-                     if isinstance(getattr(b, k, None), torch.Tensor))
+                     if isinstance(getattr(b, k, None), torch.Tensor)) + \
+            tuple(bool((getattr(b, "_dc_edges_equal", None) or (False,))[0]) for b in batches)
 
     def _fwd_bwd(self, rest, deff, rig):
         out = losses(self.model, rest, deff, rig, self.lam)
@@ -142,6 +167,9 @@ class GraphedTrainStep:
                     t.copy_(getattr(src, k), non_blocking=True)
         self._graph.replay()
         self.replays += 1
+        if self.replays == 1:
+            from .graph import validate_pending
+            validate_pending()                  # DC_VALIDATE=1: adjacencies built under the capture
         if not self._tail_in_graph:
             self._tail()
         return self._out

@@ -37,6 +37,10 @@ extern "C" {
 
 typedef void *dc_stream_t; /* hipStream_t */
 
+#define DC_MAX_PARTS 4     /* edge_index parts of one merged (block-diagonal) adjacency */
+#define DC_MAX_GROUPS 4    /* row groups with their own weights in one grouped dense launch */
+#define DC_GROUP_ALIGN 256 /* every group of a grouped launch starts at a multiple of this many rows */
+
 int dc_version(void);
 const char *dc_last_error(void);
 /* Sequence id of the hipGraph capture `stream` currently takes part in, 0 when it is not
@@ -94,6 +98,25 @@ int dc_graph_build(const int64_t *edge_index, int64_t E, int64_t N, int self_loo
                    int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
                    int32_t *status, void *workspace, int64_t workspace_bytes, dc_stream_t stream);
 
+/* dc_graph_build over a MERGED edge set: `nparts` (<= DC_MAX_PARTS) edge_index arrays
+ * (edge_index_parts[p] = int64 [2, E_parts[p]]) read as one concatenated edge list - edge ids run
+ * through the parts in order - over ONE node space of N nodes in which part p's node ids are
+ * shifted by node_offset_parts[p] (ascending; part p must stay inside
+ * [node_offset_parts[p], node_offset_parts[p] + nodes_parts[p]), which is also the range its ids
+ * are checked against).  This is the block-diagonal union PyG's Batch.from_data_list builds per
+ * graph type, taken one step further: the soft and the rigid graph of a batch (train.py:36-38)
+ * in one adjacency, so that the conv layers of both encoder branches (models/model.py:69-78) run
+ * as single launches.  Nodes that belong to no part (padding between parts) are isolated.  Rows
+ * of part p come out exactly as dc_graph_build over that part alone would emit them (same stable
+ * order, same gcn_norm weights), with `other` shifted by the part's offset and `perm` by the
+ * part's first edge id. */
+int dc_graph_build_parts(const int64_t *const *edge_index_parts, const int64_t *E_parts,
+                         const int64_t *node_offset_parts, const int64_t *nodes_parts, int nparts,
+                         int64_t N, int self_loops,
+                         int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
+                         int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
+                         int32_t *status, void *workspace, int64_t workspace_bytes, dc_stream_t stream);
+
 /* 30-bit Morton (Z-order) code of every point of pos [n, >=3] (fp32, leading dimension ld): each
  * axis is mapped from [lo[a], lo[a] + 1 / inv_extent[a]) to 10 bits (lo / inv_extent are HOST
  * arrays of 3 floats).  The host sorts nodes by it (graph.NodeOrder.morton) so that the rows a
@@ -122,6 +145,15 @@ int dc_hash_i64(const int64_t *v, int64_t n, uint64_t *out, dc_stream_t stream);
 int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
                 int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
                 int64_t N, int64_t F, dc_stream_t stream);
+
+/* dc_spmm_f32 over a ROW WINDOW of a merged adjacency (dc_graph_build_parts): `ptr` points at the
+ * window's first row (N + 1 entries; its values index the full other / w arrays), neighbour ids are
+ * ids of the merged node space, and x / addend / y hold only the window's N rows: the neighbour
+ * row read is other[p] - row_offset.  Lets one part of a merged graph (e.g. the first, narrow
+ * layer of one encoder branch) hop over its own feature matrix without a second adjacency. */
+int dc_spmm_f32_window(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
+                       int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
+                       int64_t N, int64_t F, int64_t row_offset, dc_stream_t stream);
 
 /* The same hop over bf16-STORED feature rows ("bf16 features, fp32
  * accumulate"; PyG reaches it as conv(x.bfloat16(), edge_index) under autocast, where
@@ -326,6 +358,51 @@ int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_image, cons
 int dc_tag_linear_fwd_h2p_exp(const float *x, int64_t ldx, const void *w_image, float *out, int64_t ldo,
                               int64_t N, int64_t K, int64_t Fo, const float *x_rowmax, const float *w_rowmax,
                               const float *row_lse, int64_t ncols_valid, dc_stream_t stream);
+/* ---- grouped launches: both encoder branches as ONE block-diagonal launch ----
+ * The reference runs its two branches as 2 x 2 conv calls (models/model.py:69-78).  Over a merged node
+ * space (dc_graph_build_parts) the second layers of both branches - same widths, different weights -
+ * become single launches: the hops need nothing new (one adjacency), the dense blocks take GROUPS:
+ * group g = rows [row_beg[g], row_beg[g] + rows[g]) of the merged matrices, with its own weights.
+ * row_beg[g] and N_total are multiples of DC_GROUP_ALIGN; the rows between groups are padding the
+ * CALLER keeps at zero in x and in the gradients (isolated nodes: the hops write zeros there), so
+ * they add exact zeros to dW and their outputs are never read.  Per row the arithmetic is exactly
+ * that of the ungrouped h2 entries on that group alone: outputs, dX and (with the per-group node
+ * chunks of the ungrouped plan) dW are bit-identical to separate launches.
+ *   dc_tag_grouped_weight_prep   dc_tag_weight_prep for every group in one launch; ws[g*nseg + s],
+ *                                per-group output pointer arrays [ngroups]
+ *   dc_tag_grouped_fwd_h2p       dc_tag_linear_fwd_h2p (K % 32 == 0; forward and, with the transposed
+ *                                images over the gradient slab, dX)
+ *   dc_tag_grouped_mask_grad     dc_tag_mask_grad with one upstream-gradient matrix per group
+ *                                (g[k] = rows[k] x F, local row numbering); padding rows get zeros
+ *   dc_tag_grouped_bwd_dw_h2     dc_tag_linear_bwd_dw_h2 on the pre-masked gradient (Fi == 256 per
+ *                                segment, Fo % 128 == 0): gws[g*nseg + s] [Fo, Fi], gbias[g] [Fo] */
+int dc_tag_grouped_weight_prep(const float *const *ws, int ngroups, int nseg, int64_t Fo, int64_t Fi,
+                               float *const *w_rowmax, void *const *w_image, void *const *wt_image,
+                               float *const *wt_rowmax, dc_stream_t stream);
+int dc_tag_grouped_fwd_h2p(const float *x, int64_t ldx, int ngroups, const int64_t *row_beg,
+                           const int64_t *rows, int64_t N_total, const void *const *w_images,
+                           const float *const *biases, int relu, float *out, int64_t ldo, int64_t K,
+                           int64_t Fo, const float *x_rowmax, const float *const *w_rowmaxes,
+                           dc_stream_t stream);
+int dc_tag_grouped_mask_grad(const float *const *g, const int64_t *ldg, int ngroups, const int64_t *row_beg,
+                             const int64_t *rows, int64_t N_total, const float *out_for_mask, int64_t ldo,
+                             float *gm, int64_t ldgm, int64_t F, float *rowmax_a, float *rowmax_b,
+                             dc_stream_t stream);
+int64_t dc_tag_grouped_bwd_dw_workspace_bytes(const int64_t *rows, int ngroups, int64_t Fi, int64_t Fo,
+                                              int nseg);
+int dc_tag_grouped_bwd_dw_h2(const float *g, int64_t ldg, const float *const *xs, const int64_t *ldxs,
+                             int nseg, int ngroups, const int64_t *row_beg, const int64_t *rows,
+                             int64_t N_total, float *const *gws, float *const *gbias, int accumulate,
+                             void *partials, int64_t partials_bytes, int64_t Fi, int64_t Fo,
+                             const float *g_rowmax, const float *x_rowmax, dc_stream_t stream);
+
+/* Number of launches of the GENERIC dense kernels (any shape / alignment, bounds logic per load, scalar
+ * loads when misaligned) since the library was loaded or the counter was last reset (reset != 0 returns the
+ * count and clears it).  Every shape of the shipped configuration has a tuned kernel; a non-zero count after a
+ * default-config step means an operand lost its alignment or a shape fell off the fast paths (round 2 found two
+ * such silent fallbacks only through DC_DENSE_TRACE=1) - the test suite pins it at zero. */
+int64_t dc_generic_dense_launches(int reset);
+
 /* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
 int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,
                      dc_stream_t stream);

@@ -14,9 +14,11 @@ What is imported from ``/root/reference`` (unchanged, nothing copied):
     collate_fn``; ``configs/config.py: Config`` with ``configs/everyday.json``.
 ``torch_geometric`` is absent from the image, so ``oracle/pyg_ref.py`` is
 registered under that name first; only the conv
-internals are therefore a restatement.  ``loaders/common.py`` needs ``open3d``
-and cannot be imported; its 13-line ``_feature_rigid`` (``:6-19``) is restated in
-``rigid_features`` below.
+internals are therefore a restatement.  ``loaders/common.py`` imports ``open3d`` at
+module level (absent here): it is imported behind an EMPTY stub module of that name -
+``_feature_rigid`` (``:6-19``) itself touches only torch - and its output is stored in
+``feature_rigid.npz``; ``rigid_features`` below (used while building the other fixtures)
+is asserted equal to it.
 """
 from __future__ import annotations
 
@@ -198,11 +200,34 @@ def small_fixtures():
     print("wrote small fixtures")
 
 
+def feature_rigid_fixture():
+    """``loaders/common.py:6-19`` ``_feature_rigid`` - the REFERENCE's own function, imported with a stub
+    ``open3d`` (the module only needs the name at import time) - on closed-form inputs."""
+    from oracle.weights import hashed_uniform
+    sys.modules.setdefault("open3d", types.ModuleType("open3d"))
+    from loaders.common import _feature_rigid
+    from utils.pos_encoding import to_log_freq
+    cases = {}
+    for i, (v, f) in enumerate([(7, 0.25), (1, 0.0), (42, 0.875)]):
+        pos = torch.from_numpy(hashed_uniform((v, 3), 31 + i, 0.4))
+        enc = to_log_freq(pos, 3, 1)
+        fv = torch.from_numpy(hashed_uniform((3,), 41 + i, 1.0))
+        out = _feature_rigid({"force_vector": fv, "force": f}, enc)
+        assert torch.equal(out, rigid_features(fv, f, enc)), "make_golden.rigid_features != reference"
+        cases.update({f"force_vector{i}": np_(fv), f"force{i}": np.float32(f), f"pos_enc{i}": np_(enc),
+                      f"features{i}": np_(out)})
+    np.savez_compressed(os.path.join(OUT, "feature_rigid.npz"), n_cases=3, **cases)
+    print("wrote feature_rigid.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_oracle_as_pyg()
     sys.path.insert(0, REF)
     torch.set_num_threads(1)       # deterministic CPU summation order for the fixtures
+    feature_rigid_fixture()
+    if "--only-feature-rigid" in sys.argv:
+        return
     small_fixtures()
     graphnet_fixture("TAGConv", 32, True, "graphnet_tag_h32.npz")
     graphnet_fixture("GCNConv", 32, True, "graphnet_gcn_h32.npz")

@@ -1,0 +1,48 @@
+"""Data-parallel step through `train.GraphedTrainStep` on real kernels: two ranks on the one
+device of the test box, collectives over gloo (RCCL on the 8-GPU node; the code path is the same:
+`dp.GradBucket.all_reduce_mean` + `FlatAdam.step` outside the captured forward/backward).  The ranks are child
+processes started while THIS process has not initialised the HIP runtime (this file sorts before the other GPU tests
+for that reason); rank 0 checks the replicas against a single-process run over both ranks' batches
+(tests/dp_graphed_worker.py).  Reference: /root/reference/train.py:46-58,71-73 (the step), SURVEY.md 8(e)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_rank_graphed_train_step_equals_single_process_mean_gradient(tmp_path):
+    if torch.cuda.is_initialized():
+        pytest.skip("HIP already initialised in this process; not starting child processes from it")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "dp")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_graphed_worker.py"), out],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    logs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append((p.returncode, e.decode(errors="replace")[-2000:]))
+    assert all(rc == 0 for rc, _ in logs), logs
+    r0, r1 = (json.load(open(f"{out}.rank{r}.json")) for r in range(2))
+    assert r0["replays"] == r1["replays"] == 4
+    assert r0["losses"] != r1["losses"]                                   # different batches per rank
+    # replicas == single process on the mean gradient: same kernels, same order -> the same bits
+    assert r0["bit_identical"], f"max |diff| {r0['max_abs_diff']:.3e} at scale {r0['scale']:.3e}"

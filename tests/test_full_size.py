@@ -1,0 +1,280 @@
+"""Full-size (BASELINE.json configs[1] / configs[2]) parity cases that round 2 left open ("what is
+weak" 2, 3 and "missing" 4): the B=32 step the bench times with DEFAULT initialisation - the ReLU masks exercised at
+full size -, the GCN / GAT backbones at B=32, the loss curve of the shipped configuration (hidden 256, batch 4), and
+a pin on WHICH dense kernels a default step launches.  Reference: /root/reference/models/model.py:39-50,69-78,
+train.py:46-58,71-73."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deformcontact_amd import _lib, loaders, synth
+from deformcontact_amd.graph import clear_cache
+from deformcontact_amd.graphnet import EVERYDAY_NETWORK, ContactEncoder, load_model
+from oracle import pyg_ref
+from tests.helpers import G, assert_parity, rel_err, row_rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def everyday_b32():
+    rest, _, rig = synth.make_batch(32)
+    return rest, rig
+
+
+class _MaskedBranch(torch.nn.Module):
+    """One encoder branch of the oracle in float64 with the ReLU replaced by GIVEN 0/1 masks (the masks the HIP
+    path applied): the float64 truth of the backward the HIP path actually ran."""
+
+    def __init__(self, convs, masks):
+        super().__init__()
+        self.convs, self.masks = convs, masks
+        self.pre = []
+
+    def forward(self, x, edge_index):
+        self.pre = []
+        for conv, m in zip(self.convs, self.masks):
+            h = conv(x, edge_index)
+            self.pre.append(h.detach())
+            x = h * m
+        return x
+
+
+@pytest.mark.parametrize("merged", [False, True])
+def test_b32_default_init_step_with_relu_masks_vs_oracle(everyday_b32, merged):
+    """The step the bench times: B=32, DEFAULT initialisation (zero biases: half of the 15 M pre-activations are
+    negative, a few lie within fp32 rounding of the kink).  Outputs per row against the fp32 oracle / float64.
+    Gradients: the fp32 oracle, the float64 oracle and the HIP path may each decide a handful of near-zero
+    pre-activations differently, and ONE flipped mask element moves a bias gradient by 1e-4 whatever the precision of
+    the sums - so (1) the HIP masks are checked element by element against the float64 pre-activations: every
+    disagreement must sit within 1e-5 of its row's scale of the kink, and (2) the gradients are checked, under the
+    usual three-way rule, against the float64 backward evaluated WITH THE HIP PATH'S OWN MASKS - i.e. the ReLU
+    backward, the masked dW / dX blocks and the transposed hops are exercised at full size on real masks."""
+    rest, rig = everyday_b32
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256)
+    ref = ContactEncoder([21, 25], 256, conv_module=pyg_ref)
+    ref.load_state_dict(enc.state_dict())
+    ref64 = ContactEncoder([21, 25], 256, conv_module=pyg_ref)
+    ref64.load_state_dict(enc.state_dict())
+    ref64 = ref64.double()
+    enc = enc.to(DEV)
+    enc.merge_branches = merged
+    assert enc._mergeable(rest.x.to(DEV), rig.x.to(DEV)) == merged
+    clear_cache()
+    acts = {}
+    hooks = [c.register_forward_hook(lambda m, i, o, k=(b, l): acts.__setitem__(k, o.detach()))
+             for b, layers in (("s", enc.conv_layers_resting), ("r", enc.conv_layers_rigid))
+             for l, c in enumerate(layers) if l == 0]
+    gen = torch.Generator().manual_seed(5)
+    ga = torch.randn(rest.x.shape[0], 256, generator=gen)
+    gb = torch.randn(rig.x.shape[0], 256, generator=gen)
+    a, b = enc(rest.clone().to(DEV), rig.clone().to(DEV))
+    torch.autograd.backward([a, b], [ga.to(DEV), gb.to(DEV)])
+    for h in hooks:
+        h.remove()
+    hip_act = {("s", 0): acts[("s", 0)].cpu(), ("r", 0): acts[("r", 0)].cpu(), ("s", 1): a.detach().cpu(),
+               ("r", 1): b.detach().cpu()}
+    assert 0.2 < float((hip_act[("s", 1)] > 0).double().mean()) < 0.8          # the masks are real masks
+    # fp32 oracle, its own ReLU
+    rest_c, rig_c = G(rest.x, rest.edge_index), G(rig.x, rig.edge_index)
+    ra, rb = ref(rest_c, rig_c)
+    torch.autograd.backward([ra, rb], [ga, gb])
+    # float64 oracle with the HIP path's masks
+    br = {"s": _MaskedBranch(ref64.conv_layers_resting, [(hip_act[("s", l)] > 0).double() for l in range(2)]),
+          "r": _MaskedBranch(ref64.conv_layers_rigid, [(hip_act[("r", l)] > 0).double() for l in range(2)])}
+    ta = br["s"](rest.x.double(), rest.edge_index)
+    tb = br["r"](rig.x.double(), rig.edge_index)
+    torch.autograd.backward([ta, tb], [ga.double(), gb.double()])
+    # (1) mask consistency: where the HIP mask and the float64 pre-activation's sign disagree, the pre-activation
+    # is within rounding of zero on its row's scale
+    flips = 0
+    for k in ("s", "r"):
+        for l in range(2):
+            pre = br[k].pre[l]
+            bad = (hip_act[(k, l)] > 0) != (pre > 0)
+            flips += int(bad.sum())
+            if bad.any():
+                scale = pre.abs().amax(dim=1, keepdim=True).expand_as(pre)
+                assert float((pre.abs() / scale)[bad].max()) < 1e-5, f"mask of branch {k} layer {l}"
+    assert flips < 2000, f"{flips} mask elements differ from the float64 evaluation"
+    # (2) outputs per row, every parameter gradient
+    assert_parity(_np(a), _np(ra), _np(ta), TOL, "soft per row", metric=row_rel_err)
+    assert_parity(_np(b), _np(rb), _np(tb), TOL, "rigid per row", metric=row_rel_err)
+    rp, tp = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for name, p in enc.named_parameters():
+        e_h = rel_err(_np(p.grad), _np(tp[name].grad))
+        assert e_h < TOL, f"{name}: {e_h:.2e} from the float64 backward over the HIP path's own masks"
+        # and the north-star bar against the fp32 oracle wherever the two fp32 evaluations took the same masks
+        if flips == 0:
+            assert_parity(_np(p.grad), _np(rp[name].grad), _np(tp[name].grad), TOL, name)
+
+
+@pytest.mark.parametrize("backbone", ["GCNConv", "GATConv"])
+def test_b32_encoder_other_backbones_vs_oracle(everyday_b32, backbone):
+    """`backbone` = GCNConv / GATConv (models/model.py:39) at the benchmark size: forward per row and every parameter
+    gradient against the oracle (fp32, float64 under the three-way rule).  Biases are raised off the ReLU kink as
+    in test_full_size_encoder_vs_oracle (masks at full size: the TAGConv test above)."""
+    rest, rig = everyday_b32
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256, backbone=backbone)
+    with torch.no_grad():
+        for name, p_ in enc.named_parameters():
+            if name.endswith(".bias"):
+                p_.fill_(3.0)
+    ref = ContactEncoder([21, 25], 256, backbone=backbone, conv_module=pyg_ref)
+    ref.load_state_dict(enc.state_dict())
+    ref64 = ContactEncoder([21, 25], 256, backbone=backbone, conv_module=pyg_ref)
+    ref64.load_state_dict(enc.state_dict())
+    ref64 = ref64.double()
+    enc = enc.to(DEV)
+    clear_cache()
+    gen = torch.Generator().manual_seed(6)
+    ga = torch.randn(rest.x.shape[0], 256, generator=gen)
+    gb = torch.randn(rig.x.shape[0], 256, generator=gen)
+    a, b = enc(rest.clone().to(DEV), rig.clone().to(DEV))
+    torch.autograd.backward([a, b], [ga.to(DEV), gb.to(DEV)])
+    ra, rb = ref(G(rest.x, rest.edge_index), G(rig.x, rig.edge_index))
+    torch.autograd.backward([ra, rb], [ga, gb])
+    ta, tb = ref64(G(rest.x.double(), rest.edge_index), G(rig.x.double(), rig.edge_index))
+    torch.autograd.backward([ta, tb], [ga.double(), gb.double()])
+    assert float(ta.min()) > 0.02 and float(tb.min()) > 0.02, "a ReLU came near its kink: raise the biases"
+    assert_parity(_np(a), _np(ra), _np(ta), TOL, "soft per row", metric=row_rel_err)
+    assert_parity(_np(b), _np(rb), _np(tb), TOL, "rigid per row", metric=row_rel_err)
+    rp, tp = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for name, p in enc.named_parameters():
+        assert_parity(_np(p.grad), _np(rp[name].grad), _np(tp[name].grad), TOL, name)
+
+
+def test_loss_curve_of_the_shipped_configuration_vs_oracle():
+    """BASELINE.json configs[2] at the SHIPPED configuration (configs/everyday.json: hidden 256, 2 + 2 TAGConv
+    layers, 2 attention heads, batch 4; full-size meshes): 8 training steps, a new batch every step, same init,
+    Adam(4e-4) - HIP path (FlatAdam over the direct-gradient bucket, steps replayed from one hipGraph) vs the CPU
+    oracle in fp32 and in float64.  Per step the three-way rule: within 1e-5 of the fp32 oracle's loss, or no
+    further from the float64 curve than twice the fp32 oracle is."""
+    from deformcontact_amd import dp
+    from deformcontact_amd.train import GraphedTrainStep, train_step
+    torch.manual_seed(0)
+    ref = load_model(EVERYDAY_NETWORK, conv_module=pyg_ref)
+    ref64 = load_model(EVERYDAY_NETWORK, conv_module=pyg_ref)
+    ref64.load_state_dict(ref.state_dict())
+    ref64 = ref64.double()
+    gpu = load_model(EVERYDAY_NETWORK)
+    gpu.load_state_dict(ref.state_dict())
+    gpu = gpu.to(DEV)
+    o_ref = torch.optim.Adam(ref.parameters(), lr=4e-4)
+    o_ref64 = torch.optim.Adam(ref64.parameters(), lr=4e-4)
+    bucket = dp.GradBucket(gpu.parameters(), direct=True)
+    o_gpu = dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=True)
+    step = GraphedTrainStep(gpu, o_gpu, bucket, 1.0, eager_steps=2)
+    ds = loaders.SyntheticEverydayDataset(32, 0)
+    curves = {"gpu": [], "f32": [], "f64": []}
+    for collated in loaders.iterate_batches(ds, 4):
+        cpu = loaders.to_batches(collated)
+        curves["f32"].append(float(train_step(ref, o_ref, *cpu)["loss"]))
+        c64 = loaders.to_batches(collated)
+        for bt in c64:
+            bt.x, bt.pos = bt.x.double(), bt.pos.double()
+        curves["f64"].append(float(train_step(ref64, o_ref64, *c64)["loss"]))
+        curves["gpu"].append(float(step(*loaders.to_batches(collated, DEV))["loss"]))
+    assert len(curves["gpu"]) == 8 and step.replays == 6
+    for i, (g, r, t) in enumerate(zip(curves["gpu"], curves["f32"], curves["f64"])):
+        d = abs(g - r) / abs(r)
+        if d >= TOL:
+            e_h, e_o = abs(g - t) / abs(t), abs(r - t) / abs(t)
+            assert e_h <= max(2 * e_o, TOL), (f"step {i}: HIP {g:.9g} vs fp32 oracle {r:.9g} ({d:.2e}); vs float64 "
+                                              f"{t:.9g}: HIP {e_h:.2e}, oracle {e_o:.2e}", curves)
+    assert curves["gpu"][-1] < curves["gpu"][0]
+    # the parameters after 8 steps: against the float64 run, no worse than twice the fp32 oracle's drift
+    for (name, pg), pr, pt in zip(gpu.named_parameters(), ref.parameters(), ref64.parameters()):
+        e_h = rel_err(_np(pg), _np(pt))
+        e_o = rel_err(_np(pr), _np(pt))
+        assert e_h <= max(2 * e_o, 2e-5), f"{name}: HIP {e_h:.2e} vs oracle {e_o:.2e} from float64 after 8 steps"
+
+
+@pytest.mark.parametrize("merged", [False, True])
+def test_default_b32_step_launches_no_generic_dense_kernel(everyday_b32, merged):
+    """Pin on the kernel surface: a default-config B=32 encoder step (forward + backward, direct-gradient bucket)
+    and a shipped-config full step at batch 4 never reach the generic (bounds-checked, scalar-load) dense kernels
+    (`dc_generic_dense_launches`; round 2 found two silent fallbacks of that kind by accident)."""
+    from deformcontact_amd import dp
+    from deformcontact_amd.train import losses
+    L = _lib.lib()
+    rest, rig = everyday_b32
+    rest, rig = rest.clone().to(DEV), rig.clone().to(DEV)
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256).to(DEV)
+    enc.merge_branches = merged
+    bucket = dp.GradBucket(enc.parameters(), direct=True)
+    bucket.zero()
+    ga = torch.randn(rest.x.shape[0], 256, device=DEV)
+    gb = torch.randn(rig.x.shape[0], 256, device=DEV)
+    clear_cache()
+    L.dc_generic_dense_launches(1)
+    a, b = enc(rest, rig)
+    torch.autograd.backward([a, b], [ga, gb])
+    torch.cuda.synchronize()
+    assert L.dc_generic_dense_launches(1) == 0, "a dense block of the default B=32 step took the generic kernel"
+    # the whole reference step at the shipped batch size (decoder and attention heads included)
+    model = load_model(EVERYDAY_NETWORK).to(DEV)
+    model.merge_branches = merged
+    mb = dp.GradBucket(model.parameters(), direct=True)
+    mb.zero()
+    r4, d4, g4 = (t.to(DEV) for t in synth.make_batch(4))
+    losses(model, r4, d4, g4, 1.0)["loss"].backward()
+    torch.cuda.synchronize()
+    n = L.dc_generic_dense_launches(1)
+    # the decoder's last Linear (256 -> 3) has no tuned kernel: Fo = 3.  Its forward, dX and dW are the only
+    # generic launches of the step.
+    assert n <= 3, f"{n} generic dense launches in the shipped-config step (expected the 256 -> 3 output layer only)"
+
+
+@pytest.mark.parametrize("npad,n", [(8192 + 4, 8192 + 1), (16384 + 128, 16384 + 77), (24448, 24384), (32768, 32000)])
+def test_attention_row_kernels_register_rows_vs_strided_and_float64(npad, n):
+    """the batch-32 step launches the register-row variants of the attention row kernels
+    (`k_attn_softmax_rows_reg<16/24/32>`, `k_attn_ds_rows_reg<16/24>`: rows of up to 32 K floats held in registers)
+    which no unit test reached.  Each against the strided kernels (forced through a 4-byte-misaligned copy of the
+    same rows) and against the float64 formulas, with padded key columns (n < npad)."""
+    from deformcontact_amd.graph import current_stream_ptr
+    L = _lib.lib()
+    st = current_stream_ptr(torch.device(DEV))
+    rows = 6
+    gen = torch.Generator().manual_seed(npad)
+    s0 = (torch.randn(rows, npad, generator=gen) * 3.0).to(DEV)
+    dp0 = torch.randn(rows, npad, generator=gen).to(DEV)
+
+    def misaligned(t):                                     # same values, row pointer 4 bytes off a 16-byte boundary
+        buf = torch.empty(rows * npad + 8, device=DEV)
+        v = buf[1:1 + rows * npad].view(rows, npad)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+    res = {}
+    for tag, mk in (("reg", lambda t: t.clone()), ("strided", misaligned)):
+        s, lse = mk(s0), torch.empty(rows, device=DEV)
+        _lib.check(L.dc_attn_softmax_rows(s.data_ptr(), npad, rows, n, npad, lse.data_ptr(), st), "softmax")
+        dpv, rm = mk(dp0), torch.empty(rows, device=DEV)
+        _lib.check(L.dc_attn_ds_rows(s.data_ptr(), dpv.data_ptr(), npad, rows, npad, None, rm.data_ptr(), st), "ds")
+        torch.cuda.synchronize()
+        res[tag] = (s.clone(), lse, dpv.clone(), rm)
+    s64 = s0[:, :n].double().cpu()
+    p64 = torch.softmax(s64, dim=1)
+    lse64 = torch.logsumexp(s64, dim=1)
+    d64 = dp0[:, :n].double().cpu()
+    delta = (p64 * d64).sum(1, keepdim=True) / p64.sum(1, keepdim=True)
+    ds64 = p64 * (d64 - delta)
+    for tag, (p, lse, ds, rm) in res.items():
+        assert not p[:, n:].any() and not ds[:, n:].any(), f"{tag}: padded key columns must come out zero"
+        assert rel_err(_np(p[:, :n]), p64.numpy()) < 2e-6, tag
+        assert np.abs(_np(lse) - lse64.numpy()).max() < 2e-6 * np.abs(lse64.numpy()).max(), tag
+        assert rel_err(_np(ds[:, :n]), ds64.numpy()) < 5e-6, tag
+        assert np.allclose(_np(rm), np.abs(_np(ds)).max(1), rtol=0, atol=0), tag
+    assert rel_err(_np(res["reg"][0]), _np(res["strided"][0])) < 1e-6
+    assert rel_err(_np(res["reg"][2]), _np(res["strided"][2])) < 2e-6

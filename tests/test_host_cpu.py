@@ -138,6 +138,17 @@ def test_feature_rigid_layout():
     assert torch.equal(f[:, 3], torch.tensor([0.5, 0.5])) and torch.equal(f[:, 4:], enc)
 
 
+def test_feature_rigid_matches_reference_function():
+    """a10: ``features.feature_rigid`` against the output of the REFERENCE's own ``_feature_rigid``
+    (``/root/reference/loaders/common.py:6-19``, imported by ``oracle/make_golden.py`` behind a stub
+    ``open3d``) - bit for bit, also for a single-vertex encoding and a zero force."""
+    z = load_golden("feature_rigid.npz")
+    for i in range(int(z["n_cases"])):
+        out = features.feature_rigid(torch.from_numpy(z[f"force_vector{i}"]), float(z[f"force{i}"]),
+                                     torch.from_numpy(z[f"pos_enc{i}"]))
+        assert out.dtype == torch.float32 and np.array_equal(out.numpy(), z[f"features{i}"])
+
+
 def test_gcl_loss_golden():
     from deformcontact_amd.graphnet import gradient_consistency_loss
     from tests.helpers import G

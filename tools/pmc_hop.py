@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Run ONLY the F=256 hop launches bench.py prices in its `roofline` object (the 12 hop launches
-of a B=32 step in step order: forward and transposed chains of both branches), so rocprofv3 --pmc
-passes can attribute HBM traffic to dc::k_spmm_wave.
+"""Run ONLY the F=256 hop launches bench.py prices in its `roofline` object (the hop launches of a B=32
+step in step order: forward and transposed chains - 6 launches over the merged adjacency of both
+branches, or 12 per-branch launches with DC_MERGE_BRANCHES=0), so rocprofv3 --pmc passes can attribute
+HBM traffic to dc::k_spmm_wave.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 tools/pmc_hop.py
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d out/write -- python3 tools/pmc_hop.py
@@ -19,26 +20,46 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run():
+def hop_sequence(dev, parts, merged: bool, f: int = 256):
+    """The F=256 hop launches of ONE encoder step in step order on step-shaped slabs - what `roofline` prices
+    and what the --pmc passes measure.  `parts` = [(edge_index, n), ...] (soft, rigid).  merged (the default
+    encoder path): ONE adjacency over both graphs, 3 forward hops on the merged layer-2 slab + 3 transposed
+    hops on the merged gradient slab = 6 launches; else the same chains per branch = 12 launches.
+    -> (fn, launches, compulsory bytes of all launches, gather-model bytes of all launches)."""
     import torch
-    from deformcontact_amd import ops, synth
+    from deformcontact_amd import ops
     from deformcontact_amd.graph import GraphIndex
-    dev = torch.device("cuda:0")
-    rest, _, rig = synth.make_batch(32)
-    f = 256
-    seq = []
-    for b in (rest, rig):
-        n = b.x.shape[0]
-        g = GraphIndex(b.edge_index.to(dev), n)
+    seq, comp, gath = [], 0, 0
+    n_real = sum(n for _, n in parts)
+    e_all = sum(int(ei.shape[1]) for ei, _ in parts)
+    graphs = [(GraphIndex.from_parts(parts), n_real, e_all)] if merged else \
+        [(GraphIndex(ei, n), n, int(ei.shape[1])) for ei, n in parts]
+    for g, n, e in graphs:
         for bwd in (False, True):
-            seq.append((g, ops._alloc_slab(n, 4 * f, dev).normal_(), torch.zeros(n, device=dev), bwd))
-    for _ in range(10):                          # the launches bench.py prices, in the same order:
+            seq.append((g, ops._alloc_slab(g.num_nodes, 4 * f, dev).normal_(), torch.zeros(g.num_nodes, device=dev), bwd))
+            comp += 3 * (e * 8 + n * (8 * f + 4))                   # rows of padding nodes are not counted
+            gath += 3 * (e * (8 + 4 * f) + n * (4 * f + 4))
+
+    def fn():
         for g, slab, rm, bwd in seq:             # forward / transposed chains of 3 hops + row maxima
             if bwd:
                 ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm, transposed=True,
                                  rowmax_has_block0=True)
             else:
                 ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm)
+    return fn, 3 * len(seq), comp, gath
+
+
+def run():
+    import torch
+    from deformcontact_amd import synth
+    dev = torch.device("cuda:0")
+    rest, _, rig = synth.make_batch(32)
+    merged = os.environ.get("DC_MERGE_BRANCHES", "1") != "0"
+    fn, _, _, _ = hop_sequence(dev, [(rest.edge_index.to(dev), rest.x.shape[0]),
+                                     (rig.edge_index.to(dev), rig.x.shape[0])], merged)
+    for _ in range(10):                          # the launches bench.py prices, in the same order
+        fn()
     torch.cuda.synchronize()
 
 

@@ -2,6 +2,11 @@
 # Everything profiles/rNN/ cites, in one pass on a GPU box:   tools/refresh_profiles.sh gpurun_out/<tag>
 # (pytest -m gpu, smoke, the default bench line incl. its own --pmc child passes, kbench, rocprofv3 kernel stats of
 # the step with serial and with two-stream branches, the two PMC passes over the layer-2 dense blocks).
+set -u
+if [ $# -lt 1 ] || [ -z "$1" ] || [ "${1#/}" != "$1" ]; then
+    echo "usage: tools/refresh_profiles.sh <output dir RELATIVE to the repo root, e.g. gpurun_out/p>" >&2
+    exit 2
+fi
 O=$1
 R=$(pwd)
 mkdir -p "$R/$O"
