@@ -31,6 +31,8 @@ _SIGNATURES = {
                                      _vp]),
     "dc_spmm_f32_window": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                                    c_int64, c_int64, _vp]),
+    "dc_spmm_f32_rowmax_window": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
+                                          c_int64, _vp, c_int, c_int64, _vp]),
     "dc_tag_grouped_weight_prep": (c_int, [POINTER(_vp), c_int, c_int, c_int64, c_int64, POINTER(_vp),
                                            POINTER(_vp), POINTER(_vp), POINTER(_vp), _vp]),
     "dc_tag_grouped_fwd_h2p": (c_int, [_vp, c_int64, c_int, POINTER(c_int64), POINTER(c_int64), c_int64,

@@ -733,7 +733,6 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
         t.bias_partial = p.bias_partial ? p.bias_partial + (int64_t)p.nchunks * Fo : nullptr;
         t.h2 = H2Scales{};
         const dim3 gt((unsigned)(tiles * nseg));
-        ++g_generic_dense_launches;                      // (only the < 16 trailing rows)
         if (mb == 2) {
             if (p.has_mask) hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, true>), gt, bd, 0, hs, t);
             else hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, false>), gt, bd, 0, hs, t);

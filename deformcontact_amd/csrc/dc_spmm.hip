@@ -602,10 +602,10 @@ extern "C" int dc_spmm_bf16(const int32_t *ptr, const int32_t *other, const floa
 }
 
 
-extern "C" int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
-                                  const float *x, int64_t ldx, const float *addend, int64_t ldadd,
-                                  float *y, int64_t ldy, int64_t N, int64_t F, float *rowmax,
-                                  int mode, dc_stream_t stream_) {
+static int spmm_f32_rowmax_impl(const int32_t *ptr, const int32_t *other, const float *w,
+                                const float *x, int64_t ldx, const float *addend, int64_t ldadd,
+                                float *y, int64_t ldy, int64_t N, int64_t F, float *rowmax,
+                                int mode, int src_off, dc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DC_REQUIRE(N >= 0 && F >= 0, "dc_spmm_f32_rowmax: negative size");
     if (N == 0) return DC_OK;
@@ -620,9 +620,25 @@ extern "C" int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, cons
     const unsigned grid = (unsigned)((N + 3) / 4);
     if (vec4)
         hipLaunchKernelGGL((k_spmm_wave<4, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
-                           x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode);
+                           x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode, src_off);
     else
         hipLaunchKernelGGL((k_spmm_wave<1, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
-                           x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode);
+                           x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode, src_off);
     return check_launch("dc_spmm_f32_rowmax");
+}
+
+extern "C" int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
+                                  const float *x, int64_t ldx, const float *addend, int64_t ldadd,
+                                  float *y, int64_t ldy, int64_t N, int64_t F, float *rowmax,
+                                  int mode, dc_stream_t stream) {
+    return spmm_f32_rowmax_impl(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, rowmax, mode, 0, stream);
+}
+
+extern "C" int dc_spmm_f32_rowmax_window(const int32_t *ptr, const int32_t *other, const float *w,
+                                         const float *x, int64_t ldx, const float *addend, int64_t ldadd,
+                                         float *y, int64_t ldy, int64_t N, int64_t F, float *rowmax,
+                                         int mode, int64_t row_offset, dc_stream_t stream) {
+    DC_REQUIRE(row_offset >= 0 && row_offset < (int64_t)INT32_MAX, "dc_spmm_f32_rowmax_window: bad row_offset");
+    return spmm_f32_rowmax_impl(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, rowmax, mode, (int)row_offset,
+                                stream);
 }

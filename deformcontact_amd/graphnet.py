@@ -102,10 +102,8 @@ class ContactEncoder(nn.Module):
                 if c.graph_flags() != flags:
                     return False
             if i == 0:
-                # row windows of the merged adjacency carry no row maxima: narrow first layers only
-                if ops._tag_uses_h2(a.in_channels, a.K) or ops._tag_uses_h2(b.in_channels, b.K):
-                    return False
-            elif not ((a.in_channels, a.out_channels, a.K) == (b.in_channels, b.out_channels, b.K)
+                continue                  # first layers run per branch over row windows of the merged adjacency
+            if not ((a.in_channels, a.out_channels, a.K) == (b.in_channels, b.out_channels, b.K)
                       and (a.bias is None) == (b.bias is None)
                       and ops.grouped_eligible(a.in_channels, a.out_channels, a.K)):
                 return False

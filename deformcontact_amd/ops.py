@@ -50,10 +50,18 @@ def hop(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = Non
             raise ValueError("hop: addend shape mismatch")
         lda = _rowmajor(addend, "addend")
     w = adj.w if weighted else None
+    if rowmax is not None and (rowmax.dtype != torch.float32 or rowmax.numel() != n or not rowmax.is_contiguous()):
+        raise ValueError("hop: rowmax must be a contiguous float32 [N] tensor")
     if adj.row_offset:
-        # a row window of a merged adjacency: x / out / addend hold only the window's rows
+        # a row window of a merged adjacency: x / out / addend / rowmax hold only the window's rows
         if rowmax is not None:
-            raise NotImplementedError("hop: row maxima over a window of a merged adjacency")
+            rc = _lib.lib().dc_spmm_f32_rowmax_window(
+                adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+                x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,
+                out.data_ptr(), ldy, n, f, rowmax.data_ptr(), int(rowmax_mode), int(adj.row_offset),
+                current_stream_ptr(x.device))
+            _lib.check(rc, "dc_spmm_f32_rowmax_window")
+            return out
         rc = _lib.lib().dc_spmm_f32_window(
             adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
             x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,
@@ -61,8 +69,6 @@ def hop(adj: SortedAdjacency, x: torch.Tensor, out: Optional[torch.Tensor] = Non
         _lib.check(rc, "dc_spmm_f32_window")
         return out
     if rowmax is not None:
-        if rowmax.dtype != torch.float32 or rowmax.numel() != n or not rowmax.is_contiguous():
-            raise ValueError("hop: rowmax must be a contiguous float32 [N] tensor")
         rc = _lib.lib().dc_spmm_f32_rowmax(
             adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
             x.data_ptr(), ldx, addend.data_ptr() if addend is not None else None, lda,

@@ -154,6 +154,11 @@ int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w, const 
 int dc_spmm_f32_window(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
                        int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
                        int64_t N, int64_t F, int64_t row_offset, dc_stream_t stream);
+/* ... and with the row maxima of dc_spmm_f32_rowmax (rowmax holds the window's N rows). */
+int dc_spmm_f32_rowmax_window(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
+                              int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
+                              int64_t N, int64_t F, float *rowmax, int mode, int64_t row_offset,
+                              dc_stream_t stream);
 
 /* The same hop over bf16-STORED feature rows ("bf16 features, fp32
  * accumulate"; PyG reaches it as conv(x.bfloat16(), edge_index) under autocast, where

@@ -44,6 +44,5 @@ def test_direct_two_rank_launch_on_one_device_over_gloo():
     assert out["value"] > 0 and out["value_cached_topology"] > 0
     assert 0 < out["roofline"]["frac"] <= 1.0
     d = out["dist"]                       # what the driver reads at N > 1 (world size as torch.distributed sees it)
-    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["allreduce_bytes"] == 577536 * 4 + 0 * 16 \
-        or d["allreduce_bytes"] >= 577536 * 4
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["allreduce_bytes"] >= 572416 * 4
     assert d["allreduce_us"] is not None and d["allreduce_us"] > 0

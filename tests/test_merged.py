@@ -81,6 +81,11 @@ def test_window_hop_equals_standalone_hop_bitwise(f):
         for adj_w, adj_g in ((w.fwd, g.fwd), (w.bwd, g.bwd)):
             assert torch.equal(ops.hop(adj_w, x), ops.hop(adj_g, x))
             assert torch.equal(ops.hop(adj_w, x, addend=add), ops.hop(adj_g, x, addend=add))
+            for mode in (0, 1, 3):                   # ... and with the row maxima the wide dense block scales by
+                rm_w, rm_g = torch.full((n,), 0.5, device=DEV), torch.full((n,), 0.5, device=DEV)
+                assert torch.equal(ops.hop(adj_w, x, rowmax=rm_w, rowmax_mode=mode),
+                                   ops.hop(adj_g, x, rowmax=rm_g, rowmax_mode=mode))
+                assert torch.equal(rm_w, rm_g)
         # oracle: the scalar C hop over the part's own edge list
         e = ei.shape[1]
         w_edge = np.zeros(e, np.float32)
@@ -255,7 +260,7 @@ def test_encoder_merged_path_with_direct_gradient_bucket_and_adam():
     """The product's training configuration: gradients accumulated straight into the flat bucket
     (`GradBucket(direct=True)`), FlatAdam - three steps merged vs per-branch end with the same parameters."""
     from deformcontact_amd import dp
-    rest, _, rig = (b.to(DEV) for b in synth.make_batch(2))
+    rest, _, rig = (b.to(DEV) for b in synth.make_batch(16))     # 16 spheres = 12,192 rows: whole 32-row stages
     g_rest = torch.randn(rest.x.shape[0], 256, device=DEV)
     g_rig = torch.randn(rig.x.shape[0], 256, device=DEV)
     finals = []
@@ -279,7 +284,7 @@ def test_encoder_merged_path_with_direct_gradient_bucket_and_adam():
 
 def test_encoder_merged_path_under_hipgraph_with_changing_batches():
     """One captured step (merged adjacency build inside) replayed on new batches vs eager per-branch steps."""
-    batches = [tuple(b.to(DEV) for b in synth.make_batch(2, first_idx=10 * i)) for i in range(3)]
+    batches = [tuple(b.to(DEV) for b in synth.make_batch(16, first_idx=16 * i)) for i in range(3)]
     rest, _, rig = (b.clone() for b in batches[0])
     g_rest = torch.randn(rest.x.shape[0], 256, device=DEV)
     g_rig = torch.randn(rig.x.shape[0], 256, device=DEV)

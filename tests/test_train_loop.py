@@ -151,10 +151,19 @@ def test_fused_contact_losses_match_reference_formulation_and_golden():
     gg.backward()
     assert abs(float(gg) - float(keys["loss"])) <= 1e-5 * abs(float(keys["loss"]))
     assert np.abs(pp.grad.cpu().numpy() - keys["grad_pred"]).max() <= 1e-5 * np.abs(keys["grad_pred"]).max()
-    # through train.losses: fused == stock on a real batch, NaN when the deformed batch's edges differ
+    # through train.losses: fused == stock on a real batch (the loader marked the deformed batch's edges equal
+    # to the rest batch's ON THE HOST); a deformed batch whose edges DIFFER - the reference builds them from a
+    # second mesh file, nothing enforces equal triangle order - takes the stock formulation (it used to
+    # turn both losses into NaN), and DC_LOSS_DEBUG keeps the device-side comparison as a debug assert
     model = load_model(SMALL).to(dev)
-    rest, deff, rig = loaders.to_batches(_batches(2, 2)[0], dev)
+    collated = _batches(2, 2)[0]
+    rest, deff, rig = loaders.to_batches(collated, dev)
+    assert deff._dc_edges_equal == (True,)
+    calls = []
+    real = ops.contact_losses
+    ops.contact_losses = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     fused = dc_train.losses(model, rest, deff, rig)
+    assert len(calls) == 1
     old, dc_train.FUSED_LOSS = dc_train.FUSED_LOSS, False
     try:
         stock = dc_train.losses(model, rest, deff, rig)
@@ -162,6 +171,30 @@ def test_fused_contact_losses_match_reference_formulation_and_golden():
         dc_train.FUSED_LOSS = old
     for k in ("loss", "l1", "consistency"):
         assert abs(float(fused[k]) - float(stock[k])) <= 1e-5 * abs(float(stock[k])), k
-    deff.edge_index = deff.edge_index.clone()
-    deff.edge_index[0, 0] = (deff.edge_index[0, 0] + 1) % 5
-    assert torch.isnan(dc_train.losses(model, rest, deff, rig)["loss"])
+    # a permuted deformed mesh: same edge SET per triangle order change -> different edge_index content
+    names, rests, defs, meta, rigids = collated
+    defs2 = []
+    for d in defs:
+        d2 = d.clone()
+        d2.edge_index = torch.flip(d.edge_index, dims=[1])
+        defs2.append(d2)
+    rest2, deff2, rig2 = loaders.to_batches((names, rests, tuple(defs2), meta, rigids), dev)
+    assert deff2._dc_edges_equal == (False,)
+    out2 = dc_train.losses(model, rest2, deff2, rig2)
+    assert len(calls) == 1                                               # stock formulation, no fused kernel
+    from tests.helpers import G as _G
+    with torch.no_grad():
+        pred = model(rest2, rig2)
+        pred.pos = pred.pos - rest2.pos
+        tgt = _G(None, deff2.edge_index, deff2.pos - rest2.pos)
+        want = torch.nn.functional.l1_loss(pred.pos, tgt.pos) + gradient_consistency_loss(pred, tgt)
+    assert torch.isfinite(out2["loss"]) and abs(float(out2["loss"]) - float(want)) <= 1e-5 * abs(float(want))
+    # debug assert: a batch MARKED equal whose device content differs poisons the losses
+    old_dbg, dc_train.LOSS_DEBUG = dc_train.LOSS_DEBUG, True
+    try:
+        deff.edge_index = deff.edge_index.clone()
+        deff.edge_index[0, 0] = (deff.edge_index[0, 0] + 1) % 5
+        assert torch.isnan(dc_train.losses(model, rest, deff, rig)["loss"])
+    finally:
+        dc_train.LOSS_DEBUG = old_dbg
+        ops.contact_losses = real
