@@ -137,13 +137,15 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
 // Broadcast of the value held by lane J of each 16-lane DPP row to all lanes of that row: a VALU move with
 // the row_share modifier - no LDS round trip (ds_bpermute, which __shfl compiles to, has ~100 cycles of
 // latency behind an lgkmcnt wait, in front of every chunk's gathers).
+// (`old` = the source itself: every lane of the row is written, so no separate v_mov to initialise the destination)
 template <int J>
 __device__ __forceinline__ int row_share_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, false);
 }
 template <int J>
 __device__ __forceinline__ float row_share_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, false));
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x150 + J, 0xF, 0xF, false));
 }
 // ids / weights of a chunk of 8 edges for a lane group of L >= 8 lanes (sub = lane index inside the group):
 // L >= 16: the first 8 lanes of EVERY 16-lane row load them (one coalesced 32-byte load each), row_share
