@@ -95,7 +95,7 @@ def main():
         for window in (False, True):
             us = chain_time(X, mk(), window)
             print(f"{name:26s} {'LDS window' if window else 'gather    '}: {us:7.1f} us per step's F=256 hops, "
-                  f"compulsory-bytes frac of 8 TB/s {comp / us / 1e6 / 8000.0:.3f}")
+                  f"compulsory-bytes frac of 8 TB/s {comp / us / 1e6 / 8.0:.3f}")
 
 
 if __name__ == "__main__":
