@@ -55,6 +55,10 @@ _SIGNATURES = {
                              c_int64, c_int, _vp]),
     "dc_tag_linear_fwd_bf16": (c_int, [_vp, c_int64, _vp, _vp, c_int, _vp, c_int64, c_int, c_int64, c_int64,
                                        c_int64, _vp]),
+    "dc_tag_mask_grad_bf16": (c_int, [_vp, c_int64, c_int, _vp, c_int64, c_int, _vp, c_int64, c_int64, c_int64, _vp]),
+    "dc_tag_linear_bwd_dw_bf16_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64, c_int]),
+    "dc_tag_linear_bwd_dw_bf16": (c_int, [_vp, c_int64, _vp, c_int64, c_int, POINTER(_vp), _vp, c_int, _vp, c_int64,
+                                          c_int64, c_int64, c_int64, _vp]),
     "dc_to_bf16": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, c_int64, _vp, c_int64, _vp]),
     "dc_contact_loss_workspace_bytes": (c_int64, [c_int64]),
     "dc_contact_loss": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int64, _vp, c_int64, c_int64, c_int64, _vp, _vp,

@@ -197,6 +197,17 @@ struct DwParams {
 };
 
 
+// dW over bf16-stored operands (dc_dense_bf16.hip): gm [N, Fo] and the hop slab x [N, nseg * Fi], both bf16
+struct DwBf16Params {
+    const uint16_t *g, *x;
+    int64_t ldg, ldx;
+    float *partial;        // [nchunks][nseg][Fo][Fi]
+    float *bias_partial;   // [nchunks][Fo] or null
+    int64_t N, Fi, Fo, chunk_rows;
+    int nseg, nchunks;
+};
+bool dw_bf16_launch(const DwBf16Params &p, hipStream_t hs);
+
 // lean fast-path launchers (dc_dense_fast.hip); return false when the shape is not eligible
 bool fwd_fast_launch(const FwdParams &p, int mb, hipStream_t hs);
 bool dx_fast_launch(const DxParams &p, int mb, hipStream_t hs);

@@ -1345,3 +1345,58 @@ extern "C" int dc_tag_grouped_bwd_dw_h2(const float *g, int64_t ldg, const float
 extern "C" int64_t dc_generic_dense_launches(int reset) {
     return reset ? (int64_t)g_generic_dense_launches.exchange(0) : (int64_t)g_generic_dense_launches.load();
 }
+
+// ---- dW of the bf16-storage layer (BASELINE.json configs[4] backward): partial slabs per node chunk + slab reduce ----
+static void dw_bf16_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_rows, int *nchunks) {
+    const int64_t tiles = (Fo / 128) * (Fi / 256) * nseg;
+    int64_t want = 1024 / (tiles > 0 ? tiles : 1);                  // ~4 workgroups per CU: short tiles, good balance
+    if (want < 1) want = 1;
+    if (want > 128) want = 128;
+    int64_t rows = (N + want - 1) / want;
+    if (rows < 256) rows = 256;
+    rows = (rows + 31) / 32 * 32;
+    *chunk_rows = rows;
+    *nchunks = (int)((N + rows - 1) / rows);
+    if (*nchunks < 1) *nchunks = 1;
+}
+
+extern "C" int64_t dc_tag_linear_bwd_dw_bf16_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo, int nseg) {
+    if (N < 0 || Fi < 1 || Fo < 1 || nseg < 1 || nseg > kMaxSeg) return DC_EINVAL;
+    int64_t rows;
+    int nch;
+    dw_bf16_plan(N, Fi, Fo, nseg, &rows, &nch);
+    return (int64_t)sizeof(float) * nch * (nseg * Fo * Fi + Fo) + 16;
+}
+
+extern "C" int dc_tag_linear_bwd_dw_bf16(const uint16_t *g, int64_t ldg, const uint16_t *x, int64_t ldx, int nseg,
+                                         float *const *gws, float *gbias, int accumulate, void *partials,
+                                         int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo,
+                                         dc_stream_t stream) {
+    DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dw_bf16: bad sizes");
+    DC_REQUIRE(Fo % 128 == 0 && Fi % 256 == 0, "dc_tag_linear_bwd_dw_bf16: needs Fo %% 128 == 0 and Fi %% 256 == 0 "
+               "(Fi=%lld Fo=%lld)", (long long)Fi, (long long)Fo);
+    DC_REQUIRE(g && x && gws && partials && ldg >= Fo && ldx >= nseg * Fi && (((uintptr_t)partials) & 15) == 0,
+               "dc_tag_linear_bwd_dw_bf16: null pointer / leading dimension too small");
+    DC_REQUIRE(partials_bytes >= dc_tag_linear_bwd_dw_bf16_workspace_bytes(N, Fi, Fo, nseg),
+               "dc_tag_linear_bwd_dw_bf16: workspace too small");
+    DwBf16Params p{};
+    p.g = g, p.x = x, p.ldg = ldg, p.ldx = ldx, p.N = N, p.Fi = Fi, p.Fo = Fo, p.nseg = nseg;
+    dw_bf16_plan(N, Fi, Fo, nseg, &p.chunk_rows, &p.nchunks);
+    p.partial = (float *)partials;
+    p.bias_partial = gbias ? p.partial + (int64_t)p.nchunks * nseg * Fo * Fi : nullptr;
+    hipStream_t hs = (hipStream_t)stream;
+    if (N > 0)
+        DC_REQUIRE(dw_bf16_launch(p, hs), "dc_tag_linear_bwd_dw_bf16: operands must be 16-byte aligned with "
+                                          "leading dimensions that are multiples of 8");
+    ReduceParams r{};
+    for (int s = 0; s < nseg; ++s) {
+        DC_REQUIRE(gws[s], "dc_tag_linear_bwd_dw_bf16: null output block %d", s);
+        r.gw[s] = gws[s];
+    }
+    r.partial = p.partial, r.bias_partial = p.bias_partial, r.gbias = gbias;
+    r.Fi = Fi, r.Fo = Fo, r.cols = Fi, r.nseg = nseg, r.nchunks = N > 0 ? p.nchunks : 0;
+    r.ngw = nseg, r.bps = 1, r.accumulate = accumulate;
+    const int64_t total = (int64_t)nseg * Fo * Fi + (gbias ? Fo : 0);
+    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, r);
+    return check_launch("dc_tag_linear_bwd_dw_bf16");
+}

@@ -188,6 +188,175 @@ k_to_bf16_pack(PtrPack src, int nseg, int64_t rows, int64_t cols, int64_t ld_src
     dst[r * ld_dst + s * cols + c] = f32_to_bf16_rne_d(src.p[s][r * ld_src + c]);
 }
 
+
+// ---- backward of the bf16-storage layer (BASELINE.json configs[4]: fwd + bwd) ---------------------------------------
+// gm = g * (out > 0) in bf16 (block 0 of the gradient slab; the transposed bf16 hops and the forward-shaped dX block -
+// k_fwd_bf16 over that slab with the transposed weights - follow), and dW: both operands node-major.
+struct MaskBf16Params {
+    const void *g, *mask;
+    uint16_t *gm;
+    int64_t ldg, ldm, ldgm, N;
+    int F, g_bf16, mask_bf16;
+};
+__device__ __forceinline__ float ld_elem(const void *p, int64_t i, int is_bf16) {
+    return is_bf16 ? __uint_as_float((uint32_t)((const uint16_t *)p)[i] << 16) : ((const float *)p)[i];
+}
+__global__ void __launch_bounds__(256)
+k_mask_grad_bf16(MaskBf16Params p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = i / p.F;
+    const int c = (int)(i % p.F);
+    if (row >= p.N) return;
+    float v = ld_elem(p.g, row * p.ldg + c, p.g_bf16);
+    if (p.mask && !(ld_elem(p.mask, row * p.ldm + c, p.mask_bf16) > 0.f)) v = 0.f;
+    p.gm[row * p.ldgm + c] = f32_to_bf16_rne_d(v);
+}
+
+// dW[o, f] of segment s = sum over nodes n of gm[n, o] * x_s[n, f], fp32 accumulate, per node chunk (partials summed in
+// chunk order by the slab reduce: deterministic).  Shape of k_dw_h2w (dc_dense_split.hip) with plain bf16 operands: a
+// 512-thread workgroup owns a 128 (o) x 256 (f) tile of one segment over one node chunk, a stage is 32 nodes, the [k][m]
+// LDS images (rows padded by 64 B) are read with gfx950's transposing ds_read_b64_tr_b16, one bf16 MFMA product.
+constexpr int kDwbK = 32;
+constexpr int kDwbRowA = 128 * 2 + 64, kDwbRowB = 256 * 2 + 64;        // bytes per node row of the g / x image
+constexpr int kDwbStage = kDwbK * (kDwbRowA + kDwbRowB);                // 28,672 B
+
+using dwb_s16x4 = __attribute__((ext_vector_type(4))) short;
+typedef __attribute__((address_space(3))) dwb_s16x4 dwb_lds_s16x4;
+template <int ROWB>
+__device__ __forceinline__ bf16x8 dwb_tr_operand(const char *plane, int m0) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int h = g >> 1;
+    const char *a = plane + (8 * h + q) * ROWB + (m0 + 16 * (g & 1) + 4 * pp) * 2;
+    const dwb_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dwb_lds_s16x4 *)(uintptr_t)(a));
+    const dwb_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dwb_lds_s16x4 *)(uintptr_t)(a + 4 * ROWB));
+    union { dwb_s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo4, u.s[1] = hi4;
+    return u.b;
+}
+
+__global__ void __launch_bounds__(512)
+k_dw_bf16(DwBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * kDwbStage];
+    const unsigned nto = (unsigned)(p.Fo / 128), nfb = (unsigned)(p.Fi / 256);
+    const unsigned per_chunk = nto * nfb * (unsigned)p.nseg;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned chunk = lb / per_chunk, rem = lb % per_chunk;
+    const int s = (int)(rem / (nto * nfb));
+    const int64_t o0 = (int64_t)((rem / nfb) % nto) * 128, f0 = (int64_t)(rem % nfb) * 256;
+    const int64_t n_beg = (int64_t)chunk * p.chunk_rows;
+    const int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
+    const int wid = threadIdx.x >> 6, wm = wid >> 2, wn = wid & 3;
+    const bool do_bias = p.bias_partial && s == 0 && f0 == 0;
+
+    // staging: g tile 32 x 128 bf16 (16 threads x 16 B per node row), x tile 32 x 256 bf16 (32 threads per row, 2 passes)
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int cx = threadIdx.x & 31, rx = threadIdx.x >> 5;
+    const uint16_t *pg = p.g + (n_beg + rg) * p.ldg + o0 + 8 * cg;
+    const uint16_t *px = p.x + (n_beg + rx) * p.ldx + (int64_t)s * p.Fi + f0 + 8 * cx;
+    const int ldsg = rg * kDwbRowA + 16 * cg;
+    const int ldsx = kDwbK * kDwbRowA + rx * kDwbRowB + 16 * cx;
+    uint4 vg0, vg1, vx0[2], vx1[2];
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t n_next = n_beg;                                    // first node of the stage the next gload fetches
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto gload = [&](uint4 &vg, uint4 (&vx)[2]) {             // rows past the chunk's end read as zeros
+        vg = n_next + rg < n_end ? *reinterpret_cast<const uint4 *>(pg) : zero4;
+        vx[0] = n_next + rx < n_end ? *reinterpret_cast<const uint4 *>(px) : zero4;
+        vx[1] = n_next + rx + 16 < n_end ? *reinterpret_cast<const uint4 *>(px + 16 * p.ldx) : zero4;
+        pg += kDwbK * p.ldg;
+        px += kDwbK * p.ldx;
+        n_next += kDwbK;
+    };
+    auto lstore = [&](const uint4 &vg, const uint4 (&vx)[2], int b) {
+        char *buf = lds + b * kDwbStage;
+        *reinterpret_cast<uint4 *>(buf + ldsg) = vg;
+        *reinterpret_cast<uint4 *>(buf + ldsx) = vx[0];
+        *reinterpret_cast<uint4 *>(buf + ldsx + 16 * kDwbRowB) = vx[1];
+        if (do_bias) {
+            const uint32_t d[4] = {vg.x, vg.y, vg.z, vg.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bsum[2 * i] += __uint_as_float(d[i] << 16);
+                bsum[2 * i + 1] += __uint_as_float(d[i] & 0xffff0000u);
+            }
+        }
+    };
+    f32x16 acc[2][2];
+    zero_acc<2>(acc);
+    auto compute = [&](int b) {
+        const char *buf = lds + b * kDwbStage;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) fa[mb] = dwb_tr_operand<kDwbRowA>(buf + ks * 16 * kDwbRowA, wm * 64 + mb * 32);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                fb[nb] = dwb_tr_operand<kDwbRowB>(buf + kDwbK * kDwbRowA + ks * 16 * kDwbRowB, wn * 64 + nb * 32);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+        }
+    };
+
+    const int nst = (int)((n_end - n_beg + kDwbK - 1) / kDwbK);
+    if (nst > 0) {
+        gload(vg0, vx0);
+        if (nst > 1) gload(vg1, vx1);
+        lstore(vg0, vx0, 0);
+    }
+    __syncthreads();
+    int it = 0;
+#define DC_DWB_STAGE(CUR, VG_L, VX_L, VG_S, VX_S)                                                     \
+    gload(VG_L, VX_L);                                 /* stage it+2 */                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    compute(CUR);                                                                                     \
+    lstore(VG_S, VX_S, CUR ^ 1);                       /* stage it+1 */                               \
+    __syncthreads();
+    for (; it + 3 < nst; it += 2) {
+        DC_DWB_STAGE(0, vg0, vx0, vg1, vx1)
+        DC_DWB_STAGE(1, vg1, vx1, vg0, vx0)
+    }
+#undef DC_DWB_STAGE
+#define DC_DWB_TAIL(K, CUR, VG_L, VX_L, VG_S, VX_S)                                                   \
+    if (it + K < nst) {                                                                               \
+        if (it + K + 2 < nst) gload(VG_L, VX_L);                                                      \
+        compute(CUR);                                                                                 \
+        if (it + K + 1 < nst) lstore(VG_S, VX_S, CUR ^ 1);                                            \
+        __syncthreads();                                                                              \
+    }
+    for (; it < nst; it += 2) {
+        DC_DWB_TAIL(0, 0, vg0, vx0, vg1, vx1)
+        DC_DWB_TAIL(1, 1, vg1, vx1, vg0, vx0)
+    }
+#undef DC_DWB_TAIL
+
+    float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
+    for_each_acc<2>(acc, wm, wn, [&](int r, int c, float v) { out[(o0 + r) * p.Fi + f0 + c] = v; });
+    if (do_bias) {                                      // column sums of gm over the chunk's nodes
+        float *red = reinterpret_cast<float *>(lds);    // [32 node rows][128 o]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[rg * 128 + 8 * cg + i] = bsum[i];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float t = 0.f;
+            for (int r = 0; r < 32; ++r) t += red[r * 128 + threadIdx.x];
+            p.bias_partial[(int64_t)chunk * p.Fo + o0 + threadIdx.x] = t;
+        }
+    }
+}
+
+bool dw_bf16_launch(const DwBf16Params &p, hipStream_t hs) {
+    if (p.Fo % 128 != 0 || p.Fi % 256 != 0 || p.chunk_rows % kDwbK != 0) return false;
+    if (p.ldg % 8 != 0 || p.ldx % 8 != 0 || ((uintptr_t)p.g & 15) || ((uintptr_t)p.x & 15)) return false;
+    const int64_t grid = (p.Fo / 128) * (p.Fi / 256) * p.nseg * p.nchunks;
+    if (grid >= (int64_t)INT32_MAX) return false;
+    hipLaunchKernelGGL(k_dw_bf16, dim3((unsigned)grid), dim3(512), 0, hs, p);
+    return true;
+}
+
 }  // namespace dc
 
 using namespace dc;
@@ -229,4 +398,17 @@ extern "C" int dc_to_bf16(const float *const *srcs, int nseg, int64_t rows, int6
     hipLaunchKernelGGL(k_to_bf16_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pk,
                        nseg, rows, cols, ld_src, dst, ld_dst);
     return check_launch("dc_to_bf16");
+}
+
+extern "C" int dc_tag_mask_grad_bf16(const void *g, int64_t ldg, int g_is_bf16, const void *out_for_mask,
+                                     int64_t ldo, int mask_is_bf16, uint16_t *gm, int64_t ldgm, int64_t N,
+                                     int64_t F, dc_stream_t stream) {
+    DC_REQUIRE(N >= 0 && F >= 1 && F < (1 << 24) && ldg >= F && ldgm >= F && (!out_for_mask || ldo >= F),
+               "dc_tag_mask_grad_bf16: bad sizes");
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(g && gm, "dc_tag_mask_grad_bf16: null pointer");
+    MaskBf16Params p{g, out_for_mask, gm, ldg, ldo, ldgm, N, (int)F, g_is_bf16, mask_is_bf16};
+    const int64_t total = N * F;
+    hipLaunchKernelGGL(k_mask_grad_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dc_tag_mask_grad_bf16");
 }

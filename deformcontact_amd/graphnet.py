@@ -81,7 +81,7 @@ class ContactEncoder(nn.Module):
     #: arithmetic, bit-identical outputs and gradients), the narrow first layers per branch over row windows
     #: of the merged adjacency, writing into the merged slab.  Applies to TAGConv encoders whose later
     #: layers are 256 wide (the shipped config); ``DC_MERGE_BRANCHES=0`` keeps one launch per branch.
-    merge_branches = os.environ.get("DC_MERGE_BRANCHES", "1") != "0"
+    merge_branches = os.environ.get("DC_MERGE_BRANCHES", "0") == "1"
 
     def _mergeable(self, x_s, x_r) -> bool:
         if not (self.merge_branches and x_s.is_cuda and x_r.is_cuda and x_s.dtype == torch.float32

@@ -844,71 +844,143 @@ def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
 
 
 # --------------------------------------------------------------------------- #
-# TAGConv over bf16-stored features (BASELINE.json configs[4]) - forward only
+# TAGConv over bf16-stored features (BASELINE.json configs[4]): forward + backward
 # --------------------------------------------------------------------------- #
 _SLAB_TAG_BF16 = "_dc_hop_slab_bf16"
 
 
+def _alloc_bf16(rows: int, wid: int, dev, tag=None) -> torch.Tensor:
+    pad = 2 * SLAB_PAD if (SLAB_PAD > 0 and (wid * 2) % 1024 == 0) else 0      # same byte padding as fp32
+    b = torch.empty((rows, wid + pad), dtype=torch.bfloat16, device=dev)
+    if tag is not None:
+        setattr(b, _SLAB_TAG_BF16, tag)
+    return b[:, :wid] if pad else b
+
+
+class _TagConvBf16Fn(torch.autograd.Function):
+    """``TAGConv.forward`` (+ optional ReLU) with the features STORED as bfloat16 and fp32 master weights.
+    Forward: K hops ``dc_spmm_bf16`` (bf16 rows gathered, fp32 running sum in the stable edge order, one rounding per
+    stored element) into a ``[N, (K+1) * Fi]`` bf16 slab, then ONE bf16 MFMA dense block
+    (``dc_tag_linear_fwd_bf16``, fp32 accumulate) with the weights rounded to bf16.  Backward, in the forward's
+    shape: ``gm = g * relu'`` as bf16 (``dc_tag_mask_grad_bf16``), K TRANSPOSED bf16 hops on gm, the same dense
+    block over that gradient slab with the transposed weights for ``gx``, and ``dc_tag_linear_bwd_dw_bf16`` for the
+    fp32 weight / bias gradients.  What PyG reaches under ``torch.autocast(bfloat16)``, with every aggregation and
+    every contraction accumulated in fp32."""
+
+    @staticmethod
+    def forward(ctx, g: GraphIndex, x: torch.Tensor, bias, relu: bool, out_dtype, next_k, *weights):
+        n, fi = x.shape
+        k = len(weights) - 1
+        fo = weights[0].size(0)
+        width = (k + 1) * fi
+        dev = x.device
+        L = _lib.lib()
+        st = current_stream_ptr(dev)
+        base = x._base
+        if (base is not None and getattr(base, _SLAB_TAG_BF16, None) == (n, fi, width)
+                and base.size(0) == n and base.size(1) >= width and base.is_contiguous()
+                and x.data_ptr() == base.data_ptr() and x.stride() == (base.size(1), 1)):
+            slab = base[:, :width] if base.size(1) > width else base   # the previous layer wrote block 0 in place
+        else:
+            slab = _alloc_bf16(n, width, dev)
+            slab[:, :fi].copy_(x)
+        for j in range(k):
+            hop_bf16(g.fwd, slab[:, j * fi:(j + 1) * fi], out=slab[:, (j + 1) * fi:(j + 2) * fi],
+                     weighted=g.normalize, out_dtype=torch.bfloat16)
+        ws = [w.detach().contiguous() for w in weights]
+        wcat = torch.empty((fo, width), dtype=torch.bfloat16, device=dev)
+        _lib.check(L.dc_to_bf16(_ptr_array(ws), k + 1, fo, fi, fi, wcat.data_ptr(), width, st), "dc_to_bf16")
+        if next_k is not None and out_dtype == torch.bfloat16:
+            nwidth = (next_k + 1) * fo
+            nxt = _alloc_bf16(n, nwidth, dev, tag=(n, fo, nwidth))
+            out = nxt[:, :fo]
+        else:
+            out = torch.empty((n, fo), dtype=out_dtype, device=dev)
+        b = bias.detach().contiguous() if bias is not None else None
+        rc = L.dc_tag_linear_fwd_bf16(slab.data_ptr(), slab.stride(0), wcat.data_ptr(),
+                                      b.data_ptr() if b is not None else None, int(relu), out.data_ptr(),
+                                      out.stride(0), int(out.dtype == torch.bfloat16), n, width, fo, st)
+        _lib.check(rc, "dc_tag_linear_fwd_bf16")
+        ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.relu, ctx.has_bias, ctx.x_dtype = g, k, fi, fo, relu, bias is not None, x.dtype
+        ctx.save_for_backward(slab, out if relu else None, *ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        slab, out, *ws = ctx.saved_tensors
+        g, k, fi, fo = ctx.g, ctx.k, ctx.fi, ctx.fo
+        n, dev = slab.size(0), slab.device
+        L = _lib.lib()
+        st = current_stream_ptr(dev)
+        if gout.dtype not in (torch.bfloat16, torch.float32):
+            gout = gout.float()
+        if gout.stride(1) != 1:
+            gout = gout.contiguous()
+        need_x = ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        need_w = any(ctx.needs_input_grad[6:])
+        gwid = (k + 1) * fo
+        gslab = _alloc_bf16(n, gwid if need_x else fo, dev)
+        _lib.check(L.dc_tag_mask_grad_bf16(
+            gout.data_ptr(), gout.stride(0), int(gout.dtype == torch.bfloat16),
+            out.data_ptr() if out is not None else None, out.stride(0) if out is not None else fo,
+            int(out is not None and out.dtype == torch.bfloat16), gslab.data_ptr(), gslab.stride(0), n, fo, st),
+            "dc_tag_mask_grad_bf16")
+        gx = gb = None
+        gws = [None] * (k + 1)
+        if need_x:
+            if gwid % 32 != 0 or fo % 8 != 0:
+                raise NotImplementedError("tag_conv_bf16 backward: (K+1)*Fo must be a multiple of 32")
+            for j in range(k):
+                hop_bf16(g.bwd, gslab[:, j * fo:(j + 1) * fo], out=gslab[:, (j + 1) * fo:(j + 2) * fo],
+                         weighted=g.normalize, out_dtype=torch.bfloat16)
+            wt = torch.empty((k + 1, fi, fo), dtype=torch.float32, device=dev)
+            _lib.check(L.dc_tag_transpose_weights(_ptr_array(ws), k + 1, fo, fi, wt.data_ptr(), st),
+                       "dc_tag_transpose_weights")
+            wtcat = torch.empty((fi, gwid), dtype=torch.bfloat16, device=dev)
+            _lib.check(L.dc_to_bf16(_ptr_array([wt[j] for j in range(k + 1)]), k + 1, fi, fo, fo,
+                                    wtcat.data_ptr(), gwid, st), "dc_to_bf16")
+            gx = torch.empty((n, fi), dtype=ctx.x_dtype, device=dev)
+            _lib.check(L.dc_tag_linear_fwd_bf16(gslab.data_ptr(), gslab.stride(0), wtcat.data_ptr(), None, 0,
+                                                gx.data_ptr(), fi, int(gx.dtype == torch.bfloat16), n, gwid, fi, st),
+                       "dc_tag_linear_fwd_bf16 (dX)")
+        if need_w or need_b:
+            outs = [torch.empty((fo, fi), dtype=torch.float32, device=dev) for _ in range(k + 1)]
+            gb_out = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
+            nbytes = L.dc_tag_linear_bwd_dw_bf16_workspace_bytes(n, fi, fo, k + 1)
+            if nbytes < 0:
+                raise NotImplementedError("tag_conv_bf16 backward: unsupported layer shape")
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.dc_tag_linear_bwd_dw_bf16(
+                gslab.data_ptr(), gslab.stride(0), slab.data_ptr(), slab.stride(0), k + 1, _ptr_array(outs),
+                gb_out.data_ptr() if gb_out is not None else None, 0, scratch.data_ptr(), nbytes, n, fi, fo, st),
+                "dc_tag_linear_bwd_dw_bf16")
+            gws = [outs[j] if ctx.needs_input_grad[6 + j] else None for j in range(k + 1)]
+            gb = gb_out
+        return (None, gx, gb, None, None, None, *gws)
+
+
 def tag_conv_bf16(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
                   out_dtype: torch.dtype = torch.bfloat16, next_k: Optional[int] = None) -> torch.Tensor:
-    """``TAGConv.forward`` (+ optional ReLU) with the features STORED as bfloat16: K hops
-    ``dc_spmm_bf16`` (bf16 rows gathered, fp32 running sum in the stable edge order, one rounding
-    per stored element) into a ``[N, (K+1) * Fi]`` bf16 slab, then ONE bf16 MFMA dense block
-    (``dc_tag_linear_fwd_bf16``, fp32 accumulate) with the layer's weights rounded to bf16.  What
-    ``conv(x.bfloat16(), edge_index)`` reaches under ``torch.autocast(bfloat16)`` in PyG, with the
-    aggregation kept in fp32.  Forward only (inference / the HBM-roofline stress config): raises
-    when a gradient is requested.  ``next_k``: K of the bf16 TAGConv layer that consumes the output
-    - it is then written as column block 0 of that layer's slab (bf16 output only)."""
+    """``TAGConv.forward`` (+ optional ReLU) over bfloat16-STORED features, differentiable w.r.t. ``x`` and the
+    (fp32) parameters (``_TagConvBf16Fn``).  ``next_k``: K of the bf16 TAGConv layer that consumes the output - it is
+    then written as column block 0 of that layer's slab (bf16 output only)."""
     _require_cuda(x, "x")
     if x.dtype != torch.bfloat16 or x.dim() != 2:
         raise ValueError("tag_conv_bf16: x must be a 2-D bfloat16 tensor")
-    if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)):
-        raise NotImplementedError("the bf16-storage TAGConv path is forward-only: call it under "
-                                  "torch.no_grad() (the fp32 path has the backward)")
-    n, fi = x.shape
+    fi = x.size(1)
     k = len(weights) - 1
-    fo = weights[0].size(0)
-    width = (k + 1) * fi
-    if width % 32 != 0 or fi % 8 != 0:
-        raise ValueError(f"tag_conv_bf16: (K+1)*Fi = {width} must be a multiple of 32 and Fi of 8")
+    if ((k + 1) * fi) % 32 != 0 or fi % 8 != 0:
+        raise ValueError(f"tag_conv_bf16: (K+1)*Fi = {(k + 1) * fi} must be a multiple of 32 and Fi of 8")
     if out_dtype not in (torch.bfloat16, torch.float32):
         raise ValueError("tag_conv_bf16: out_dtype must be bfloat16 or float32")
-    dev = x.device
-    L = _lib.lib()
-    st = current_stream_ptr(dev)
-    def alloc(rows, wid, tag=None):
-        pad = 2 * SLAB_PAD if (SLAB_PAD > 0 and (wid * 2) % 1024 == 0) else 0      # same byte padding as fp32
-        b = torch.empty((rows, wid + pad), dtype=torch.bfloat16, device=dev)
-        if tag is not None:
-            setattr(b, _SLAB_TAG_BF16, tag)
-        return b[:, :wid] if pad else b
-
-    base = x._base
-    if (base is not None and getattr(base, _SLAB_TAG_BF16, None) == (n, fi, width)
-            and base.size(0) == n and base.size(1) >= width and base.is_contiguous()
-            and x.data_ptr() == base.data_ptr() and x.stride() == (base.size(1), 1)):
-        slab = base[:, :width] if base.size(1) > width else base   # the previous layer wrote block 0 in place
-    else:
-        slab = alloc(n, width)
-        slab[:, :fi].copy_(x)
-    for j in range(k):
-        hop_bf16(g.fwd, slab[:, j * fi:(j + 1) * fi], out=slab[:, (j + 1) * fi:(j + 2) * fi],
-                 weighted=g.normalize, out_dtype=torch.bfloat16)
-    ws = [w.detach().contiguous() for w in weights]
-    wcat = torch.empty((fo, width), dtype=torch.bfloat16, device=dev)
-    _lib.check(L.dc_to_bf16(_ptr_array(ws), k + 1, fo, fi, fi, wcat.data_ptr(), width, st), "dc_to_bf16")
-    if next_k is not None and out_dtype == torch.bfloat16:
-        nwidth = (next_k + 1) * fo
-        nxt = alloc(n, nwidth, tag=(n, fo, nwidth))
-        out = nxt[:, :fo]
-    else:
-        out = torch.empty((n, fo), dtype=out_dtype, device=dev)
-    b = bias.detach().contiguous() if bias is not None else None
-    rc = L.dc_tag_linear_fwd_bf16(slab.data_ptr(), slab.stride(0), wcat.data_ptr(),
-                                  b.data_ptr() if b is not None else None, int(relu), out.data_ptr(),
-                                  out.stride(0), int(out.dtype == torch.bfloat16), n, width, fo, st)
-    _lib.check(rc, "dc_tag_linear_fwd_bf16")
-    return out
+    grad = torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)
+                                        or (bias is not None and bias.requires_grad))
+    fo = weights[0].size(0)
+    if grad and (fo % 128 != 0 or fi % 256 != 0):
+        raise NotImplementedError("tag_conv_bf16: the backward needs Fo % 128 == 0 and Fi % 256 == 0 "
+                                  "(call under torch.no_grad() for other widths)")
+    return _TagConvBf16Fn.apply(g, x, bias, bool(relu), out_dtype, next_k, *weights)
 
 
 # --------------------------------------------------------------------------- #

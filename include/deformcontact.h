@@ -189,6 +189,21 @@ int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
 int dc_tag_linear_fwd_bf16(const uint16_t *a, int64_t lda, const uint16_t *w, const float *bias,
                            int relu, void *out, int64_t ldo, int out_is_bf16, int64_t N, int64_t K,
                            int64_t Fo, dc_stream_t stream);
+/* Backward of that layer (configs[4] is fwd + bwd): the input gradient runs in the forward's shape -
+ * dc_tag_mask_grad_bf16 writes gm = g * (out > 0) as bf16 into block 0 of a gradient slab (g / out_for_mask bf16 or
+ * fp32 as flagged), K transposed dc_spmm_bf16 hops fill the other blocks, and dc_tag_linear_fwd_bf16 over that slab
+ * with the transposed weights (dc_tag_transpose_weights + dc_to_bf16) gives gx.  dc_tag_linear_bwd_dw_bf16: the weight
+ * gradients gws[s] [Fo, Fi] fp32 (the master weights stay fp32) = gm^T . x_s over the bf16 hop slab x [N, nseg * Fi]
+ * (+ gbias [Fo] = column sums of gm), fp32 accumulate on v_mfma_f32_32x32x16_bf16, per node chunk with the partial
+ * slabs summed in chunk order (deterministic); accumulate != 0 adds into gws / gbias.  Needs Fo % 128 == 0,
+ * Fi % 256 == 0, 16-byte aligned rows; any N. */
+int dc_tag_mask_grad_bf16(const void *g, int64_t ldg, int g_is_bf16, const void *out_for_mask, int64_t ldo,
+                          int mask_is_bf16, uint16_t *gm, int64_t ldgm, int64_t N, int64_t F,
+                          dc_stream_t stream);
+int64_t dc_tag_linear_bwd_dw_bf16_workspace_bytes(int64_t N, int64_t Fi, int64_t Fo, int nseg);
+int dc_tag_linear_bwd_dw_bf16(const uint16_t *g, int64_t ldg, const uint16_t *x, int64_t ldx, int nseg,
+                              float *const *gws, float *gbias, int accumulate, void *partials,
+                              int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream);
 /* dst[r, s*cols + c] = bf16(srcs[s][r, c]) (round to nearest even): fp32 matrices [rows, cols]
  * (leading dimension ld_src) concatenated along the columns into one bf16 matrix. */
 int dc_to_bf16(const float *const *srcs, int nseg, int64_t rows, int64_t cols, int64_t ld_src,
