@@ -63,10 +63,6 @@ _SIGNATURES = {
     "dc_contact_loss_workspace_bytes": (c_int64, [c_int64]),
     "dc_contact_loss": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int64, _vp, c_int64, c_int64, c_int64, _vp, _vp,
                                 _vp, _vp, c_int64, _vp]),
-    "dc_multihop_max_segment_nodes": (c_int64, []),
-    "dc_multihop_max_segment_edges": (c_int64, []),
-    "dc_multihop_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, c_int64, c_int, c_int,
-                                c_int, c_int, _vp]),
     "dc_tag_linear_fwd": (c_int, [POINTER(_vp), POINTER(c_int64), POINTER(_vp), c_int, _vp, c_int,
                                   _vp, c_int64, c_int64, c_int64, c_int64, _vp]),
     "dc_tag_linear_bwd_dx": (c_int, [_vp, c_int64, _vp, c_int64, POINTER(_vp), c_int,

@@ -18,6 +18,8 @@
 // position q ^ ((r >> 2) & 3)) applied on the GLOBAL side of the DMA.
 #include "dc_dense.h"
 
+#include <stdlib.h>
+
 namespace dc {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -160,6 +162,173 @@ k_fwd_bf16(Bf16Params p) {
             else ((float *)p.out)[row * p.ldo + col] = v;
         }
     });
+}
+
+
+// ---- 256 x 256 tiles, all operands by LDS-DMA in a four-stage ring, one raw barrier per stage (r03) ----------------
+// The bf16 block of configs[4] is HBM-bound, not MFMA-bound: [100k, 1024] bf16 activations are read ONCE (205 MB)
+// for 52 GFLOP - 204 FLOP per byte against a machine balance of 312 - so the floor is ~45 us (the 0.41 "of the MFMA
+// peak" that 256 MB at the ~6 TB/s streaming rate allows), and what decides the time is how many bytes each CU keeps in
+// flight (MI355X_MICROARCH.md: ~24 GB/s per CU with 72 KiB outstanding).  k_fwd_bf16 above (128 x 128 tiles, loader /
+// consumer waves) and a two-buffer version of this kernel with one __syncthreads() per 64-deep K tile both ran at
+// 111 us: one K tile of prefetch covers ~1 us of MFMA work against 2 - 4 us of loaded HBM latency.
+// Here: a 512-thread workgroup owns 256 rows x 256 columns (A is read once, the 512 KB of weights come from L2), 8
+// waves as 2 x 4 with 128 x 64 per wave (eight 32 x 32 accumulator blocks), BK = 32, BOTH operands global -> LDS by
+// LDS-DMA into a ring of four 32 KB stages, THREE stages (48 KB of A per CU) in flight behind the one being multiplied,
+// retired with a counted vmcnt and ONE raw s_barrier per stage (barriers do not drain VMEM; all LDS is one array, so
+// hipcc does not guard the fragment reads against the DMAs still in flight).  The XOR swizzle of the four 16-byte
+// pieces of a row is applied to the per-lane SOURCE address; the LDS image is lane-linear.  Same products in the same
+// order as k_fwd_bf16: bit-identical results.
+constexpr int kGxBM = 256, kGxBN = 256, kGxBK = 32;
+constexpr int kGxRow = kGxBK * 2;                          // 64 bytes per LDS row
+constexpr int kGxTile = kGxBM * kGxRow;                    // 16 KB per operand and stage
+constexpr int kGxSlots = 4, kGxAhead = 3;
+
+template <bool OUT_BF16>
+__global__ void __launch_bounds__(512)
+k_fwd_bf16x(Bf16Params p) {
+    // [slot][operand]: 128 KB of ring; the epilogue's output image needs 256 x 528 B (bf16) / 128 x 1040 B (fp32): ONE array
+    __shared__ __attribute__((aligned(16))) char lds[kGxBM * (kGxBN * 2 + 16)];
+    const unsigned ntn = (unsigned)((p.Fo + kGxBN - 1) / kGxBN);
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row0 = (int64_t)(lb / ntn) * kGxBM, col0 = (int64_t)(lb % ntn) * kGxBN;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int nst = (int)(p.K / kGxBK);
+
+    // staging: wave-instruction j (of 2) of wave w fills rows 16 (2 w + j) .. + 15 of a tile (1 KiB, lane-linear):
+    // lane l is row 16 c + (l >> 2), position l & 3, and fetches the piece that belongs there: q = position ^ ((row >> 2) & 3)
+    unsigned offA[2], offB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rl = 16 * (2 * wid + j) + (lane >> 2);
+        const int q = (lane & 3) ^ ((rl >> 2) & 3);
+        int64_t row = row0 + rl, col = col0 + rl;
+        row = row < p.N ? row : p.N - 1;
+        col = col < p.Fo ? col : p.Fo - 1;
+        offA[j] = (unsigned)((row - row0) * p.lda + 8 * q);                 // elements
+        offB[j] = (unsigned)((col - col0) * p.K + 8 * q);
+    }
+    const uint16_t *baseA = p.a + row0 * p.lda;
+    const uint16_t *baseB = p.w + col0 * p.K;
+    auto stage = [&](int slot) {                                            // 4 DMA instructions per wave and stage
+        char *ta = lds + (2 * slot) * kGxTile, *tb = ta + kGxTile;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(baseA + offA[j]),
+                                             (void __attribute__((address_space(3))) *)(ta + (2 * wid + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(baseB + offB[j]),
+                                             (void __attribute__((address_space(3))) *)(tb + (2 * wid + j) * 1024), 16, 0, 0);
+        }
+        baseA += kGxBK;
+        baseB += kGxBK;
+    };
+    // fragments: lane (fr = lane & 31, fh = lane >> 5) of k-step t reads k = 16 t + 8 fh .. + 7 of its row = piece 2 t + fh
+    const int fr = lane & 31, fh = lane >> 5;
+    int fragA[2], fragB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        // rows wm * 128 + mb * 32 + fr and wn * 64 + nb * 32 + fr: (row >> 2) & 3 == (fr >> 2) & 3
+        fragA[t] = (wm * 128 + fr) * kGxRow + 16 * ((2 * t + fh) ^ ((fr >> 2) & 3));
+        fragB[t] = (wn * 64 + fr) * kGxRow + 16 * ((2 * t + fh) ^ ((fr >> 2) & 3));
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    // (vmcnt retires in order, so the L2-resident weights cannot ride a shallower ring than the activations: a weight
+    // tile issued one stage ahead would sit BEHIND the activation tiles issued before it and waiting for it would
+    // drain them - both operands share the ring depth)
+    for (int s = 0; s < kGxAhead && s < nst; ++s) stage(s);
+    for (int it = 0; it < nst; ++it) {
+        // stage `it` has landed once only the DMA instructions of the LATER stages (4 per wave each, at most two of
+        // them issued so far) are outstanding; the barrier publishes every wave's pieces and says that everybody is
+        // done with stage it - 1, whose slot then takes stage it + 3
+        const int later = nst - 1 - it;
+        if (later >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);            // vmcnt(8)
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);       // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | 0);                       // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (it + kGxAhead < nst) stage((it + kGxAhead) & (kGxSlots - 1));
+        const char *ta = lds + (2 * (it & (kGxSlots - 1))) * kGxTile, *tb = ta + kGxTile;
+        bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) fb[t][nb] = *reinterpret_cast<const bf16x8 *>(tb + fragB[t] + nb * 32 * kGxRow);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) fa[t][mb] = *reinterpret_cast<const bf16x8 *>(ta + fragA[t] + mb * 32 * kGxRow);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][mb], fb[t][nb], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // epilogue.  The C/D fragment is column-per-lane ((reg, lane) -> row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col
+    // lane & 31): stored as it stands, a wave-instruction writes two 64-byte pieces (bf16) - 128 such instructions per
+    // wave, 42 of the kernel's 129 us (r03 ablation).  The tile goes through LDS instead (the ring is free now) and leaves
+    // as full rows, 16 bytes per lane: bf16 in one pass (256 rows x 512 B), fp32 in two (128 rows x 1 KiB each).
+    const bool relu = p.relu != 0;
+    const int c = lane & 31, h = lane >> 5;
+    constexpr int esz = OUT_BF16 ? 2 : 4;
+    constexpr int rs = kGxBN * esz + 16;                      // LDS row stride: + 16 B keeps the two half-waves on
+    constexpr int npass = OUT_BF16 ? 1 : 2;                   // disjoint banks
+    const bool vec_ok = ((p.ldo * esz) % 16 == 0) && (((uintptr_t)p.out) % 16 == 0);
+    __syncthreads();
+    for (int pass = 0; pass < npass; ++pass) {
+        if (npass == 1 || wm == pass) {
+            const int rbase = npass == 1 ? wm * 128 : 0;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int64_t col = col0 + wn * 64 + nb * 32 + c;
+                const float bcol = (p.bias && col < p.Fo) ? p.bias[col] : 0.f;
+                char *dst = lds + (wn * 64 + nb * 32 + c) * esz;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rl = rbase + mb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        float v = acc[mb][nb][reg] + bcol;
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (OUT_BF16) *reinterpret_cast<uint16_t *>(dst + rl * rs) = f32_to_bf16_rne_d(v);
+                        else *reinterpret_cast<float *>(dst + rl * rs) = v;
+                    }
+            }
+        }
+        __syncthreads();
+        constexpr int rows_here = npass == 1 ? kGxBM : kGxBM / 2;
+        constexpr int tpr = kGxBN * esz / 16;                  // threads per row (16 B each): 32 (bf16) / 64 (fp32)
+        constexpr int rpp = 512 / tpr;                        // rows per sweep
+        const int tr = threadIdx.x / tpr, tc = threadIdx.x % tpr;
+        constexpr int epl = 16 / esz;                         // elements per lane
+        for (int r = tr; r < rows_here; r += rpp) {
+            const int64_t row = row0 + (npass == 1 ? 0 : pass * 128) + r;
+            const int64_t col = col0 + (int64_t)tc * epl;
+            if (row >= p.N || col >= p.Fo) continue;
+            const uint4 q = *reinterpret_cast<const uint4 *>(lds + r * rs + tc * 16);
+            char *o = (char *)p.out + (row * p.ldo + col) * esz;
+            if (vec_ok && col + epl <= p.Fo) {
+                *reinterpret_cast<uint4 *>(o) = q;
+            } else {                                          // ragged right edge / unaligned output: element by element
+                const char *src = reinterpret_cast<const char *>(&q);
+                for (int e = 0; e < epl && col + e < p.Fo; ++e)
+                    for (int bb = 0; bb < esz; ++bb) o[e * esz + bb] = src[e * esz + bb];
+            }
+        }
+        if (pass + 1 < npass) __syncthreads();
+    }
 }
 
 // fp32 [rows, cols] (ld) -> bf16 (round to nearest even), optionally K-concatenating nseg matrices:
@@ -377,6 +546,16 @@ extern "C" int dc_tag_linear_fwd_bf16(const uint16_t *a, int64_t lda, const uint
     DC_REQUIRE(lda * 128 < ((int64_t)1 << 31) && K * 128 < ((int64_t)1 << 31),
                "dc_tag_linear_fwd_bf16: leading dimension too large for 32-bit tile offsets");
     Bf16Params p{a, w, bias, out, lda, ldo, N, K, Fo, relu, out_is_bf16};
+    // 256 x 256 tiles (one per CU) once a launch has enough of them to fill most of the chip and K is whole 64-deep
+    // tiles; else the 128 x 128 kernel.  DC_BF16_X=0 / 1 forces the choice (experiments; results are bit-identical).
+    static const int force = getenv("DC_BF16_X") ? atoi(getenv("DC_BF16_X")) : -1;
+    const int64_t xtiles = ((N + kGxBM - 1) / kGxBM) * ((Fo + kGxBN - 1) / kGxBN);
+    const bool xok = K % kGxBK == 0 && lda * kGxBM < ((int64_t)1 << 31) && K * kGxBN < ((int64_t)1 << 31);
+    if (xok && (force == 1 || (force != 0 && xtiles >= 160))) {
+        if (out_is_bf16) hipLaunchKernelGGL(k_fwd_bf16x<true>, dim3((unsigned)xtiles), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(k_fwd_bf16x<false>, dim3((unsigned)xtiles), dim3(512), 0, stream, p);
+        return check_launch("dc_tag_linear_fwd_bf16");
+    }
     const int64_t grid = ((N + 127) / 128) * ((Fo + BN - 1) / BN);
     hipLaunchKernelGGL(k_fwd_bf16, dim3((unsigned)grid), dim3(512), 0, stream, p);
     return check_launch("dc_tag_linear_fwd_bf16");

@@ -130,7 +130,6 @@ class GraphIndex:
         nbytes = _lib.lib().dc_graph_workspace_bytes(self.num_input_edges, n)
         self._workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         self._pos_fwd = None
-        self._segments = False          # not computed yet
         self._bwd_to_fwd = None
         self._num_edges = None if self_loops else self.num_input_edges
         self.rebuild()
@@ -169,7 +168,6 @@ class GraphIndex:
                 self.edge_index.data_ptr(), self.num_input_edges, self.num_nodes, int(self.self_loops), *out)
             _lib.check(rc, "dc_graph_build")
         self._pos_fwd = self._bwd_to_fwd = None
-        self._segments = False
         if self.self_loops:
             self._num_edges = None
 
@@ -224,42 +222,6 @@ class GraphIndex:
     def record_stream(self, stream) -> None:
         for t in self.tensors():
             t.record_stream(stream)
-
-    def segments(self):
-        """Node ranges no edge leaves (one or more whole meshes of the batch each), merged greedily
-        up to the LDS capacity of ``dc_multihop_f32``; ``None`` when some connected block is too
-        large (then the hops run one launch at a time).  Computed once (synchronises)."""
-        if self._segments is not False:
-            return self._segments
-        L = _lib.lib()
-        cap_n, cap_e = L.dc_multihop_max_segment_nodes(), L.dc_multihop_max_segment_edges()
-        n, ei = self.num_nodes, self.edge_index
-        self._segments = None
-        if n == 0 or ei is None:
-            return None
-        idx = torch.arange(n, device=self.device)
-        hi, lo = idx.clone(), idx.clone()
-        if ei.size(1) > 0:
-            a, b = ei[0].clamp(0, n - 1), ei[1].clamp(0, n - 1)
-            hi.scatter_reduce_(0, a, b, "amax").scatter_reduce_(0, b, a, "amax")
-            lo.scatter_reduce_(0, a, b, "amin").scatter_reduce_(0, b, a, "amin")
-        pm = torch.cummax(hi, 0).values                      # max reach of nodes 0..i
-        sm = torch.cummin(lo.flip(0), 0).values.flip(0)      # min reach of nodes i..n-1
-        ok = (pm[:-1] < idx[1:]) & (sm[1:] >= idx[1:])       # a cut before node b is clean
-        cuts = [0] + (torch.nonzero(ok).flatten() + 1).tolist() + [n]
-        eptr = self.fwd.ptr[torch.tensor(cuts, device=self.device)].tolist()
-        seg, start, nodes, edges = [0], 0, 0, 0
-        for i in range(len(cuts) - 1):
-            cn, ce = cuts[i + 1] - cuts[i], eptr[i + 1] - eptr[i]
-            if cn > cap_n or ce > cap_e:
-                return None
-            if nodes + cn > cap_n or edges + ce > cap_e:
-                seg.append(cuts[i])
-                nodes, edges = 0, 0
-            nodes, edges = nodes + cn, edges + ce
-        seg.append(n)
-        self._segments = (torch.tensor(seg, dtype=torch.int32, device=self.device), len(seg) - 1)
-        return self._segments
 
     def pos_in_fwd(self) -> torch.Tensor:
         """``pos[e]`` = position of edge id ``e`` in the destination-sorted order."""
@@ -333,9 +295,6 @@ class GraphWindow:
     @property
     def capacity(self) -> int:
         return self.merged.capacity
-
-    def segments(self):
-        return None
 
     def validate(self) -> None:
         self.merged.validate()

@@ -206,16 +206,6 @@ DENSE_PRODUCTS = int(os.environ.get("DC_DENSE_PRODUCTS", "6"))
 DENSE_F16X2 = os.environ.get("DC_DENSE_F16X2", "1") != "0"
 
 
-#: Run the K chained hops of a TAGConv layer (forward: x_k = A x_{k-1}; backward: g_{k-1} = G_{k-1}
-#: + A^T g_k) as ONE launch with the features and adjacency of each mesh resident in LDS
-#: (``dc_multihop_f32``) whenever the batch splits into small enough segments; bit-identical to
-#: hop-by-hop.  OFF by default: measured on MI355X (r01, ``tools/kbench.py --multihop``) the
-#: L2-served single hops are faster at the everyday-deform shape (F = 256: 47 vs 54 us forward,
-#: 52 vs 74 us backward for three hops) - one 1024-thread workgroup per CU cannot hide the
-#: dependent LDS gathers the way 32 resident waves hide L2 latency.  ``DC_MULTIHOP=1`` enables it.
-MULTIHOP = os.environ.get("DC_MULTIHOP", "0") == "1"
-
-
 def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool,
                  rowmax: Optional[torch.Tensor] = None, transposed: bool = False,
                  rowmax_has_block0: bool = False) -> None:
@@ -227,15 +217,6 @@ def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bo
     if k == 0:
         return
     adj = g.bwd if (backward or transposed) else g.fwd
-    seg = g.segments() if (MULTIHOP and rowmax is None and not transposed) else None
-    if seg is not None:
-        w = adj.w if g.normalize else None
-        rc = _lib.lib().dc_multihop_f32(
-            adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
-            seg[0].data_ptr(), seg[1], slab.data_ptr(), slab.stride(0), f, k,
-            k if backward else 0, -1 if backward else 1, int(backward), current_stream_ptr(slab.device))
-        _lib.check(rc, "dc_multihop_f32")
-        return
     blocks = [slab[:, j * f:(j + 1) * f] for j in range(k + 1)]
     if backward:
         for j in range(k, 0, -1):

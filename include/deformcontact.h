@@ -224,22 +224,6 @@ int dc_contact_loss(const int32_t *ptr_f, const int32_t *other_f, const int32_t 
                     float *losses /* [2] */, void *workspace, int64_t workspace_bytes,
                     dc_stream_t stream);
 
-/* ---- K chained hops in one launch (block-diagonal batches) -------------------
- * TAGConv.forward calls propagate K = 3 times in a row (x_k = A_hat x_{k-1}); its backward runs
- * the chain g_{k-1} = G_{k-1} + A_hat^T g_k.  For a batch whose nodes split into segments no edge
- * leaves (Batch.from_data_list: one mesh per segment), one workgroup per (segment, column slice)
- * keeps the slice in LDS across all K hops.  `slab` [N, ld] holds K+1 column blocks of width F;
- * step s = 0..K-1 reads block src_block + s*dir and writes block src_block + (s+1)*dir
- * (dir = +1 forward, -1 backward), adding what the destination block already holds when
- * accumulate != 0.  seg_ptr [nseg+1] (device) are the node ranges; the CALLER guarantees every
- * segment has at most dc_multihop_max_segment_nodes() nodes and ..._edges() edges (LDS capacity)
- * and that no edge leaves its segment.  Bit-identical to K dc_spmm_f32 calls. */
-int64_t dc_multihop_max_segment_nodes(void);
-int64_t dc_multihop_max_segment_edges(void);
-int dc_multihop_f32(const int32_t *ptr, const int32_t *other, const float *w,
-                    const int32_t *seg_ptr, int64_t nseg, float *slab, int64_t ld, int64_t F,
-                    int K, int src_block, int dir, int accumulate, dc_stream_t stream);
-
 /* ---- dense block of TAGConv ------------------------------------------------
  * Replaces `out = lins[0](x); out = out + lins[k](x_k) ...; out = out + bias`
  * (nn/conv/tag_conv.py forward) = up to DC_MAX_SEG bias-free F.linear calls,

@@ -585,18 +585,17 @@ def test_conv_forward_backward_vs_oracle(kind, n, e, fi, fo):
         assert_parity(_np(p.grad), _np(gc[name].grad), _np(g64[name].grad), TOL, name)
 
 
-@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x3", "bf16x3_multihop"])
+@pytest.mark.parametrize("path", ["fp32_mfma", "bf16x3"])
 def test_tagconv_alternative_dense_paths_vs_oracle(path):
     """The dense-block implementations the default (scaled fp16x2) replaces stay selectable
-    (DC_DENSE_SPLIT=0, DC_DENSE_F16X2=0, DC_MULTIHOP=1): same parity bar on a wide layer."""
-    saved = (ops.DENSE_SPLIT_BF16, ops.DENSE_F16X2, ops.MULTIHOP)
+    (DC_DENSE_SPLIT=0: the auditable strict-fp32 line of bench.py; DC_DENSE_F16X2=0): same parity bar on a wide layer."""
+    saved = (ops.DENSE_SPLIT_BF16, ops.DENSE_F16X2)
     try:
         ops.DENSE_SPLIT_BF16 = path != "fp32_mfma"
         ops.DENSE_F16X2 = False
-        ops.MULTIHOP = path.endswith("multihop")
         test_conv_forward_backward_vs_oracle("TAGConv", 150, 1100, 256, 256)
     finally:
-        ops.DENSE_SPLIT_BF16, ops.DENSE_F16X2, ops.MULTIHOP = saved
+        ops.DENSE_SPLIT_BF16, ops.DENSE_F16X2 = saved
 
 
 @pytest.mark.parametrize("backbone,fname", [("TAGConv", "graphnet_tag_h32.npz"),
@@ -1047,50 +1046,6 @@ def test_encoder_slab_handoff_any_hidden_width(hidden):
     rp, tp = dict(ref.named_parameters()), dict(ref64.named_parameters())
     for name, p in enc.named_parameters():
         assert_parity(_np(p.grad), _np(rp[name].grad), _np(tp[name].grad), TOL, name)
-
-
-def _block_diag_graph(sizes, edges_per, seed):
-    """Batch of random multigraphs (one per segment), PyG-style concatenation."""
-    parts, off = [], 0
-    for i, (n, e) in enumerate(zip(sizes, edges_per)):
-        parts.append(random_multigraph(n, e, seed + i) + off)
-        off += n
-    return np.concatenate(parts, axis=1), off
-
-
-@pytest.mark.parametrize("f", [21, 25, 32, 100, 256])
-@pytest.mark.parametrize("sizes,edges_per", [((300, 1, 762, 40), (2000, 0, 4560, 300)),
-                                             ((1024, 1024), (6132, 6132))])
-def test_multihop_bit_identical_to_single_hops(f, sizes, edges_per):
-    from deformcontact_amd import ops as O
-    ei, n = _block_diag_graph(sizes, edges_per, 3)
-    g = GraphIndex(torch.from_numpy(ei).to(DEV), n)
-    seg = g.segments()
-    assert seg is not None and seg[1] >= 1
-    sp = _np(seg[0])
-    assert sp[0] == 0 and sp[-1] == n and np.all(np.diff(sp) <= 1024)
-    k = 3
-    base = torch.from_numpy(hashed_uniform((n, (k + 1) * f + 4), f, 2.0)).to(DEV)[:, :(k + 1) * f]
-    for backward in (False, True):
-        a, b = base.clone(), base.clone()
-        old = O.MULTIHOP
-        try:
-            O.MULTIHOP = True
-            O.chained_hops(g, a, f, k, backward)
-            O.MULTIHOP = False
-            O.chained_hops(g, b, f, k, backward)
-        finally:
-            O.MULTIHOP = old
-        assert torch.equal(a, b), f"multihop differs (backward={backward}): {rel_err(_np(a), _np(b)):.3e}"
-
-
-def test_multihop_falls_back_on_large_components():
-    ei = random_multigraph(3000, 20000, 1)                 # one big connected blob
-    g = GraphIndex(torch.from_numpy(ei).to(DEV), 3000)
-    assert g.segments() is None
-    conv = dc.nn.TAGConv(16, 16).to(DEV)
-    x = torch.randn(3000, 16, device=DEV)
-    assert torch.isfinite(conv(x, torch.from_numpy(ei).to(DEV))).all()
 
 
 # --------------------------------------------------------------------------- #

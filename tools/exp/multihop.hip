@@ -1,3 +1,7 @@
+// tools/exp/multihop.hip -- EXPERIMENT retired from the product library in r03 (was dc_multihop.hip, off by default since r01):
+// K chained hops with the meshes resident in LDS.  Bit-identical to K single hops; slower than them on MI355X at the
+// everyday-deform shape (F = 256: 52.8 vs 49.1 us for three hops, F = 21: 40.0 vs 30.7 us; profiles/r02/k_kbench_multihop.txt).
+// Kept for the record; not built by deformcontact_amd/build.py.
 // dc_multihop.hip -- K chained hops of a block-diagonal batch in ONE launch, features in LDS.
 //
 // A PyG batch is a block-diagonal union of small meshes (everyday-deform: 1,024 / 762 nodes
@@ -12,7 +16,7 @@
 //
 // Arithmetic and order are those of dc_spmm_f32 (separately rounded multiply and add, stable
 // edge order, addend first), so results are bit-identical to K single hops.
-#include "dc_common.h"
+#include "../../deformcontact_amd/csrc/dc_common.h"
 
 #pragma clang fp contract(off)
 

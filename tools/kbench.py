@@ -130,29 +130,5 @@ def main():
             print(f"hop {name:6s} F={f:4d} (ld {4 * f}): {ms * 1e3:8.1f} us  {nbytes / ms / 1e6:9.1f} GB/s algorithmic")
 
 
-if __name__ == "__main__" and "--multihop" not in sys.argv:
+if __name__ == "__main__":
     main()
-
-
-def multihop_bench(reps=20):
-    import torch
-    from deformcontact_amd import ops as O, synth
-    from deformcontact_amd.graph import GraphIndex
-    dev = torch.device("cuda:0")
-    rest, _, rig = synth.make_batch(32)
-    for name, b in (("soft", rest), ("rigid", rig)):
-        n = b.x.shape[0]
-        g = GraphIndex(b.edge_index.to(dev), n)
-        g.segments()
-        for f in (256, 21):
-            slab = torch.randn(n, 4 * f if f == 256 else 96, device=dev)
-            for bw in (False, True):
-                res = {}
-                for mh in (True, False):
-                    O.MULTIHOP = mh
-                    res[mh] = timeit(lambda: O.chained_hops(g, slab, f, 3, bw), reps)
-                print(f"chained hops {name:5s} F={f:3d} {'bwd' if bw else 'fwd'}: multihop {res[True]*1e3:7.1f} us   3 single hops {res[False]*1e3:7.1f} us")
-
-
-if __name__ == "__main__" and "--multihop" in sys.argv:
-    multihop_bench()
