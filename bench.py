@@ -74,6 +74,8 @@ def parse():
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--workload", default="everyday", choices=["everyday", "radius100k"],
                     help="radius100k: only the bf16 100k-point radius-graph stress (BASELINE.json configs[4])")
+    ap.add_argument("--no-merged", action="store_true",
+                    help="skip the extra line with both branches merged into one block-diagonal launch set")
     ap.add_argument("--no-radius100k", action="store_true",
                     help="leave the radius100k extra out of the default line")
     ap.add_argument("--distinct-batches", type=int, default=4,
@@ -1044,6 +1046,30 @@ def main():
                                       "dense_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32), DC_DENSE_SPLIT=0"}
             finally:
                 ops.DENSE_SPLIT_BF16 = keep
+        if world == 1 and not args.no_merged and not merged and ops.DENSE_SPLIT_BF16 and ops.DENSE_F16X2:
+            # the OTHER encoder path, same step definition: both branches as one block-diagonal problem (one merged
+            # adjacency, 6 instead of 12 F=256 hop launches, grouped dense launches; DC_MERGE_BRANCHES=1).  Same bits
+            # out; measured slower than two overlapped per-branch streams, hence opt-in - numbers kept side by side.
+            was_merged, enc.merge_branches = enc.merge_branches, True
+            try:
+                if enc._mergeable(rest.x, rig.x):
+                    k = max(5, args.steps // 2)
+                    el = timed(make_mode("serial"), k, 3)
+                    fn_m, nl_m, comp_m, _ = pmc_hop.hop_sequence(dev, parts, True, f)
+                    t_m = graph_time(fn_m, nl_m, calls=5) * nl_m
+                    mf = dense_roofline_grouped(dev, parts, args.kernel_reps // 4 or 1)
+                    out["merged_branches"] = {
+                        "value": round(edges_per_rank * k / el / 1e6, 3), "unit": "M edges/s",
+                        "ms_per_step": round(el / k * 1e3, 4), "steps": k,
+                        "hop": {"launches_per_step": nl_m, "avg_launch_us": round(t_m / nl_m * 1e3, 2),
+                                "compulsory_bytes_per_launch": int(comp_m / nl_m),
+                                "frac_of_8TBps": round(comp_m / t_m / 1e6 / HBM_PEAK_GBS, 4)},
+                        "dense_grouped": {"frac_of_2500_TF": mf["frac"], "in_sequence_us": mf["in_sequence_us"]},
+                        "note": "ContactEncoder.merge_branches = True: one dc_graph_build_parts, first layers over "
+                                "row windows, layer 2 of both branches as single launches; outputs and gradients "
+                                "bit-identical to the default path (tests/test_merged.py)"}
+            finally:
+                enc.merge_branches = was_merged
         if world == 1 and not args.no_radius100k:
             try:
                 out["radius100k"] = radius100k(dev, args.kernel_reps // 3 or 3)

@@ -91,19 +91,49 @@ k_init(Build b) {
     }
 }
 
+// Block-local histogram (r03).  Consecutive edges of a mesh batch name nearby nodes (triangle-major edge order, locally
+// numbered meshes): the 256 edges of a block hit ~100 distinct keys inside a window of a few hundred ids, yet each edge
+// paid a global int atomic (k_count / k_fill were 11 - 12 us each at B = 32, atomic-latency bound).  Here a block keeps
+// kBins counters in LDS for the id window [base, base + kBins) around its first edge, counts in-window keys there and
+// sends ONE global atomic per non-empty bin; keys outside the window (arbitrary graphs) keep the direct global atomic.
+constexpr int kBins = 1024;
+
 __global__ void __launch_bounds__(256)
 k_count(Build b, int nsides) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= b.E) return;
-    int64_t src, dst;
-    if (!load_edge(b.ed, e, src, dst)) {
-        atomicOr(b.status, 1);
-        return;
+    __shared__ int32_t bins[2][kBins];
+    __shared__ int64_t base[2];
+    const int64_t e0 = (int64_t)blockIdx.x * blockDim.x, e = e0 + threadIdx.x;
+    for (int i = threadIdx.x; i < 2 * kBins; i += 256) (&bins[0][0])[i] = 0;
+    if (threadIdx.x == 0) {
+        int64_t src = 0, dst = 0;
+        load_edge(b.ed, e0, src, dst);                    // e0 < E: the grid covers E edges (garbage ids only move the window)
+        const int64_t k0 = b.s[0].key_is_dst ? dst : src, o0 = b.s[0].key_is_dst ? src : dst;
+        base[0] = k0 - kBins / 2, base[1] = o0 - kBins / 2;
     }
-    const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
-    if (b.self_loops && k == o) return;
-    atomicAdd(&b.s[0].cnt[k], 1);
-    if (nsides == 2) atomicAdd(&b.s[1].cnt[o], 1);   // side 1 groups by side 0's other row
+    __syncthreads();
+    if (e < b.E) {
+        int64_t src, dst;
+        if (!load_edge(b.ed, e, src, dst)) {
+            atomicOr(b.status, 1);
+        } else {
+            const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
+            if (!(b.self_loops && k == o)) {
+                const int64_t rk = k - base[0], ro = o - base[1];
+                if (rk >= 0 && rk < kBins) atomicAdd(&bins[0][rk], 1);
+                else atomicAdd(&b.s[0].cnt[k], 1);
+                if (nsides == 2) {                        // side 1 groups by side 0's other row
+                    if (ro >= 0 && ro < kBins) atomicAdd(&bins[1][ro], 1);
+                    else atomicAdd(&b.s[1].cnt[o], 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int sd = 0; sd < nsides; ++sd)
+        for (int i = threadIdx.x; i < kBins; i += 256) {
+            const int c = bins[sd][i];
+            if (c) atomicAdd(&b.s[sd].cnt[base[sd] + i], c);
+        }
 }
 
 // ---- exclusive scan of cnt[0..N) into ptr[0..N], ptr[N] = total -----------
@@ -258,20 +288,55 @@ k_scan_apply(Build b, int64_t ntiles) {
     if (blockIdx.x == 0 && threadIdx.x == 0) sd.ptr[b.N] = sd.tiles[ntiles];
 }
 
+// Bucket every edge id into its group (arbitrary order inside a group; k_emit ranks).  Same block-local scheme as
+// k_count: an edge takes its slot inside the block's share of a group from an LDS counter, the block reserves the share
+// with ONE global atomic per non-empty bin, then every edge writes at reserved base + local slot.
 __global__ void __launch_bounds__(256)
 k_fill(Build b, int nsides) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int32_t bins[2][kBins];
+    __shared__ int64_t base[2];
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x, t = t0 + threadIdx.x;
+    for (int i = threadIdx.x; i < 2 * kBins; i += 256) (&bins[0][0])[i] = 0;
+    if (threadIdx.x == 0) {
+        int64_t k0 = t0 - b.E, o0 = t0 - b.E;              // a block of appended self loops: keys = node ids
+        if (t0 < b.E) {
+            int64_t src = 0, dst = 0;
+            load_edge(b.ed, t0, src, dst);
+            k0 = b.s[0].key_is_dst ? dst : src, o0 = b.s[0].key_is_dst ? src : dst;
+        }
+        base[0] = k0 - kBins / 2, base[1] = o0 - kBins / 2;
+    }
+    __syncthreads();
+    int64_t key[2] = {-1, -1};                             // -1: this thread places nothing on that side
     if (t < b.E) {
         int64_t src, dst;
-        if (!load_edge(b.ed, t, src, dst)) return;
-        const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
-        if (b.self_loops && k == o) return;
-        b.s[0].tmp[atomicAdd(&b.s[0].cur[k], 1)] = (int32_t)t;
-        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cur[o], 1)] = (int32_t)t;
+        if (load_edge(b.ed, t, src, dst)) {
+            const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
+            if (!(b.self_loops && k == o)) key[0] = k, key[1] = o;
+        }
     } else if (b.self_loops && t < b.E + b.N) {
-        const int64_t k = t - b.E;
-        b.s[0].tmp[atomicAdd(&b.s[0].cur[k], 1)] = (int32_t)t;
-        if (nsides == 2) b.s[1].tmp[atomicAdd(&b.s[1].cur[k], 1)] = (int32_t)t;
+        key[0] = key[1] = t - b.E;
+    }
+    int slot[2] = {-1, -1};                                // local slot inside the block's share (-1: direct global)
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+        if (sd >= nsides || key[sd] < 0) continue;
+        const int64_t r = key[sd] - base[sd];
+        if (r >= 0 && r < kBins) slot[sd] = atomicAdd(&bins[sd][r], 1);
+    }
+    __syncthreads();
+    for (int sd = 0; sd < nsides; ++sd)                    // bins: count -> reserved global base
+        for (int i = threadIdx.x; i < kBins; i += 256) {
+            const int c = bins[sd][i];
+            if (c) bins[sd][i] = atomicAdd(&b.s[sd].cur[base[sd] + i], c);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+        if (sd >= nsides || key[sd] < 0) continue;
+        const int pos = slot[sd] >= 0 ? bins[sd][key[sd] - base[sd]] + slot[sd]
+                                      : atomicAdd(&b.s[sd].cur[key[sd]], 1);
+        b.s[sd].tmp[pos] = (int32_t)t;
     }
 }
 

@@ -242,6 +242,7 @@ def test_encoder_merged_path_equals_per_branch_path(batch, soft_v, res, overlap)
     torch.manual_seed(0)
     enc = ContactEncoder([21, 25], 256).to(DEV)
     enc.overlap_branches = overlap
+    enc.merge_branches = True
     assert enc._mergeable(rest.x, rig.x)
     g_rest = torch.randn(rest.x.shape[0], 256, device=DEV)
     g_rig = torch.randn(rig.x.shape[0], 256, device=DEV)
