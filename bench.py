@@ -995,10 +995,10 @@ def main():
             for tag, adj, x, o in (("fwd", g.fwd, slab[:, :f], slab[:, f:2 * f]),
                                    ("bwd", g.bwd, slab[:, 2 * f:3 * f], slab[:, 3 * f:])):
                 ms = graph_time(lambda: ops.hop(adj, x, out=o, rowmax=rm, rowmax_mode=2), 1)
-                nb = hop_bytes_compulsory(n, e, f, False)
-                per_case[f"{name}_{tag}"] = {"compulsory_bytes": nb, "us": round(ms * 1e3, 2),
-                                             "GBps": round(nb / ms / 1e6, 1),
-                                             "frac": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                cb = hop_bytes_compulsory(n, e, f, False)
+                per_case[f"{name}_{tag}"] = {"compulsory_bytes": cb, "us": round(ms * 1e3, 2),
+                                             "GBps": round(cb / ms / 1e6, 1),
+                                             "frac": round(cb / ms / 1e6 / HBM_PEAK_GBS, 4)}
         # the roofline figure: the F=256 hop launches of a step IN THE ORDER AND ON THE BUFFERS a step uses -
         # the forward chain block0 -> 1 -> 2 -> 3 of the layer-2 slab (each hop reads what the previous one
         # wrote) and the same chain over the transposed adjacency on the gradient slab, all with the row-maxima

@@ -55,7 +55,7 @@ def run():
     from deformcontact_amd import synth
     dev = torch.device("cuda:0")
     rest, _, rig = synth.make_batch(32)
-    merged = os.environ.get("DC_MERGE_BRANCHES", "1") != "0"
+    merged = os.environ.get("DC_MERGE_BRANCHES", "0") == "1"
     fn, _, _, _ = hop_sequence(dev, [(rest.edge_index.to(dev), rest.x.shape[0]),
                                      (rig.edge_index.to(dev), rig.x.shape[0])], merged)
     for _ in range(10):                          # the launches bench.py prices, in the same order
@@ -80,8 +80,22 @@ def parse(fetch_dir, write_dir):
     print(json.dumps(out, indent=1))
 
 
+def parse_l2(d):
+    """Averages per k_spmm_wave launch of every counter in a rocprofv3 --pmc run of this script (e.g.
+    TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum: L1 -> L2 read requests and L2 -> fabric read requests, 128 / 64-byte units
+    as MI355X_MICROARCH.md states them)."""
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if "k_spmm_wave" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    print(json.dumps({k: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for k, v in acc.items()}, indent=1))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] == "--parse":
+    if len(sys.argv) >= 3 and sys.argv[1] == "--parse-l2":
+        parse_l2(sys.argv[2])
+    elif len(sys.argv) >= 4 and sys.argv[1] == "--parse":
         parse(sys.argv[2], sys.argv[3])
     else:
         run()

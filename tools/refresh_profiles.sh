@@ -22,6 +22,14 @@ timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/
 timeout -s KILL 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d "$R/$O/pmc_a" -- python3 "$R/tools/pmc_dense.py" > "$R/$O/pmc_a.log" 2>&1
 timeout -s KILL 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$R/$O/pmc_b" -- python3 "$R/tools/pmc_dense.py" > "$R/$O/pmc_b.log" 2>&1
 (cd "$R" && python tools/pmc_dense.py --parse "$O/pmc_a" "$O/pmc_b" > "$O/dense_pmc.json" 2> "$O/dense_pmc.err")
+# L1 -> L2 and L2 -> fabric read requests of the F=256 hop: per-branch launches and ONE launch over the merged adjacency
+for M in 0 1; do
+    DC_MERGE_BRANCHES=$M timeout -s KILL 400 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$R/$O/pmc_hop_l2_$M" -- python3 "$R/tools/pmc_hop.py" > "$R/$O/pmc_hop_l2_$M.log" 2>&1
+    (cd "$R" && python tools/pmc_hop.py --parse-l2 "$O/pmc_hop_l2_$M" > "$O/hop_l2_requests_merged$M.json" 2>> "$O/dense_pmc.err")
+done
+(cd "$R" && timeout -s KILL 300 python tools/exp/hop_win.py > "$O/hop_window_experiment.txt" 2>&1)
+(cd "$R" && timeout -s KILL 300 python tools/exp/build_time.py > "$O/graph_build_time.txt" 2>&1)
+(cd "$R" && DC_BF16_X=0 timeout -s KILL 300 python tools/exp/bf16_dense.py > "$O/bf16_dense_128tiles.txt" 2>&1; DC_BF16_X=1 timeout -s KILL 300 python tools/exp/bf16_dense.py > "$O/bf16_dense_256tiles.txt" 2>&1)
 # keep the summaries, drop the bulky per-dispatch traces (gpurun_out/ travels back, 64 MiB cap)
 find "$R/$O" -name "*kernel_trace.csv" -delete
 find "$R/$O" -name "*counter_collection.csv" -delete
