@@ -411,8 +411,8 @@ def full_step_b4(dev, steps: int = 20, batch: int = 4):
     """Extra, not the headline: the reference's whole train step (train.py:46-58,71-73) at its
     shipped batch size 4 (configs/everyday.json:26) and at the benchmark batch 32 - encoder on the
     HIP path, unmasked cross-attention (blocked on the library's dense kernels once the score
-    matrix is large, stock PyTorch below that), decoder + L1 / gradient-consistency losses on
-    stock PyTorch, Adam."""
+    matrix is large, stock PyTorch below that), decoder on the library's dense block, both losses fused
+    (dc_contact_loss), FlatAdam."""
     from deformcontact_amd import synth
     from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
     from deformcontact_amd.train import train_step
@@ -463,7 +463,8 @@ def full_step_b4(dev, steps: int = 20, batch: int = 4):
             "loss": round(float(loss_t), 6), "hipgraph": captured,
             "note": "whole model on the library's kernels; attention " +
                     ("blocked on the fp16x2 dense kernels" if big else "softmax materialised on stock PyTorch") +
-                    "; losses on stock PyTorch; Adam = dc_adam_flat"}
+                    "; L1 + gradient-consistency losses and their gradients in one launch (dc_contact_loss); "
+                    "Adam = dc_adam_flat"}
 
 
 def train_loop(dev, batch: int = 4, steps: int = 40):
