@@ -136,6 +136,7 @@ constexpr int kGroupAlign = DC_GROUP_ALIGN;
 struct FwdGroups {
     int n;                              // 0 = ungrouped (p.w[0] / p.bias / p.h2.b_rowmax apply to every row)
     int64_t row_beg[kMaxGroups];
+    int64_t row_end[kMaxGroups];        // row_beg[g] + data rows of group g: the rows behind are padding and are stored as 0
     const float *w[kMaxGroups];         // pre-split weight image of group g
     const float *bias[kMaxGroups];
     const float *b_rowmax[kMaxGroups];

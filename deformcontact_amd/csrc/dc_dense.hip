@@ -1223,7 +1223,8 @@ extern "C" int dc_tag_grouped_fwd_h2p(const float *x, int64_t ldx, int ngroups, 
     for (int g = 0; g < ngroups; ++g) {
         DC_REQUIRE(w_images[g] && w_rowmaxes[g] && (((uintptr_t)w_images[g]) & 15) == 0,
                    "dc_tag_grouped_fwd_h2p: null / misaligned weights of group %d", g);
-        p.grp.row_beg[g] = row_beg[g], p.grp.w[g] = (const float *)w_images[g];
+        p.grp.row_beg[g] = row_beg[g], p.grp.row_end[g] = row_beg[g] + rows[g];
+        p.grp.w[g] = (const float *)w_images[g];
         p.grp.bias[g] = biases ? biases[g] : nullptr, p.grp.b_rowmax[g] = w_rowmaxes[g];
     }
     // a single group is the ungrouped launch

@@ -59,9 +59,11 @@ k_fwd_h2w(FwdParams p) {
     const int64_t lda = p.x[0].ld;
     // grouped launch (block-diagonal union, dc_tag_grouped_fwd_h2p): the tile's group picks weights / bias / scales
     const float *wimg = p.w[0].p, *bias = p.bias, *brm = p.h2.b_rowmax;
-    if (p.grp.n > 1) {
+    int64_t data_end = p.N;                                   // rows at and behind it are a group's zero padding
+    if (p.grp.n >= 1) {
         const int g = group_of_row(p.grp.row_beg, p.grp.n, row0);
         wimg = p.grp.w[g], bias = p.grp.bias[g], brm = p.grp.b_rowmax[g];
+        data_end = p.grp.row_end[g];
     }
 
     unsigned offA[2], offB[4];
@@ -277,6 +279,7 @@ k_fwd_h2w(FwdParams p) {
                     if (relu) v = fmaxf(v, 0.f);
                     if (p.exp_lse)                  // attention recompute: the block's weights from the saved row lse
                         v = col < p.exp_ncols ? expf(v - p.exp_lse[(FULL || row < p.N) ? row : p.N - 1]) : 0.f;
+                    if (row >= data_end) v = 0.f;            // padding rows of a grouped launch stay zero rows
                     if (FULL || (cok && row < p.N)) p.out[row * p.ldo + col] = v;
                 }
             }
@@ -294,7 +297,7 @@ static inline int hw_env_int(const char *name, int dflt) {
 bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     static const int wide = hw_env_int("DC_H2_WIDE", 1);
     if (!p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1) return false;
-    if (!wide && p.grp.n <= 1) return false;
+    if (!wide && p.grp.n < 1) return false;
     const int64_t ks = p.ksplit > 1 ? p.ksplit : 1;
     if (ks > 1 && (!p.kpartial || p.bias || p.relu || p.exp_lse)) return false;
     if (p.Fi % kWBK != 0 || p.Fi < kWBK) return false;
@@ -302,7 +305,7 @@ bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     if (!hw_al16(p.x[0].p) || !hw_al16(p.w[0].p) || p.x[0].ld % 4 != 0) return false;
     const int64_t tiles = ((p.N + kWBM - 1) / kWBM) * ((p.Fo + kWBN - 1) / kWBN);
     static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
-    if ((tiles * ks < min_tiles && p.grp.n <= 1) || tiles * ks >= (int64_t)INT32_MAX) return false;
+    if ((tiles * ks < min_tiles && p.grp.n < 1) || tiles * ks >= (int64_t)INT32_MAX) return false;
     const dim3 gd((unsigned)(tiles * ks)), bd(512);
     if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
         hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);

@@ -325,3 +325,25 @@ def test_encoder_merged_path_under_hipgraph_with_changing_batches():
         assert torch.equal(a, outs[i][0]) and torch.equal(b, outs[i][1])
         for n in gr:
             assert torch.equal(gr[n], outs[i][2][n]), n
+
+
+def test_three_layer_encoder_merged_path_equals_per_branch_path():
+    """encoder_layers = 3: TWO grouped layers in a row - the first writes its outputs as the part views of the second
+    one's merged slab (padding rows stay zero rows) - against the per-branch path, bit for bit (16 samples: whole stages)."""
+    rest, _, rig = (b.to(DEV) for b in synth.make_batch(16, soft_vertices=256, sphere_resolution=8))
+    assert rest.x.shape[0] % 32 == 0 and rig.x.shape[0] % 32 == 0
+    torch.manual_seed(3)
+    enc = ContactEncoder([21, 25], 256, encoder_layers=3).to(DEV)
+    with torch.no_grad():
+        for n_, p_ in enc.named_parameters():
+            if n_.endswith(".bias"):
+                p_.uniform_(0.5, 1.0)            # relu(b) of a padding row would be far from zero
+    enc.merge_branches = True
+    assert enc._mergeable(rest.x, rig.x)
+    g_rest = torch.randn(rest.x.shape[0], 256, device=DEV)
+    g_rig = torch.randn(rig.x.shape[0], 256, device=DEV)
+    a0, b0, gr0 = _encoder_run(enc, rest, rig, g_rest, g_rig, merged=False)
+    a1, b1, gr1 = _encoder_run(enc, rest, rig, g_rest, g_rig, merged=True)
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    for name in gr0:
+        assert torch.equal(gr0[name], gr1[name]), name
