@@ -148,6 +148,16 @@ def prepare_for(model, cache: "TopologyCache | None" = None):
     def prepare(batches):
         rest, _, rig = batches
         built = []
+        if getattr(model, "_mergeable", None) is not None and model._mergeable(rest.x, rig.x):
+            # merged encoder path (ContactEncoder.merge_branches): ONE adjacency over both graphs, whose row windows
+            # are what the first layers will ask for (the per-topology cache is per edge_index and does not apply)
+            for g in model.topology(rest, rig):
+                built.append(g)
+                for i, (convs, b) in enumerate(((model.conv_layers_resting, rest), (model.conv_layers_rigid, rig))):
+                    if hasattr(convs[0], "K"):
+                        # (the window registered for this edge_index: the object the first layer will find)
+                        ops.precompute_input_hops(convs[0].graph(b.edge_index, b.x.size(0)), b.x, convs[0].K)
+            return built
         for convs, b in ((getattr(model, "conv_layers_resting", []), rest),
                          (getattr(model, "conv_layers_rigid", []), rig)):
             if not len(convs) or not hasattr(convs[0], "graph_flags"):
