@@ -686,8 +686,13 @@ def launch_ranks(n: int) -> int:
                                           env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
         rc = 0
         live = list(procs)
+        deadline = time.time() + float(os.environ.get("DC_LAUNCH_TIMEOUT", "1500"))
         while live and rc == 0:
             time.sleep(0.2)
+            if time.time() > deadline:                # a stuck rendezvous must not hold the caller for ever
+                sys.stderr.write("bench.py: ranks still running at the launch deadline (DC_LAUNCH_TIMEOUT): stopping\n")
+                rc = 124
+                break
             for p in list(live):
                 code = p.poll()
                 if code is not None:
@@ -737,7 +742,11 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(backend)
+            # ranks of one node: keep gloo's pairwise connections on the loopback interface (a container hostname that
+            # resolves to an address the ranks cannot reach each other on leaves them waiting in the rendezvous)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            import datetime
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=240))
 
     from deformcontact_amd import dp, ops, synth
     from deformcontact_amd.graph import clear_cache, graph_index

@@ -438,6 +438,100 @@ k_emit(Build b, unsigned slot_blocks) {
     emit_one(b, sd, eid, k, beg + rank);
 }
 
+// ---- segmented build (r03): a batch whose graphs are known, contiguous node AND edge ranges ---------------------
+// Batch.from_data_list concatenates meshes: graph i owns nodes [node_ptr[i], node_ptr[i+1]) and edges
+// [edge_ptr[i], edge_ptr[i+1]), and none of its edges leaves its node range.  Then the stable sort by destination (or
+// source) of the whole edge list is the concatenation of the per-graph sorts, every graph fits in LDS (a 1024-node
+// mesh has ~6k directed edges) and the five dependent launches of the global pipeline - count, scan, fill, emit, each
+// bound by launch + atomic latency, ~41 us at B = 32 - collapse into ONE launch: workgroup (graph, side) counts in
+// LDS, scans its <= kSegNodes counters, buckets the edge ids (LDS cursors), ranks each id inside its group and writes
+// ptr / other / perm / w at the graph's own offsets (consecutive threads -> consecutive output slots).  No global
+// atomics, no workspace.  The result is the arrays dc_graph_build writes, bit for bit.
+constexpr int kSegNodes = DC_SEG_MAX_NODES;   // per-graph caps (LDS: 3 x 2 B x edges + 3 x 4 B x nodes = 144 KiB)
+constexpr int kSegEdges = DC_SEG_MAX_EDGES;
+
+struct SegBuild {
+    const int64_t *src, *dst;            // rows 0 / 1 of edge_index
+    const int64_t *node_ptr, *edge_ptr;  // [nseg + 1] device arrays (host-validated: monotone, 0 .. N / E, within caps)
+    int64_t E, N;
+    int nseg;
+    int32_t *ptr[2], *other[2], *perm[2];
+    float *w[2];
+    int32_t *status;
+};
+
+__device__ __forceinline__ float inv_sqrt_count(int d) {
+    return d > 0 ? 1.0f / sqrtf((float)d) : 0.0f;      // as inv_sqrt_deg
+}
+
+__global__ void __launch_bounds__(1024)
+k_build_segment(SegBuild b) {
+    __shared__ uint16_t key16[kSegEdges], oth16[kSegEdges], tmp[kSegEdges];
+    __shared__ int32_t excl[kSegNodes + 4], cur[kSegNodes], degin[kSegNodes];
+    const int seg = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;   // side 0: by destination, 1: by source
+    const int64_t n0 = b.node_ptr[seg], e0 = b.edge_ptr[seg];
+    int nn = (int)(b.node_ptr[seg + 1] - n0), ne = (int)(b.edge_ptr[seg + 1] - e0);
+    if (nn < 0 || nn > kSegNodes || ne < 0 || ne > kSegEdges || n0 < 0 || n0 + nn > b.N || e0 < 0 || e0 + ne > b.E) {
+        if (tid == 0) atomicOr(b.status, 2);           // cannot happen with host-validated offsets
+        return;
+    }
+    for (int i = tid; i < nn; i += 1024) cur[i] = 0, degin[i] = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int e = tid; e < ne; e += 1024) {
+        int64_t s = b.src[e0 + e] - n0, d = b.dst[e0 + e] - n0;
+        if (s < 0 || s >= nn || d < 0 || d >= nn) bad = true, s = d = 0;   // flagged; placed on node 0 so that every
+        const int k = (int)(side ? s : d), o = (int)(side ? d : s);        // output slot is still written
+        key16[e] = (uint16_t)k, oth16[e] = (uint16_t)o;
+        atomicAdd(&cur[k], 1);
+        if (side) atomicAdd(&degin[d], 1);             // gcn_norm degrees are in-degrees (= side 0's own counts)
+    }
+    if (bad) atomicOr(b.status, 1);
+    __syncthreads();
+    int v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * tid + j;
+        v[j] = i < nn ? cur[i] : 0;
+        sum += v[j];
+    }
+    int total;
+    int run = block_incl_scan<16>(sum, &total) - sum;
+    int32_t *__restrict__ ptr = b.ptr[side];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * tid + j;
+        if (i < nn) {
+            excl[i] = run, cur[i] = run;
+            if (!side) degin[i] = v[j];
+            ptr[n0 + i] = (int32_t)(e0 + run);
+        }
+        run += v[j];
+    }
+    if (tid == 0) {
+        excl[nn] = total;
+        if (seg == b.nseg - 1) ptr[b.N] = (int32_t)b.E;
+    }
+    __syncthreads();
+    for (int e = tid; e < ne; e += 1024) tmp[atomicAdd(&cur[key16[e]], 1)] = (uint16_t)e;
+    __syncthreads();
+    int32_t *__restrict__ other = b.other[side], *__restrict__ perm = b.perm[side];
+    float *__restrict__ w = b.w[side];
+    for (int p = tid; p < ne; p += 1024) {
+        const int e = tmp[p], k = key16[e], o = oth16[e];
+        const int beg = excl[k], end = excl[k + 1];
+        int rank = 0;
+        for (int q = beg; q < end; ++q) rank += tmp[q] < e;
+        const int64_t out = e0 + beg + rank;
+        perm[out] = (int32_t)(e0 + e);
+        other[out] = (int32_t)(n0 + o);
+        if (w) {
+            const int sl = side ? k : o, dl = side ? o : k;      // gcn_norm: dis[source] * 1 * dis[destination]
+            w[out] = inv_sqrt_count(degin[sl]) * 1.0f * inv_sqrt_count(degin[dl]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_invert_perm(const int32_t *perm, const int32_t *n_ptr, int32_t *pos_of, int64_t max_edges) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -658,6 +752,32 @@ extern "C" int dc_graph_build_parts(const int64_t *const *edge_index_parts, cons
     f.ptr = ptr_f, f.other = other_f, f.perm = perm_f, f.w = w_f, f.deg_ptr = ptr_f, f.key_is_dst = 1;
     t.ptr = ptr_b, t.other = other_b, t.perm = perm_b, t.w = w_b, t.deg_ptr = ptr_f, t.key_is_dst = 0;
     return run_build(b, 2, stream, "dc_graph_build_parts");
+}
+
+extern "C" int dc_graph_build_segmented(const int64_t *edge_index, int64_t E, int64_t N,
+                                        const int64_t *node_ptr, const int64_t *edge_ptr, int nseg,
+                                        int64_t max_seg_nodes, int64_t max_seg_edges,
+                                        int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
+                                        int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
+                                        int32_t *status, dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(E > 0 && N > 0 && nseg >= 1, "dc_graph_build_segmented: needs E > 0, N > 0 and >= 1 graph");
+    DC_REQUIRE(E + N < (int64_t)INT32_MAX, "dc_graph_build_segmented: E+N=%lld exceeds int32 indexing",
+               (long long)(E + N));
+    DC_REQUIRE(max_seg_nodes >= 0 && max_seg_nodes <= kSegNodes && max_seg_edges >= 0 && max_seg_edges <= kSegEdges,
+               "dc_graph_build_segmented: a graph of %lld nodes / %lld edges exceeds the per-graph caps (%d / %d): "
+               "use dc_graph_build", (long long)max_seg_nodes, (long long)max_seg_edges, kSegNodes, kSegEdges);
+    DC_REQUIRE(edge_index && node_ptr && edge_ptr && ptr_f && ptr_b && other_f && perm_f && other_b && perm_b && status,
+               "dc_graph_build_segmented: null pointer");
+    DC_REQUIRE((w_f == nullptr) == (w_b == nullptr), "dc_graph_build_segmented: w_f and w_b go together");
+    SegBuild b{};
+    b.src = edge_index, b.dst = edge_index + E, b.node_ptr = node_ptr, b.edge_ptr = edge_ptr;
+    b.E = E, b.N = N, b.nseg = nseg, b.status = status;
+    b.ptr[0] = ptr_f, b.other[0] = other_f, b.perm[0] = perm_f, b.w[0] = w_f;
+    b.ptr[1] = ptr_b, b.other[1] = other_b, b.perm[1] = perm_b, b.w[1] = w_b;
+    hipMemsetAsync(status, 0, sizeof(int32_t), stream);
+    hipLaunchKernelGGL(k_build_segment, dim3((unsigned)nseg, 2), dim3(1024), 0, stream, b);
+    return check_launch("dc_graph_build_segmented");
 }
 
 extern "C" int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last, int32_t *pos_of,

@@ -124,7 +124,21 @@ class Batch(Data):
         out._edge_ptr = eptr
         out._node_ptr = ptr.clone()
         out._kinds = kinds
+        # host-side layout (node / edge offsets of the graphs): survives to() / clone() as plain tuples
+        out.__dict__["_segments"] = (tuple(offs), tuple(eptr.tolist()))
         return out
+
+    def __setattr__(self, name, value):
+        # a replaced edge_index (radius graph, re-meshing) no longer follows the recorded layout
+        if name == "edge_index" and "_segments" in self.__dict__:
+            del self.__dict__["_segments"]
+        object.__setattr__(self, name, value)
+
+    def segments(self):
+        """``(node offsets, edge offsets)`` of the graphs in this batch as host tuples - graph ``i`` owns nodes
+        ``[n[i], n[i+1])`` and edges ``[e[i], e[i+1])`` of ``edge_index`` - or None once ``edge_index`` has been
+        replaced.  ``graph.graph_index(..., segments=)`` uses it to build the sorted adjacency in one launch."""
+        return self.__dict__.get("_segments")
 
     @property
     def num_graphs(self) -> int:

@@ -76,7 +76,9 @@ class GraphIndex:
     """CSR (by destination) + transposed (by source) views of one edge set."""
 
     def __init__(self, edge_index: Optional[torch.Tensor], num_nodes: int, *, self_loops: bool = False,
-                 normalize: bool = True, validate: bool = False, parts=None):
+                 normalize: bool = True, validate: bool = False, parts=None, segments=None):
+        #: ``(node_ptr, edge_ptr)`` device arrays when the one-launch segmented build applies (``_segment_arrays``)
+        self._segments = None
         #: merged (block-diagonal) adjacency: ``[(edge_index, num_nodes), ...]``; see ``from_parts``
         self.parts = None
         if parts is not None:
@@ -132,6 +134,8 @@ class GraphIndex:
         self._pos_fwd = None
         self._bwd_to_fwd = None
         self._num_edges = None if self_loops else self.num_input_edges
+        if segments is not None and parts is None and not self_loops:
+            self._segments = _segment_arrays(segments, self.num_nodes, self.num_input_edges, self.device)
         self.rebuild()
         if validate:
             self.validate()
@@ -154,7 +158,13 @@ class GraphIndex:
                t.w.data_ptr() if t.w is not None else None,
                self._status.data_ptr(), self._workspace.data_ptr(), self._workspace.numel(),
                current_stream_ptr(self.device))
-        if self.parts is not None:
+        if self._segments is not None:
+            nptr, eptr, nseg, max_n, max_e = self._segments
+            rc = _lib.lib().dc_graph_build_segmented(
+                self.edge_index.data_ptr(), self.num_input_edges, self.num_nodes, nptr.data_ptr(), eptr.data_ptr(),
+                nseg, max_n, max_e, *out[:9], out[11])
+            _lib.check(rc, "dc_graph_build_segmented")
+        elif self.parts is not None:
             import ctypes
             k = len(self.parts)
             rc = _lib.lib().dc_graph_build_parts(
@@ -249,6 +259,49 @@ class GraphIndex:
         return self._bwd_to_fwd
 
 
+#: per-graph caps of the one-launch segmented build (include/deformcontact.h DC_SEG_MAX_NODES / DC_SEG_MAX_EDGES)
+SEG_MAX_NODES, SEG_MAX_EDGES = 4096, 16384
+SEGMENTED_BUILD = os.environ.get("DC_SEGMENTED_BUILD", "1") == "1"
+_SEG_ARRAYS: dict = {}     # (device, node offsets, edge offsets) -> device copies (uploaded once per batch layout)
+
+
+def _segment_arrays(segments, num_nodes: int, num_edges: int, device):
+    """Validate (on the host) the layout of a batch - ``segments = (node offsets, edge offsets)``, two ascending
+    host sequences of B + 1 ints as ``Batch.from_data_list`` records them - and return its device copies for
+    ``dc_graph_build_segmented``, or None when the layout does not qualify (a graph beyond the LDS caps, offsets
+    that do not cover [0, N] / [0, E], an empty edge set) or when the copies would have to be uploaded under
+    hipGraph capture: the caller then runs the global pipeline."""
+    if not SEGMENTED_BUILD or num_edges <= 0 or num_nodes <= 0:
+        return None
+    nodes, edges = tuple(int(v) for v in segments[0]), tuple(int(v) for v in segments[1])
+    if len(nodes) < 2 or len(edges) != len(nodes) or nodes[-1] != num_nodes or edges[-1] != num_edges:
+        return None
+    key = (device.index, nodes, edges)
+    hit = _SEG_ARRAYS.get(key)
+    if hit is not None:
+        return hit if hit[2] else None
+    nseg = len(nodes) - 1
+    ok = nodes[0] == 0 and edges[0] == 0
+    max_n = max_e = 0
+    if ok:
+        for i in range(nseg):
+            dn, de = nodes[i + 1] - nodes[i], edges[i + 1] - edges[i]
+            ok = ok and dn >= 0 and de >= 0
+            max_n, max_e = max(max_n, dn), max(max_e, de)
+        ok = ok and max_n <= SEG_MAX_NODES and max_e <= SEG_MAX_EDGES
+    if not ok:
+        _SEG_ARRAYS[key] = (None, None, 0, 0, 0)
+        return None
+    if capture_id(device) != 0:
+        return None                                   # no host -> device copy inside a capture; not cached either
+    if len(_SEG_ARRAYS) > 64:
+        _SEG_ARRAYS.clear()
+    hit = (torch.tensor(nodes, dtype=torch.int64, device=device),
+           torch.tensor(edges, dtype=torch.int64, device=device), nseg, max_n, max_e)
+    _SEG_ARRAYS[key] = hit
+    return hit
+
+
 #: DC_VALIDATE=1 graphs built under capture, waiting for their first replay (``validate_pending``)
 _PENDING_VALIDATION: list = []
 
@@ -327,7 +380,7 @@ def _key(edge_index, num_nodes, self_loops, normalize):
 
 
 def graph_index(edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = False,
-                normalize: bool = True) -> GraphIndex:
+                normalize: bool = True, segments=None) -> GraphIndex:
     """The sorted adjacency of ``edge_index``, built on first use and cached on the tensor's
     address + version + shape.
 
@@ -337,12 +390,16 @@ def graph_index(edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = 
     ``edge_index`` buffers it reads, and replays it on whatever those buffers then hold.  Callers
     that guarantee a constant topology for the life of a captured graph may set
     ``GraphIndex._static_ok`` on an eagerly built entry to keep the build out of the capture.
+
+    ``segments`` = ``Batch.segments()`` of the batch this ``edge_index`` belongs to (host-side node / edge offsets
+    of its graphs) selects the one-launch ``dc_graph_build_segmented`` when the layout qualifies; the arrays are the
+    same bit for bit.
     """
     key = _key(edge_index, num_nodes, self_loops, normalize)
     g = _cache_get(key, edge_index.device if edge_index.is_cuda else None)
     if g is not None:
         return g
-    g = GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize)
+    g = GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize, segments=segments)
     _cache_put(key, g, (edge_index,))
     return g
 

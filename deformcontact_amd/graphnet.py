@@ -34,6 +34,12 @@ def _conv_class(backbone: str, conv_module):
     return getattr(mod, name)
 
 
+def _segments_of(batch):
+    """Host-side layout of a ``data.Batch`` (None for anything else, or once its ``edge_index`` was replaced)."""
+    f = getattr(batch, "segments", None)
+    return f() if callable(f) else None
+
+
 class ContactEncoder(nn.Module):
     def __init__(self, input_dims: Sequence[int], hidden_dim: int, encoder_layers: int = 2,
                  dropout_rate: float = 0.0, backbone: str = "TAGConv", conv_module=None):
@@ -47,8 +53,12 @@ class ContactEncoder(nn.Module):
         self.conv_layers_rigid = nn.ModuleList(
             conv(a, b) for a, b in zip(widths_rig[:-1], widths_rig[1:]))
 
-    def _branch(self, layers, x, edge_index):
+    def _branch(self, layers, x, edge_index, segments=None):
         drop = self.dropout_rate > 0.0 and self.training
+        if segments is not None and hasattr(layers[0], "graph") and x.is_cuda:
+            # the batch layout is known: the sorted adjacency every layer will look up comes from the one-launch
+            # segmented build (graph.graph_index(segments=)) instead of the 5-launch global pipeline
+            layers[0].graph(edge_index, x.size(0), segments=segments)
         for i, conv in enumerate(layers):
             if getattr(conv, "supports_fused_relu", False):
                 # ReLU in the MFMA epilogue; output written into the next layer's hop slab
@@ -118,8 +128,9 @@ class ContactEncoder(nn.Module):
             from .graph import merged_graph_index
             return [merged_graph_index([(e_s, x_s.size(0)), (e_r, x_r.size(0))],
                                        **self.conv_layers_resting[0].graph_flags())]
-        return [c.graph(e, x.size(0)) for c, e, x in ((self.conv_layers_resting[0], e_s, x_s),
-                                                      (self.conv_layers_rigid[0], e_r, x_r))
+        return [c.graph(e, x.size(0), segments=_segments_of(b))
+                for c, e, x, b in ((self.conv_layers_resting[0], e_s, x_s, graph_resting),
+                                   (self.conv_layers_rigid[0], e_r, x_r, graph_rigid))
                 if hasattr(c, "graph")]
 
     def _encode_merged(self, x_s, e_s, x_r, e_r):
@@ -154,9 +165,10 @@ class ContactEncoder(nn.Module):
         x_r, e_r = graph_rigid.x, graph_rigid.edge_index
         if self._mergeable(x_s, x_r):
             return self._encode_merged(x_s, e_s, x_r, e_r)
+        seg_s, seg_r = _segments_of(graph_resting), _segments_of(graph_rigid)
         if not (self.overlap_branches and x_s.is_cuda and x_r.is_cuda):
-            return (self._branch(self.conv_layers_resting, x_s, e_s),
-                    self._branch(self.conv_layers_rigid, x_r, e_r))
+            return (self._branch(self.conv_layers_resting, x_s, e_s, seg_s),
+                    self._branch(self.conv_layers_rigid, x_r, e_r, seg_r))
         # each branch builds (or finds) its own sorted adjacency on its own stream: the two
         # dc_graph_build pipelines of a new batch run side by side; every later use of the rigid
         # one on the caller's stream is ordered behind the join below
@@ -164,8 +176,8 @@ class ContactEncoder(nn.Module):
         side = self._side_stream(x_s.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            out_r = self._branch(self.conv_layers_rigid, x_r, e_r)
-        out_s = self._branch(self.conv_layers_resting, x_s, e_s)
+            out_r = self._branch(self.conv_layers_rigid, x_r, e_r, seg_r)
+        out_s = self._branch(self.conv_layers_resting, x_s, e_s, seg_s)
         main.wait_stream(side)
         out_r.record_stream(main)
         return out_s, out_r

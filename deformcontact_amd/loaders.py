@@ -120,14 +120,15 @@ class TopologyCache:
         self.hits = self.misses = 0
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = False,
-            normalize: bool = True):
+            normalize: bool = True, segments=None):
         from . import graph
         key = (graph.content_hash(edge_index), tuple(edge_index.shape), int(num_nodes),
                bool(self_loops), bool(normalize), edge_index.device.index)
         g = self._d.get(key)
         if g is None:
             self.misses += 1
-            g = graph.GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize)
+            g = graph.GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize,
+                                 segments=segments)
             self._d[key] = g
             while len(self._d) > self.max_entries:
                 self._d.popitem(last=False)
@@ -163,8 +164,9 @@ def prepare_for(model, cache: "TopologyCache | None" = None):
             if not len(convs) or not hasattr(convs[0], "graph_flags"):
                 continue
             conv, n = convs[0], b.x.size(0)
-            g = cache.get(b.edge_index, n, **conv.graph_flags()) if cache is not None \
-                else conv.graph(b.edge_index, n)
+            seg = b.segments() if callable(getattr(b, "segments", None)) else None
+            g = cache.get(b.edge_index, n, segments=seg, **conv.graph_flags()) if cache is not None \
+                else conv.graph(b.edge_index, n, segments=seg)
             if hasattr(conv, "K") and getattr(conv, "supports_fused_relu", False):
                 ops.precompute_input_hops(g, b.x, conv.K)
             built.append(g)

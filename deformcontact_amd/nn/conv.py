@@ -81,8 +81,8 @@ class TAGConv(nn.Module):
     def graph_flags(self) -> dict:
         return dict(self_loops=False, normalize=self.normalize)
 
-    def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
-        return graph_index(edge_index, num_nodes, **self.graph_flags())
+    def graph(self, edge_index: Tensor, num_nodes: int, segments=None) -> GraphIndex:
+        return graph_index(edge_index, num_nodes, segments=segments, **self.graph_flags())
 
     supports_fused_relu = True
     #: dtype of the output when the input is bfloat16 (the bf16-storage forward path)
@@ -142,8 +142,8 @@ class GCNConv(nn.Module):
     def graph_flags(self) -> dict:
         return dict(self_loops=True, normalize=True)
 
-    def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
-        return graph_index(edge_index, num_nodes, **self.graph_flags())
+    def graph(self, edge_index: Tensor, num_nodes: int, segments=None) -> GraphIndex:
+        return graph_index(edge_index, num_nodes, segments=segments, **self.graph_flags())
 
     def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
         _check_inputs(x, edge_index, self.in_channels)
@@ -183,8 +183,8 @@ class GATConv(nn.Module):
     def graph_flags(self) -> dict:
         return dict(self_loops=True, normalize=False)
 
-    def graph(self, edge_index: Tensor, num_nodes: int) -> GraphIndex:
-        return graph_index(edge_index, num_nodes, **self.graph_flags())
+    def graph(self, edge_index: Tensor, num_nodes: int, segments=None) -> GraphIndex:
+        return graph_index(edge_index, num_nodes, segments=segments, **self.graph_flags())
 
     def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
         _check_inputs(x, edge_index, self.in_channels)

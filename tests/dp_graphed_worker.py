@@ -26,7 +26,9 @@ def batch(step, rank, world, dev):
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out_path = sys.argv[1]
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")            # one node: pairwise connections over loopback
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     from deformcontact_amd import dp
     from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
     from deformcontact_amd.train import GraphedTrainStep, losses

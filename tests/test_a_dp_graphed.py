@@ -34,7 +34,7 @@ def test_two_rank_graphed_train_step_equals_single_process_mean_gradient(tmp_pat
     logs = []
     for p in procs:
         try:
-            o, e = p.communicate(timeout=900)
+            o, e = p.communicate(timeout=420)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()

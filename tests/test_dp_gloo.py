@@ -37,6 +37,7 @@ def _local_grads(enc, rank):
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)

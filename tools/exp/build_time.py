@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""dc_graph_build (both sides + gcn_norm) on the B=32 graphs, graph-replayed: us per build (soft, rigid, merged)."""
+"""dc_graph_build (both sides + gcn_norm) on the B=32 graphs, graph-replayed: us per build (soft, rigid, merged;
+and the one-launch segmented build of the same batches)."""
 import os
 import sys
 
@@ -15,7 +16,10 @@ def main():
     dev = torch.device("cuda:0")
     rest, _, rig = synth.make_batch(32)
     parts = [(rest.edge_index.to(dev), rest.x.shape[0]), (rig.edge_index.to(dev), rig.x.shape[0])]
-    for name, g in (("soft", GraphIndex(*parts[0])), ("rigid", GraphIndex(*parts[1])), ("merged", GraphIndex.from_parts(parts))):
+    seg = [GraphIndex(*parts[0], segments=rest.segments()), GraphIndex(*parts[1], segments=rig.segments())]
+    assert all(g._segments is not None for g in seg)
+    for name, g in (("soft", GraphIndex(*parts[0])), ("rigid", GraphIndex(*parts[1])),
+                    ("merged", GraphIndex.from_parts(parts)), ("soft/1 launch", seg[0]), ("rigid/1 launch", seg[1])):
         for _ in range(3):
             g.rebuild()
         torch.cuda.synchronize()
@@ -30,7 +34,7 @@ def main():
             gr.replay()
         e1.record()
         torch.cuda.synchronize()
-        print(f"{name:7s} N={g.num_nodes:6d} E={g.num_input_edges:7d}: {e0.elapsed_time(e1) / 200 * 1e3:6.1f} us per build")
+        print(f"{name:14s} N={g.num_nodes:6d} E={g.num_input_edges:7d}: {e0.elapsed_time(e1) / 200 * 1e3:6.1f} us per build")
 
 
 if __name__ == "__main__":
