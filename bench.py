@@ -76,6 +76,8 @@ def parse():
                     help="radius100k: only the bf16 100k-point radius-graph stress (BASELINE.json configs[4])")
     ap.add_argument("--no-merged", action="store_true",
                     help="skip the extra line with both branches merged into one block-diagonal launch set")
+    ap.add_argument("--global-build", dest="segmented_build", action="store_false",
+                    help="build the adjacencies with the 5-launch global pipeline even though the batch layout is known")
     ap.add_argument("--no-radius100k", action="store_true",
                     help="leave the radius100k extra out of the default line")
     ap.add_argument("--distinct-batches", type=int, default=4,
@@ -776,7 +778,12 @@ def main():
         if j == 0:
             rest, rig = r_h.to(dev), g_h.to(dev)           # the step's (static) input batches ...
             views = [static_buf[off:off + nbytes].view(dt).view(shp) for off, nbytes, dt, shp in layout]
+            lay_s, lay_r = rest.segments(), rig.segments()
             rest.x, rest.edge_index, rig.x, rig.edge_index = views   # ... whose tensors live in the packed buffer
+            if args.segmented_build:
+                # every batch of the pool has this layout (B meshes of one size): the adjacency build may use it
+                rest.assume_segments(lay_s)
+                rig.assume_segments(lay_r)
             static_buf.copy_(packed)
     n_s, e_s = rest.x.shape[0], rest.edge_index.shape[1]
     n_r, e_r = rig.x.shape[0], rig.edge_index.shape[1]
@@ -953,13 +960,17 @@ def main():
             "edges_per_gpu_step": edges_per_rank, "global_batch": args.batch * world,
             "step": f"EVERY step: a new batch (1 of {nb} distinct, rotated) is copied into the input buffers "
                     "(ONE packed device-to-device copy, as the loader uploads a batch), both sorted adjacencies + gcn_norm are built for both graphs "
-                    "(dc_graph_build), the first-layer hop slabs are computed, then fwd + bwd(synthetic "
+                    + ("(dc_graph_build_segmented: one launch per graph, the batch layout is host data)"
+                       if args.segmented_build else "(dc_graph_build)")
+                    + ", the first-layer hop slabs are computed, then fwd + bwd(synthetic "
                     "upstream grad)" + (" + RCCL grad all-reduce" if world > 1 else "")
                     + ("" if args.no_optim else " + Adam") + "; all of it inside the timed region, one hipGraph",
             "value_cached_topology": "one fixed batch replayed, adjacency and first-layer hops built once "
                                      "outside the loop (round-1 headline definition)",
             "hipgraph": graph_used, "two_stream_branches": not args.serial_branches,
             "merged_branches": bool(enc._mergeable(rest.x, rig.x)),
+            "segmented_adjacency_build": all(getattr(g_, "_segments", None) is not None
+                                             for g_ in enc.topology(rest, rig)),
             "parallelism": f"dp{world}",
         },
     }

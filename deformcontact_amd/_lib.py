@@ -29,7 +29,7 @@ _SIGNATURES = {
     "dc_graph_build_parts": (c_int, [POINTER(_vp), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int,
                                      c_int64, c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, c_int64,
                                      _vp]),
-    "dc_graph_build_segmented": (c_int, [_vp, c_int64, c_int64, _vp, _vp, c_int, c_int64, c_int64,
+    "dc_graph_build_segmented": (c_int, [_vp, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64), c_int,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dc_spmm_f32_window": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                                    c_int64, c_int64, _vp]),

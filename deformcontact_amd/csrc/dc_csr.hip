@@ -446,15 +446,19 @@ k_emit(Build b, unsigned slot_blocks) {
 // bound by launch + atomic latency, ~41 us at B = 32 - collapse into ONE launch: workgroup (graph, side) counts in
 // LDS, scans its <= kSegNodes counters, buckets the edge ids (LDS cursors), ranks each id inside its group and writes
 // ptr / other / perm / w at the graph's own offsets (consecutive threads -> consecutive output slots).  No global
-// atomics, no workspace.  The result is the arrays dc_graph_build writes, bit for bit.
+// atomics, no workspace, no device-side offsets: the layout is host data and travels in the kernel arguments
+// (kSegChunk graphs per launch).  The result is the arrays dc_graph_build writes, bit for bit.
 constexpr int kSegNodes = DC_SEG_MAX_NODES;   // per-graph caps (LDS: 3 x 2 B x edges + 3 x 4 B x nodes = 144 KiB)
 constexpr int kSegEdges = DC_SEG_MAX_EDGES;
 
+constexpr int kSegChunk = 96;                 // graphs per launch (their offsets travel as kernel arguments)
+
 struct SegBuild {
     const int64_t *src, *dst;            // rows 0 / 1 of edge_index
-    const int64_t *node_ptr, *edge_ptr;  // [nseg + 1] device arrays (host-validated: monotone, 0 .. N / E, within caps)
+    int32_t node_ptr[kSegChunk + 1];     // offsets of this launch's graphs (host-validated: ascending, within caps)
+    int32_t edge_ptr[kSegChunk + 1];
     int64_t E, N;
-    int nseg;
+    int nseg, last;                      // graphs in this launch; last != 0: this launch holds the batch's last graph
     int32_t *ptr[2], *other[2], *perm[2];
     float *w[2];
     int32_t *status;
@@ -469,22 +473,31 @@ k_build_segment(SegBuild b) {
     __shared__ uint16_t key16[kSegEdges], oth16[kSegEdges], tmp[kSegEdges];
     __shared__ int32_t excl[kSegNodes + 4], cur[kSegNodes], degin[kSegNodes];
     const int seg = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;   // side 0: by destination, 1: by source
-    const int64_t n0 = b.node_ptr[seg], e0 = b.edge_ptr[seg];
-    int nn = (int)(b.node_ptr[seg + 1] - n0), ne = (int)(b.edge_ptr[seg + 1] - e0);
-    if (nn < 0 || nn > kSegNodes || ne < 0 || ne > kSegEdges || n0 < 0 || n0 + nn > b.N || e0 < 0 || e0 + ne > b.E) {
-        if (tid == 0) atomicOr(b.status, 2);           // cannot happen with host-validated offsets
-        return;
-    }
+    const int n0 = b.node_ptr[seg], e0 = b.edge_ptr[seg];
+    const int nn = b.node_ptr[seg + 1] - n0, ne = b.edge_ptr[seg + 1] - e0;
     for (int i = tid; i < nn; i += 1024) cur[i] = 0, degin[i] = 0;
     __syncthreads();
     bool bad = false;
-    for (int e = tid; e < ne; e += 1024) {
-        int64_t s = b.src[e0 + e] - n0, d = b.dst[e0 + e] - n0;
-        if (s < 0 || s >= nn || d < 0 || d >= nn) bad = true, s = d = 0;   // flagged; placed on node 0 so that every
-        const int k = (int)(side ? s : d), o = (int)(side ? d : s);        // output slot is still written
-        key16[e] = (uint16_t)k, oth16[e] = (uint16_t)o;
-        atomicAdd(&cur[k], 1);
-        if (side) atomicAdd(&degin[d], 1);             // gcn_norm degrees are in-degrees (= side 0's own counts)
+    const int64_t *__restrict__ gs = b.src + e0, *__restrict__ gd = b.dst + e0;
+    for (int base = 0; base < ne; base += 8 * 1024) {
+        int64_t sv[8], dv[8];                          // all loads of the chunk in flight before the first use
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = base + j * 1024 + tid;
+            sv[j] = dv[j] = 0;
+            if (e < ne) sv[j] = gs[e], dv[j] = gd[e];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = base + j * 1024 + tid;
+            if (e >= ne) continue;
+            int64_t s = sv[j] - n0, d = dv[j] - n0;
+            if (s < 0 || s >= nn || d < 0 || d >= nn) bad = true, s = d = 0;   // flagged; placed on node 0 so that
+            const int k = (int)(side ? s : d), o = (int)(side ? d : s);        // every output slot is still written
+            key16[e] = (uint16_t)k, oth16[e] = (uint16_t)o;
+            atomicAdd(&cur[k], 1);
+            if (side) atomicAdd(&degin[d], 1);         // gcn_norm degrees are in-degrees (= side 0's own counts)
+        }
     }
     if (bad) atomicOr(b.status, 1);
     __syncthreads();
@@ -504,13 +517,13 @@ k_build_segment(SegBuild b) {
         if (i < nn) {
             excl[i] = run, cur[i] = run;
             if (!side) degin[i] = v[j];
-            ptr[n0 + i] = (int32_t)(e0 + run);
+            ptr[n0 + i] = e0 + run;
         }
         run += v[j];
     }
     if (tid == 0) {
         excl[nn] = total;
-        if (seg == b.nseg - 1) ptr[b.N] = (int32_t)b.E;
+        if (b.last && seg == b.nseg - 1) ptr[b.N] = (int32_t)b.E;
     }
     __syncthreads();
     for (int e = tid; e < ne; e += 1024) tmp[atomicAdd(&cur[key16[e]], 1)] = (uint16_t)e;
@@ -522,9 +535,9 @@ k_build_segment(SegBuild b) {
         const int beg = excl[k], end = excl[k + 1];
         int rank = 0;
         for (int q = beg; q < end; ++q) rank += tmp[q] < e;
-        const int64_t out = e0 + beg + rank;
-        perm[out] = (int32_t)(e0 + e);
-        other[out] = (int32_t)(n0 + o);
+        const int64_t out = (int64_t)e0 + beg + rank;
+        perm[out] = e0 + e;
+        other[out] = n0 + o;
         if (w) {
             const int sl = side ? k : o, dl = side ? o : k;      // gcn_norm: dis[source] * 1 * dis[destination]
             w[out] = inv_sqrt_count(degin[sl]) * 1.0f * inv_sqrt_count(degin[dl]);
@@ -755,8 +768,7 @@ extern "C" int dc_graph_build_parts(const int64_t *const *edge_index_parts, cons
 }
 
 extern "C" int dc_graph_build_segmented(const int64_t *edge_index, int64_t E, int64_t N,
-                                        const int64_t *node_ptr, const int64_t *edge_ptr, int nseg,
-                                        int64_t max_seg_nodes, int64_t max_seg_edges,
+                                        const int64_t *node_ptr_host, const int64_t *edge_ptr_host, int nseg,
                                         int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
                                         int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
                                         int32_t *status, dc_stream_t stream_) {
@@ -764,19 +776,31 @@ extern "C" int dc_graph_build_segmented(const int64_t *edge_index, int64_t E, in
     DC_REQUIRE(E > 0 && N > 0 && nseg >= 1, "dc_graph_build_segmented: needs E > 0, N > 0 and >= 1 graph");
     DC_REQUIRE(E + N < (int64_t)INT32_MAX, "dc_graph_build_segmented: E+N=%lld exceeds int32 indexing",
                (long long)(E + N));
-    DC_REQUIRE(max_seg_nodes >= 0 && max_seg_nodes <= kSegNodes && max_seg_edges >= 0 && max_seg_edges <= kSegEdges,
-               "dc_graph_build_segmented: a graph of %lld nodes / %lld edges exceeds the per-graph caps (%d / %d): "
-               "use dc_graph_build", (long long)max_seg_nodes, (long long)max_seg_edges, kSegNodes, kSegEdges);
-    DC_REQUIRE(edge_index && node_ptr && edge_ptr && ptr_f && ptr_b && other_f && perm_f && other_b && perm_b && status,
-               "dc_graph_build_segmented: null pointer");
+    DC_REQUIRE(edge_index && node_ptr_host && edge_ptr_host && ptr_f && ptr_b && other_f && perm_f && other_b &&
+                   perm_b && status, "dc_graph_build_segmented: null pointer");
     DC_REQUIRE((w_f == nullptr) == (w_b == nullptr), "dc_graph_build_segmented: w_f and w_b go together");
+    DC_REQUIRE(node_ptr_host[0] == 0 && edge_ptr_host[0] == 0 && node_ptr_host[nseg] == N && edge_ptr_host[nseg] == E,
+               "dc_graph_build_segmented: the graphs' offsets must cover [0, N] and [0, E]");
+    for (int i = 0; i < nseg; ++i) {
+        const int64_t dn = node_ptr_host[i + 1] - node_ptr_host[i], de = edge_ptr_host[i + 1] - edge_ptr_host[i];
+        DC_REQUIRE(dn >= 0 && de >= 0, "dc_graph_build_segmented: offsets of graph %d descend", i);
+        DC_REQUIRE(dn <= kSegNodes && de <= kSegEdges,
+                   "dc_graph_build_segmented: graph %d (%lld nodes, %lld edges) exceeds the per-graph caps (%d / %d): "
+                   "use dc_graph_build", i, (long long)dn, (long long)de, kSegNodes, kSegEdges);
+    }
     SegBuild b{};
-    b.src = edge_index, b.dst = edge_index + E, b.node_ptr = node_ptr, b.edge_ptr = edge_ptr;
-    b.E = E, b.N = N, b.nseg = nseg, b.status = status;
+    b.src = edge_index, b.dst = edge_index + E, b.E = E, b.N = N, b.status = status;
     b.ptr[0] = ptr_f, b.other[0] = other_f, b.perm[0] = perm_f, b.w[0] = w_f;
     b.ptr[1] = ptr_b, b.other[1] = other_b, b.perm[1] = perm_b, b.w[1] = w_b;
-    hipMemsetAsync(status, 0, sizeof(int32_t), stream);
-    hipLaunchKernelGGL(k_build_segment, dim3((unsigned)nseg, 2), dim3(1024), 0, stream, b);
+    for (int first = 0; first < nseg; first += kSegChunk) {
+        const int cnt = nseg - first < kSegChunk ? nseg - first : kSegChunk;
+        for (int i = 0; i <= cnt; ++i) {
+            b.node_ptr[i] = (int32_t)node_ptr_host[first + i];
+            b.edge_ptr[i] = (int32_t)edge_ptr_host[first + i];
+        }
+        b.nseg = cnt, b.last = first + cnt == nseg;
+        hipLaunchKernelGGL(k_build_segment, dim3((unsigned)cnt, 2), dim3(1024), 0, stream, b);
+    }
     return check_launch("dc_graph_build_segmented");
 }
 

@@ -134,6 +134,11 @@ class Batch(Data):
             del self.__dict__["_segments"]
         object.__setattr__(self, name, value)
 
+    def assume_segments(self, segments) -> None:
+        """Declare that the CURRENT ``edge_index`` (e.g. a view into a static buffer that receives batches of one
+        fixed layout) follows ``segments`` = an earlier ``segments()`` value."""
+        self.__dict__["_segments"] = (tuple(int(v) for v in segments[0]), tuple(int(v) for v in segments[1]))
+
     def segments(self):
         """``(node offsets, edge offsets)`` of the graphs in this batch as host tuples - graph ``i`` owns nodes
         ``[n[i], n[i+1])`` and edges ``[e[i], e[i+1])`` of ``edge_index`` - or None once ``edge_index`` has been

@@ -77,7 +77,7 @@ class GraphIndex:
 
     def __init__(self, edge_index: Optional[torch.Tensor], num_nodes: int, *, self_loops: bool = False,
                  normalize: bool = True, validate: bool = False, parts=None, segments=None):
-        #: ``(node_ptr, edge_ptr)`` device arrays when the one-launch segmented build applies (``_segment_arrays``)
+        #: ``(node offsets, edge offsets, B)`` host arrays when the one-launch segmented build applies
         self._segments = None
         #: merged (block-diagonal) adjacency: ``[(edge_index, num_nodes), ...]``; see ``from_parts``
         self.parts = None
@@ -159,10 +159,10 @@ class GraphIndex:
                self._status.data_ptr(), self._workspace.data_ptr(), self._workspace.numel(),
                current_stream_ptr(self.device))
         if self._segments is not None:
-            nptr, eptr, nseg, max_n, max_e = self._segments
+            nptr, eptr, nseg = self._segments
             rc = _lib.lib().dc_graph_build_segmented(
-                self.edge_index.data_ptr(), self.num_input_edges, self.num_nodes, nptr.data_ptr(), eptr.data_ptr(),
-                nseg, max_n, max_e, *out[:9], out[11])
+                self.edge_index.data_ptr(), self.num_input_edges, self.num_nodes, nptr, eptr, nseg,
+                *out[:9], out[11])
             _lib.check(rc, "dc_graph_build_segmented")
         elif self.parts is not None:
             import ctypes
@@ -215,6 +215,7 @@ class GraphIndex:
     def validate(self) -> None:
         """Raise if any endpoint was outside ``[0, num_nodes)`` (synchronises)."""
         if int(self._status.item()) != 0:
+            self._status.zero_()          # (the segmented build only ORs into the word)
             raise IndexError(
                 f"edge_index contains node ids outside [0, {self.num_nodes}) "
                 "(PyG/ATen would raise an index error here)")
@@ -262,44 +263,24 @@ class GraphIndex:
 #: per-graph caps of the one-launch segmented build (include/deformcontact.h DC_SEG_MAX_NODES / DC_SEG_MAX_EDGES)
 SEG_MAX_NODES, SEG_MAX_EDGES = 4096, 16384
 SEGMENTED_BUILD = os.environ.get("DC_SEGMENTED_BUILD", "1") == "1"
-_SEG_ARRAYS: dict = {}     # (device, node offsets, edge offsets) -> device copies (uploaded once per batch layout)
-
-
 def _segment_arrays(segments, num_nodes: int, num_edges: int, device):
-    """Validate (on the host) the layout of a batch - ``segments = (node offsets, edge offsets)``, two ascending
-    host sequences of B + 1 ints as ``Batch.from_data_list`` records them - and return its device copies for
-    ``dc_graph_build_segmented``, or None when the layout does not qualify (a graph beyond the LDS caps, offsets
-    that do not cover [0, N] / [0, E], an empty edge set) or when the copies would have to be uploaded under
-    hipGraph capture: the caller then runs the global pipeline."""
+    """Validate the layout of a batch - ``segments = (node offsets, edge offsets)``, two ascending host sequences
+    of B + 1 ints as ``Batch.from_data_list`` records them - and return it as the host arrays
+    ``dc_graph_build_segmented`` takes, or None when the layout does not qualify (a graph beyond the LDS caps,
+    offsets that do not cover [0, N] / [0, E], an empty edge set): the caller then runs the global pipeline."""
     if not SEGMENTED_BUILD or num_edges <= 0 or num_nodes <= 0:
         return None
     nodes, edges = tuple(int(v) for v in segments[0]), tuple(int(v) for v in segments[1])
-    if len(nodes) < 2 or len(edges) != len(nodes) or nodes[-1] != num_nodes or edges[-1] != num_edges:
-        return None
-    key = (device.index, nodes, edges)
-    hit = _SEG_ARRAYS.get(key)
-    if hit is not None:
-        return hit if hit[2] else None
     nseg = len(nodes) - 1
-    ok = nodes[0] == 0 and edges[0] == 0
-    max_n = max_e = 0
-    if ok:
-        for i in range(nseg):
-            dn, de = nodes[i + 1] - nodes[i], edges[i + 1] - edges[i]
-            ok = ok and dn >= 0 and de >= 0
-            max_n, max_e = max(max_n, dn), max(max_e, de)
-        ok = ok and max_n <= SEG_MAX_NODES and max_e <= SEG_MAX_EDGES
-    if not ok:
-        _SEG_ARRAYS[key] = (None, None, 0, 0, 0)
+    if nseg < 1 or len(edges) != nseg + 1 or nodes[0] != 0 or edges[0] != 0 or nodes[-1] != num_nodes \
+            or edges[-1] != num_edges:
         return None
-    if capture_id(device) != 0:
-        return None                                   # no host -> device copy inside a capture; not cached either
-    if len(_SEG_ARRAYS) > 64:
-        _SEG_ARRAYS.clear()
-    hit = (torch.tensor(nodes, dtype=torch.int64, device=device),
-           torch.tensor(edges, dtype=torch.int64, device=device), nseg, max_n, max_e)
-    _SEG_ARRAYS[key] = hit
-    return hit
+    for i in range(nseg):
+        dn, de = nodes[i + 1] - nodes[i], edges[i + 1] - edges[i]
+        if not (0 <= dn <= SEG_MAX_NODES and 0 <= de <= SEG_MAX_EDGES):
+            return None
+    import ctypes
+    return ((ctypes.c_int64 * (nseg + 1))(*nodes), (ctypes.c_int64 * (nseg + 1))(*edges), nseg)
 
 
 #: DC_VALIDATE=1 graphs built under capture, waiting for their first replay (``validate_pending``)

@@ -128,10 +128,12 @@ class GraphedTrainStep:
     @staticmethod
     def _signature(batches):
         # shapes + the host-side edge-equality mark of every batch: it selects the loss formulation the
-        # captured graph contains, so a batch with a different mark must not replay it
+        # captured graph contains, so a batch with a different mark must not replay it; + the batch layout
+        # (node / edge offsets of its graphs): the one-launch adjacency build carries it in its kernel arguments
         return tuple((k, tuple(getattr(b, k).shape)) for b in batches for k in _BATCH_TENSORS
                      if isinstance(getattr(b, k, None), torch.Tensor)) + \
-            tuple(bool((getattr(b, "_dc_edges_equal", None) or (False,))[0]) for b in batches)
+            tuple(bool((getattr(b, "_dc_edges_equal", None) or (False,))[0]) for b in batches) + \
+            tuple(b.segments() if callable(getattr(b, "segments", None)) else None for b in batches)
 
     def _fwd_bwd(self, rest, deff, rig):
         out = losses(self.model, rest, deff, rig, self.lam)

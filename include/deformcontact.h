@@ -120,18 +120,18 @@ int dc_graph_build_parts(const int64_t *const *edge_index_parts, const int64_t *
 /* dc_graph_build for a BATCH of graphs whose layout is known (Batch.from_data_list, the loaders of
  * /root/reference/loaders/everyday.py:96 via torch_geometric.data.Batch): graph i owns nodes
  * [node_ptr[i], node_ptr[i+1]) and input edges [edge_ptr[i], edge_ptr[i+1]) and no edge leaves its
- * graph.  node_ptr / edge_ptr are DEVICE arrays of nseg + 1 int64 that the HOST has validated
- * (ascending, node_ptr[0] = edge_ptr[0] = 0, node_ptr[nseg] = N, edge_ptr[nseg] = E);
- * max_seg_nodes / max_seg_edges are the largest per-graph counts (host values), at most
- * DC_SEG_MAX_NODES / DC_SEG_MAX_EDGES.  One launch - workgroup (graph, side) sorts the graph's
- * edges in LDS - no workspace, no global atomics; writes exactly the arrays dc_graph_build
- * (self_loops = 0) writes, bit for bit.  An edge that leaves its graph sets status bit 0 (the
- * arrays then hold in-range but meaningless entries, as with an out-of-range id). */
+ * graph.  node_ptr / edge_ptr are HOST arrays of nseg + 1 int64 (ascending, from 0 to N / E; checked
+ * here: DC_EINVAL otherwise, and when a graph exceeds DC_SEG_MAX_NODES / DC_SEG_MAX_EDGES); they
+ * travel in the kernel arguments, so under hipGraph capture they are part of the captured launch.
+ * One launch per 96 graphs - workgroup (graph, side) sorts the graph's edges in LDS - no workspace,
+ * no global atomics; writes exactly the arrays dc_graph_build (self_loops = 0) writes, bit for bit.
+ * status is only OR-ed into (the caller zeroes it once): bit 0 = an edge leaves its graph (the arrays
+ * then hold in-range but meaningless entries, as with an out-of-range id); a flag survives rebuilds
+ * until the caller clears it. */
 #define DC_SEG_MAX_NODES 4096
 #define DC_SEG_MAX_EDGES 16384
 int dc_graph_build_segmented(const int64_t *edge_index, int64_t E, int64_t N,
-                             const int64_t *node_ptr, const int64_t *edge_ptr, int nseg,
-                             int64_t max_seg_nodes, int64_t max_seg_edges,
+                             const int64_t *node_ptr_host, const int64_t *edge_ptr_host, int nseg,
                              int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
                              int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
                              int32_t *status, dc_stream_t stream);

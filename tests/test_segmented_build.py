@@ -50,6 +50,7 @@ def _same_arrays(a: GraphIndex, b: GraphIndex):
     ([(700, 9000), (0, 0), (4096, 16384), (33, 1000)], None),     # an empty graph; one graph exactly at the caps
     ([(500, 6000), (900, 12000)], (1, 3000)),                    # groups far beyond the rank-by-counting length
     ([(1024, 6132)] * 32, None),                                  # the B = 32 soft batch's shape
+    ([(30 + i % 7, 100 + 3 * i) for i in range(200)], None),      # more graphs than one launch carries (96)
 ])
 def test_segmented_build_equals_global_pipeline_bitwise(shapes, hub):
     b = _batch(shapes, hub=hub)
