@@ -78,6 +78,8 @@ def parse():
                     help="skip the extra line with both branches merged into one block-diagonal launch set")
     ap.add_argument("--global-build", dest="segmented_build", action="store_false",
                     help="build the adjacencies with the 5-launch global pipeline even though the batch layout is known")
+    ap.add_argument("--no-backbones", action="store_true",
+                    help="skip the extra lines with the GCNConv / GATConv encoders on the same batch")
     ap.add_argument("--no-radius100k", action="store_true",
                     help="leave the radius100k extra out of the default line")
     ap.add_argument("--distinct-batches", type=int, default=4,
@@ -407,6 +409,48 @@ def dense_roofline_grouped(dev, parts, reps: int):
                         "-> mask -> transposed merged hops -> dX -> dW + slab reduce), eager, HIP events on the "
                         "launch stream around each dense launch; FLOPs of the real rows only",
             "in_sequence_us": {k: round(sum(v) / len(v) * 1e3, 1) for k, v in t.items()}}
+
+
+def backbone_extra(dev, rest, rig, backbone: str, steps: int = 20):
+    """Extra, not the headline: the same B = 32 encoder step (topology build for a new batch + fwd + bwd, one
+    hipGraph) with the reference's other backbones (`models/model.py:39`: GCNConv / GATConv, selected by
+    network.backbone) - M edges/s on the same batch."""
+    from deformcontact_amd import graph as dc_graph
+    from deformcontact_amd.graphnet import ContactEncoder
+    torch.manual_seed(0)
+    enc = ContactEncoder([rest.x.shape[1], rig.x.shape[1]], 256, backbone=backbone).to(dev)
+    g_rest = torch.randn(rest.x.shape[0], 256, device=dev)
+    g_rig = torch.randn(rig.x.shape[0], 256, device=dev)
+
+    def body():
+        for p_ in enc.parameters():
+            p_.grad = None
+        a, b = enc(rest, rig)
+        torch.autograd.backward([a, b], [g_rest, g_rig])
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            dc_graph.clear_cache()
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    dc_graph.clear_cache()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    edges = rest.edge_index.shape[1] + rig.edge_index.shape[1]
+    return {"value": round(edges * steps / el / 1e6, 3), "unit": "M edges/s", "ms_per_step": round(el / steps * 1e3, 4),
+            "steps": steps, "step": "adjacency build (self loops rewritten) + fwd + bwd of the 2-layer encoder, both "
+                                    "branches, hidden 256, one hipGraph; no optimizer"}
 
 
 def full_step_b4(dev, steps: int = 20, batch: int = 4):
@@ -1102,6 +1146,13 @@ def main():
                                 "bit-identical to the default path (tests/test_merged.py)"}
             finally:
                 enc.merge_branches = was_merged
+        if world == 1 and not args.no_backbones:
+            out["other_backbones"] = {}
+            for bb in ("GCNConv", "GATConv"):
+                try:
+                    out["other_backbones"][bb] = backbone_extra(dev, rest, rig, bb)
+                except Exception as e:  # pragma: no cover
+                    out["other_backbones"][bb] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_radius100k:
             try:
                 out["radius100k"] = radius100k(dev, args.kernel_reps // 3 or 3)

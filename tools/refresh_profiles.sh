@@ -16,9 +16,13 @@ cd /tmp
 (cd "$R" && timeout -s KILL 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.txt" 2>&1; tail -2 "$O/smoke.txt")
 (cd "$R" && S=$(date +%s) && timeout -s KILL 900 python bench.py > "$O/bench.json" 2> "$O/bench.err"; echo "bench wall $(( $(date +%s) - S )) s" | tee "$O/bench_wall.txt"; tail -c 300 "$O/bench.json")
 (cd "$R" && timeout -s KILL 300 python tools/kbench.py > "$O/kbench.txt" 2>&1)
-Q="--no-cpu-baseline --no-full-step --no-strict-fp32 --no-radius100k --no-pmc"
+Q="--no-cpu-baseline --no-full-step --no-strict-fp32 --no-radius100k --no-pmc --no-merged --no-backbones"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/stats_serial" -- python3 "$R/bench.py" $Q --serial-branches > "$R/$O/stats_serial.log" 2>&1
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/stats_default" -- python3 "$R/bench.py" $Q > "$R/$O/stats_default.log" 2>&1
+# the GCNConv / GATConv encoders on the same batch (dc_gat_*, dc_sddmm_f32, self-loop adjacency build)
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/stats_backbones" -- python3 "$R/bench.py" --no-cpu-baseline --no-full-step --no-strict-fp32 --no-radius100k --no-pmc --no-merged --steps 5 --warmup 2 > "$R/$O/stats_backbones.log" 2>&1
+# the whole reference step at B = 32 (attention kernels), eager
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/stats_full_b32" -- python3 "$R/tools/full_step.py" --batch 32 --steps 3 > "$R/$O/stats_full_b32.log" 2>&1
 timeout -s KILL 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d "$R/$O/pmc_a" -- python3 "$R/tools/pmc_dense.py" > "$R/$O/pmc_a.log" 2>&1
 timeout -s KILL 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$R/$O/pmc_b" -- python3 "$R/tools/pmc_dense.py" > "$R/$O/pmc_b.log" 2>&1
 (cd "$R" && python tools/pmc_dense.py --parse "$O/pmc_a" "$O/pmc_b" > "$O/dense_pmc.json" 2> "$O/dense_pmc.err")
