@@ -39,7 +39,7 @@ def _ceil16(n: int) -> int:
 def _ceil_keys(n: int) -> int:
     """Padded key count: a multiple of 16 (one MFMA k-step); of 128 once there are enough keys, so that the dW-shaped
     products of the backward (dK, dV: [keys, d]) tile into the 128 x 256 blocks of ``k_dw_h2w``."""
-    return (n + 127) // 128 * 128 if n >= 1024 else _ceil16(n)
+    return (n + 127) // 128 * 128 if n >= 1024 else (n + 31) // 32 * 32      # (32: one key tile of the flash forward)
 
 
 def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
@@ -71,6 +71,12 @@ def _rowabsmax(L, t: torch.Tensor, st) -> torch.Tensor:
                "dc_rowabsmax_f32")
     return out
 
+
+#: forward in ONE launch per head (``dc_attn_flash_fwd``: online softmax over 32-key tiles, the scores never leave the
+#: compute unit) when d = dv = 256 - the shipped hidden width; ``DC_ATTN_FLASH=0``: the blocked three-launch form.
+#: Scores are bit-identical between the two (same products, same order), outputs agree to rounding.
+FLASH = os.environ.get("DC_ATTN_FLASH", "1") != "0"
+FLASH_D = 256
 
 #: recompute of a block's weights in the backward: exp(s - lse) in the score GEMM's epilogue (``DC_ATTN_FUSED_EXP=0``:
 #: separate ``dc_attn_exp_rows`` pass; bit-identical)
@@ -146,10 +152,16 @@ class _AttnCoreFn(torch.autograd.Function):
         ones = torch.ones(bq, dtype=torch.float32, device=dev)     # softmax weights are <= 1
         o = torch.empty((nsp, dv), dtype=torch.float32, device=dev)
         lse = torch.empty(nsp, dtype=torch.float32, device=dev)
-        s = torch.empty((bq, nrp), dtype=torch.float32, device=dev)
-        ws_o = _splitk_ws(L, bq, nrp, dv, dev)
+        flash_ok = FLASH and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
+        s = None if flash_ok else torch.empty((bq, nrp), dtype=torch.float32, device=dev)
+        ws_o = None if flash_ok else _splitk_ws(L, bq, nrp, dv, dev)
         vt = vp.t().contiguous() if EXACT_ALL else None
-        for r0 in range(0, nsp, bq):
+        flash = FLASH and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
+        if flash:
+            _lib.check(L.dc_attn_flash_fwd(qp.data_ptr(), d, qmax.data_ptr(), kimg.data_ptr(), kmax.data_ptr(),
+                                           vtimg.data_ptr(), vtmax.data_ptr(), nsp, nr, nrp, d, o.data_ptr(), dv,
+                                           lse.data_ptr(), st), "dc_attn_flash_fwd")
+        for r0 in (() if flash else range(0, nsp, bq)):
             rows = min(bq, nsp - r0)
             if EXACT_SCORES:
                 _gemm_exact(L, qp[r0:].data_ptr(), d, rows, d, kp, nrp, s.data_ptr(), nrp, st)

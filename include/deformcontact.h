@@ -486,6 +486,20 @@ int dc_tag_pack_weights(const float *const *ws, int nw, float *wcat, int64_t Fo,
  *   softmax_rows: s[i,0:n] <- softmax(s[i,0:n]), s[i,n:npad] <- 0, lse[i] = log sum_j exp(s[i,j])
  *   exp_rows    : s[i,0:n] <- exp(s[i,0:n] - lse[i]), s[i,n:npad] <- 0   (backward recompute)
  *   ds_rows     : dp[i,j] <- p[i,j] * (dp[i,j] - delta[i]) for j < npad; rowmax[i] = max_j |.| */
+/* Flash-style FORWARD of one attention head (models/model.py:13-21), d = dv = DC_ATTN_FLASH_D:
+ *   o[i,:] = sum_j softmax_j(q[i,:] . k[j,:]) v[j,:],   lse[i] = log sum_j exp(q[i,:] . k[j,:]),  j < nr
+ * in ONE launch - the scores of a 128-query tile never leave the compute unit (online softmax over 32-key tiles).
+ * Operands as the blocked form hands them to dc_tag_linear_fwd_h2p: q fp32 [ns, ldq] with its row maxima
+ * (dc_rowabsmax_f32); k_image / k_rowmax = dc_tag_weight_prep of the keys [nr_padded, d]; vt_image / vt_rowmax = the
+ * transposed image of the values (V^T [dv, nr_padded]); nr_padded % 32 == 0, rows nr..nr_padded of k / v are zero
+ * padding and are masked.  Same products, same order as the blocked form: score (i, j) is bit-identical to
+ * dc_tag_linear_fwd_h2p's, so the blocked backward (dc_tag_linear_fwd_h2p_exp with this lse) recomputes exactly
+ * the weights that were normalised here. */
+#define DC_ATTN_FLASH_D 256
+int dc_attn_flash_fwd(const float *q, int64_t ldq, const float *q_rowmax, const void *k_image,
+                      const float *k_rowmax, const void *vt_image, const float *vt_rowmax, int64_t ns,
+                      int64_t nr, int64_t nr_padded, int64_t d, float *o, int64_t ldo, float *lse,
+                      dc_stream_t stream);
 int dc_attn_softmax_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, float *lse,
                          dc_stream_t stream);
 int dc_attn_exp_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, const float *lse,
