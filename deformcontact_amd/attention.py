@@ -158,7 +158,10 @@ class _AttnCoreFn(torch.autograd.Function):
         vt = vp.t().contiguous() if EXACT_ALL else None
         flash = FLASH and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
         if flash:
-            _lib.check(L.dc_attn_flash_fwd(qp.data_ptr(), d, qmax.data_ptr(), kimg.data_ptr(), kmax.data_ptr(),
+            kuns = torch.empty_like(kmax)
+            _lib.check(L.dc_attn_flash_prep(vtimg.data_ptr(), dv, nrp, kmax.data_ptr(), kuns.data_ptr(), st),
+                       "dc_attn_flash_prep")
+            _lib.check(L.dc_attn_flash_fwd(qp.data_ptr(), d, qmax.data_ptr(), kimg.data_ptr(), kuns.data_ptr(),
                                            vtimg.data_ptr(), vtmax.data_ptr(), nsp, nr, nrp, d, o.data_ptr(), dv,
                                            lse.data_ptr(), st), "dc_attn_flash_fwd")
         for r0 in (() if flash else range(0, nsp, bq)):

@@ -20,20 +20,34 @@
 // lane & 31): max and sum over the keys are 16 in-lane operations + one exchange between the lane halves, the
 // running statistics are one scalar per lane, and the weights a lane holds - keys {4h..4h+3, 8+4h..11+4h} (+16) of
 // its query, h = lane >> 5 - are exactly a B-operand fragment of O^T += V^T P^T (contraction over the keys) once
-// the A operand (the V^T image) lists its keys in the same order; the staging pass writes the V^T tile into LDS
-// with the 4-key chunks of every 16 keys in the order (0, 2 | 1, 3) for that.
+// the A operand (the V^T image) lists its keys in the same order: dc_attn_flash_prep rewrites the image with the
+// 4-key chunks of every 16 keys in the order (0, 2 | 1, 3) for that.
 //
 // Per 32-key tile and wave: 48 MFMAs for S^T (16 k-steps x 3 products), 48 for O^T (8 row tiles of V^T x 2 k-steps x
 // 3 products), 64 ds_read_b128 fragment reads; q fragments (128 VGPRs) and the O^T accumulators (128) stay in
-// registers for the whole kernel (512 registers per lane at one wave per SIMD).  K / V^T tiles are staged through
-// registers into double-buffered LDS (2 x (32 + 32) KB), the loads of tile t+1 issued before the products of tile t.
+// registers for the whole kernel (512 registers per lane at one wave per SIMD).  Nothing is left for staging
+// registers (a first version that staged K / V^T through 32 registers exposed two L2 latencies per tile: 4.0 ms per
+// head at batch 32, 2.3 ms with the staging removed), so the tiles come in by LDS-DMA (global_load_lds, 16 bytes per
+// lane, 1 KB per instruction, no registers): three K buffers and two V^T buffers (160 KB, all of the LDS), the 8 + 8
+// instructions of a wave for V^T(t+1) and K(t+2) issued between the MFMA groups of tile t's score product, one
+// counted s_waitcnt vmcnt + raw s_barrier per tile.  LDS-DMA writes lane-linear, so the bank swizzle is applied on the
+// SOURCE side (a lane fetches the piece that belongs in its slot), and the key order the weights need is baked into
+// the V^T image once by dc_attn_flash_prep.  The keys' power-of-two scales come in through scalar loads.
+//
+// Register file by hand (all MFMAs are inline asm): the q fragments are pinned to 128 accumulation registers and read
+// from there as B operands, four of the eight output tiles live in the other accumulation registers, four in
+// architectural VGPRs.  With the builtins hipcc kept q in the 256 architectural registers, ran out, and moved ~140
+// registers per tile through v_accvgpr_read / write (or gathered scattered dwords in front of every MFMA).
+// Measured at batch 32 (32,768 queries x 24,384 keys, one head; tools/exp/attn_flash.py): 2.56 ms = 0.96 PFLOP/s of
+// fp16 products (0.38 of the nominal 2.5 PF, ~0.56 of what the chip sustains under DVFS); the blocked form's three
+// launches per 2,048-row block take 5.6 - 6.0 ms.  Timing ablations of this loop: no staging 2.30, no softmax
+// arithmetic 2.27, neither 2.10 ms - the two MFMA chains themselves set the time.
 #include "dc_dense.h"
 
 namespace dc {
 
 using fl_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using fl_f32x4 = __attribute__((ext_vector_type(4))) float;
-using fl_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using fl_u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 constexpr int kFlD = DC_ATTN_FLASH_D;          // d = dv
@@ -44,15 +58,15 @@ constexpr int kFlKSz = kFlT * kFlKRow;         // 32 KB
 constexpr int kFlVRow = kFlT * 4;              // bytes per V^T row and tile (2 records x 64 B)
 constexpr int kFlVSz = kFlD * kFlVRow;         // 32 KB
 constexpr int kFlORow = kFlD + 4;              // floats per query row of the epilogue transpose buffer
-constexpr int kFlSmem = 4 * 32 * kFlORow * 4;  // 133,120 B >= 2 * (kFlKSz + kFlVSz) + 256
+constexpr int kFlSmem = 3 * kFlKSz + 2 * kFlVSz;   // 160 KB (the epilogue's 4 x 32 x 260 floats fit inside)
 
 struct FlashParams {
     const float *q;        // [ns, ldq] fp32
     int64_t ldq;
     const float *qmax;     // [ns] row maxima of |q|
     const char *kimg;      // [nrp, d] fp16x2 image of the keys (rows scaled by kmax)
-    const float *kmax;     // [nrp]
-    const char *vtimg;     // [dv, nrp] fp16x2 image of V^T (rows scaled by vtmax)
+    const float *kuns;     // [nrp] h2_unscale(row maximum) of every key (dc_attn_flash_prep)
+    const char *vtimg;     // [dv, nrp] fp16x2 image of V^T (rows scaled by vtmax), chunks reordered (flash_vt_image)
     const float *vtmax;    // [dv]
     int64_t ns, nr, nrp;
     float *o;              // [ns, ldo]
@@ -62,12 +76,15 @@ struct FlashParams {
 
 __device__ __forceinline__ int fl_vswz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 1); }   // as hw_swz
 
+#define DC_FL_GPTR(p) ((const void __attribute__((address_space(1))) *)(p))
+#define DC_FL_LPTR(p) ((void __attribute__((address_space(3))) *)(p))
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_attn_flash_fwd(FlashParams p) {
     __shared__ __attribute__((aligned(16))) char smem[kFlSmem];
-    char *sK = smem, *sV = smem + 2 * kFlKSz;
-    float *sUk = reinterpret_cast<float *>(smem + 2 * kFlKSz + 2 * kFlVSz);       // 2 x 32 key unscale factors
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    char *sK = smem, *sV = smem + 3 * kFlKSz;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: DMA bases stay in SGPRs / M0
     const int64_t q0 = (int64_t)blockIdx.x * kFlQ + wid * 32;
     int64_t qrow = q0 + fr;
     qrow = qrow < p.ns ? qrow : p.ns - 1;
@@ -88,52 +105,36 @@ k_attn_flash_fwd(FlashParams p) {
                 qh[ks][i] = ha, qh[ks][4 + i] = hb;
                 ql[ks][i] = (_Float16)(a[i] - (float)ha), ql[ks][4 + i] = (_Float16)(b[i] - (float)hb);
             }
+            // every fragment as ONE 128-bit accumulation-register tuple from here on (left alone hipcc keeps the four
+            // dwords apart and gathers them in front of every MFMA)
+            asm volatile("" : "+a"(qh[ks]), "+a"(ql[ks]));
         }
     }
 
-    // ---- staging: K tile = 32 consecutive 1 KB rows of the image (piece pc of row r at pc ^ (r & 15): each 16-lane
-    // group of a ds_read_b128 fragment read sees 16 distinct 16-byte slots of the 256-byte bank row)
+    // ---- LDS-DMA staging.  An instruction moves 64 x 16 bytes into 1 KB of consecutive LDS: lane l fills slot l.
+    // K tile (32 rows of 1 KB, piece pc of row r in slot pc ^ (r & 15)): instruction (jj, hi) of wave w fills row
+    // r = 4 w + jj + 16 hi, whose swizzle only depends on 4 w + jj - four lane offsets.  V^T tile (256 rows of 128 B,
+    // piece q of row r in slot q ^ vswz(r)): instruction I = 8 w + j fills rows 8 I .. 8 I + 7 (lane l: row 8 I + (l >> 3),
+    // slot l & 7); vswz only depends on the low 4 row bits = 8 (I & 1) + (l >> 3) - two lane offsets.
     const int nt = (int)((p.nr + kFlT - 1) / kFlT);
-    fl_u32x4 rg[8];                                   // one staging register set, used for K then for V^T
-    float ruk = 0.f;
-    auto gloadK = [&](int t) {
-        const char *kb = p.kimg + (int64_t)t * kFlKSz;
+    unsigned kso[4], vso[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rg[j] = *reinterpret_cast<const fl_u32x4 *>(kb + (j * 256 + tid) * 16);
-        if (tid < 32) ruk = h2_unscale(p.kmax[(int64_t)t * kFlT + tid]);
+    for (int jj = 0; jj < 4; ++jj) kso[jj] = (unsigned)((4 * wid + jj) * kFlKRow + 16 * (lane ^ (4 * wid + jj)));
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        vso[e] = (unsigned)((lane >> 3) * (p.nrp * 4) + 16 * ((lane & 7) ^ fl_vswz(8 * e + (lane >> 3))));
+    const int64_t v8rows = 8 * p.nrp * 4;               // bytes between the row groups of consecutive V^T instructions
+    auto dma_k = [&](int t, int slot, int c) {           // instruction c (0..7) of this wave for K tile t
+        const int jj = c & 3, hi = c >> 2;
+        const char *src = p.kimg + (int64_t)t * kFlKSz + hi * 16 * kFlKRow;
+        char *dst = sK + slot * kFlKSz + (4 * wid + jj + 16 * hi) * kFlKRow;
+        __builtin_amdgcn_global_load_lds(DC_FL_GPTR(src + kso[jj]), DC_FL_LPTR(dst), 16, 0, 0);
     };
-    // piece j * 256 + tid of the tile: row 4 j + wid, piece tid & 63 -> slot piece ^ (row & 15); row & 15 = 4 (j & 3) + wid,
-    // so four lane offsets (j & 3) + an immediate (j >> 2) * 16 KB address all eight stores
-    int kst[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) kst[jj] = (4 * jj + wid) * kFlKRow + 16 * ((tid & 63) ^ (4 * jj + wid));
-    auto lstoreK = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            *reinterpret_cast<fl_u32x4 *>(sK + buf * kFlKSz + (j >> 2) * 16 * kFlKRow + kst[j & 3]) = rg[j];
-        if (tid < 32) sUk[buf * 32 + tid] = ruk;
-    };
-    // V^T tile: 8 threads per 128-byte row piece, 32 rows per pass; 32-bit lane offsets off a wave-uniform base
-    unsigned vgo[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) vgo[j] = (unsigned)(((tid >> 3) + 32 * j) * (p.nrp * 4) + (tid & 7) * 16);
-    auto gloadV = [&](int t) {
-        const char *vb = p.vtimg + (int64_t)t * kFlVRow;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rg[j] = *reinterpret_cast<const fl_u32x4 *>(vb + vgo[j]);
-    };
-    auto lstoreV = [&](int buf) {
-        // the 16 bytes a thread holds are chunks (2 cp, 2 cp + 1) of one plane of one record (4 keys each); chunk c goes
-        // to half (c & 1), 8-byte slot (c >> 1): half h of a plane then lists keys {4h..4h+3, 8+4h..11+4h}
-        const int k8 = tid & 7, m = k8 >> 2, pl = (k8 >> 1) & 1, cp = k8 & 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = (tid >> 3) + 32 * j, f = fl_vswz(row);
-            char *base = sV + buf * kFlVSz + row * kFlVRow + 8 * cp;
-            const int qp0 = 4 * m + 2 * pl;
-            *reinterpret_cast<fl_u32x2 *>(base + 16 * (qp0 ^ f)) = fl_u32x2{rg[j][0], rg[j][1]};
-            *reinterpret_cast<fl_u32x2 *>(base + 16 * ((qp0 + 1) ^ f)) = fl_u32x2{rg[j][2], rg[j][3]};
-        }
+    auto dma_v = [&](int t, int slot, int c) {           // instruction c (0..7) of this wave for V^T tile t
+        const int I = 8 * wid + c;
+        const char *src = p.vtimg + (int64_t)t * kFlVRow + I * v8rows;
+        char *dst = sV + slot * kFlVSz + I * 1024;
+        __builtin_amdgcn_global_load_lds(DC_FL_GPTR(src + vso[c & 1]), DC_FL_LPTR(dst), 16, 0, 0);
     };
 
     // fragment read offsets: the swizzle only touches the low 4 bits of a piece index, so 8 (K: k-step & 3, plane) and
@@ -152,63 +153,85 @@ k_attn_flash_fwd(FlashParams p) {
     float m_run = -INFINITY, l_run = 0.f;
     constexpr float kLog2e = 1.4426950408889634f;
 
-    gloadK(0);
-    lstoreK(0);
-    gloadV(0);
-    lstoreV(0);
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dma_k(0, 0, c);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dma_v(0, 0, c);
+    if (nt > 1) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dma_k(1, 1, c);
+    }
+    // the keys' power-of-two scales come in through SCALAR loads (constant address space: wave-uniform address, data
+    // written before the launch): a vector load inside the loop would make hipcc wait for vmcnt(0) - i.e. for the DMA
+    // queue - at its first use.  The next tile's 32 values are fetched right before the barrier that ends a tile.
+    const float __attribute__((address_space(4))) *kmaxc =
+        (const float __attribute__((address_space(4))) *)(uintptr_t)p.kuns;
+    // uk0[i] / uk1[i]: the scale of the key that accumulator register i holds in the lower / upper lane half - SSA
+    // vectors, not arrays (hipcc turns "fh ? uk[k + 4] : uk[k]" on an array into a lane-indexed load from a scratch
+    // copy: VMEM inside the loop, and a vmcnt(0) with it)
+    f32x16 uk0, uk1;
+    auto load_uk = [&](int64_t base) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (i & 3) + 8 * (i >> 2);
+            uk0[i] = kmaxc[base + kk], uk1[i] = kmaxc[base + kk + 4];
+        }
+    };
+    load_uk(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    int kslot = 0;                                       // t % 3
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) gloadK(t + 1);
+        const int vbuf = t & 1;
+        const int kslot2 = kslot == 0 ? 2 : kslot - 1;   // (t + 2) % 3
+        const bool more_v = t + 1 < nt, more_k = t + 2 < nt;
         // ---- S^T tile: rows = the tile's 32 keys, columns = this wave's 32 queries
         f32x16 st;
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = 0.f;
         {
-            // fragments of two k-steps are read while the six MFMAs of the previous two run (sched_barrier: hipcc
-            // otherwise hoists all 32 reads of the tile to the top - 128 registers - and spills)
-            const char *kb = sK + buf * kFlKSz;
-            fl_f16x8 kh0[2], kl0[2], kh1[2], kl1[2];
-            auto kfrags = [&](fl_f16x8 (&kh)[2], fl_f16x8 (&kl)[2], int g) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int ks = 2 * g + u;
-                    kh[u] = *reinterpret_cast<const fl_f16x8 *>(kb + (ks >> 2) * 256 + kfo[2 * (ks & 3)]);
-                    kl[u] = *reinterpret_cast<const fl_f16x8 *>(kb + (ks >> 2) * 256 + kfo[2 * (ks & 3) + 1]);
+            // the fragments of a k-step are read while the three MFMAs of the previous one run (sched_barrier: hipcc
+            // otherwise hoists all 32 reads of the tile to the top - 128 registers - and spills); the DMA instructions
+            // of the next tiles go one per MFMA group: V^T(t+1) first (it is waited for first), then K(t+2)
+            const char *kb = sK + kslot * kFlKSz;
+            fl_f16x8 kh[4], kl[4];                       // ring of four fragment sets: reads run three k-steps ahead
+            auto kfrags = [&](int ks) {
+                kh[ks & 3] = *reinterpret_cast<const fl_f16x8 *>(kb + (ks >> 2) * 256 + kfo[2 * (ks & 3)]);
+                kl[ks & 3] = *reinterpret_cast<const fl_f16x8 *>(kb + (ks >> 2) * 256 + kfo[2 * (ks & 3) + 1]);
+            };
+            auto kmma = [&](int ks) {
+                // same term order as k_fwd_h2w with x = q (A there) and W = k (B there): x_l w_h, x_h w_l, x_h w_h;
+                // the q fragments are read straight from the accumulation registers ("a")
+                asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kh[ks & 3]), "a"(ql[ks]));
+                asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kl[ks & 3]), "a"(qh[ks]));
+                asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kh[ks & 3]), "a"(qh[ks]));
+            };
+            auto dma1 = [&](int c) {                     // instruction c of this iteration's 16
+                if (c < 8) {
+                    if (more_v) dma_v(t + 1, vbuf ^ 1, c);
+                } else if (more_k) {
+                    dma_k(t + 2, kslot2, c - 8);
                 }
             };
-            auto kmma = [&](const fl_f16x8 (&kh)[2], const fl_f16x8 (&kl)[2], int g) {
+            kfrags(0);
+            kfrags(1);
+            kfrags(2);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int ks = 2 * g + u;
-                    // same term order as k_fwd_h2w with x = q (A there) and W = k (B there): x_l w_h, x_h w_l, x_h w_h
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[u], ql[ks], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[u], qh[ks], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[u], qh[ks], st, 0, 0, 0);
-                }
-            };
-            kfrags(kh0, kl0, 0);
-#pragma unroll
-            for (int g = 0; g < 8; g += 2) {
-                kfrags(kh1, kl1, g + 1);
-                kmma(kh0, kl0, g);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g + 2 < 8) kfrags(kh0, kl0, g + 2);
-                kmma(kh1, kl1, g + 1);
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks + 3 < 16) kfrags(ks + 3);
+                kmma(ks);
+                dma1(ks);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (t + 1 < nt) {                       // (the other K buffer was last read before the previous barrier)
-            lstoreK(buf ^ 1);
-            gloadV(t + 1);
-        }
+        // (the hazard recogniser does not see through the asm: a 32x32 MFMA result needs 18 idle issue slots before
+        // another instruction may read it)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(st));
         // ---- online softmax over the keys of this lane's query: reg i <-> key (i & 3) + 8 (i >> 2) + 4 fh
         float s[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const fl_f32x4 uk = *reinterpret_cast<const fl_f32x4 *>(sUk + buf * 32 + 8 * g + 4 * fh);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s[4 * g + i] = (st[4 * g + i] * uq) * uk[i];     // as the h2w epilogue: (acc * s_row) * s_col
+        for (int i = 0; i < 16; ++i) {
+            s[i] = (st[i] * uq) * (fh ? uk1[i] : uk0[i]);            // as the h2w epilogue: (acc * s_row) * s_col
         }
         if (t == nt - 1) {
             const int64_t kbase = (int64_t)t * kFlT + 4 * fh;
@@ -216,68 +239,80 @@ k_attn_flash_fwd(FlashParams p) {
             for (int i = 0; i < 16; ++i)
                 if (kbase + (i & 3) + 8 * (i >> 2) >= p.nr) s[i] = -INFINITY;
         }
-        float tm = s[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) tm = fmaxf(tm, s[i]);
-        tm = fmaxf(tm, __shfl_xor(tm, 32));
-        const float mn = fmaxf(m_run, tm);
-        if (__builtin_amdgcn_ballot_w64(mn > m_run) != 0) {        // rare once the running maxima have settled
-            const float alpha = __builtin_amdgcn_exp2f((m_run - mn) * kLog2e);    // 1 exactly where the max stays
-            l_run *= alpha;
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[mt][i] *= alpha;
-            m_run = mn;
-        }
-        float ps = 0.f;
         fl_f16x8 ph[2], pl[2];
+        {
+            float tm = s[0];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float e = __builtin_amdgcn_exp2f((s[i] - m_run) * kLog2e);
-            ps += e;
-            const _Float16 h = (_Float16)e;
-            ph[i >> 3][i & 7] = h;
-            pl[i >> 3][i & 7] = (_Float16)(e - (float)h);
+            for (int i = 1; i < 16; ++i) tm = fmaxf(tm, s[i]);
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const float mn = fmaxf(m_run, tm);
+            if (__builtin_amdgcn_ballot_w64(mn > m_run) != 0) {        // rare once the running maxima have settled
+                const float alpha = __builtin_amdgcn_exp2f((m_run - mn) * kLog2e);    // 1 exactly where the max stays
+                l_run *= alpha;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[mt][i] *= alpha;
+                m_run = mn;
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f((s[i] - m_run) * kLog2e);
+                ps += e;
+                const _Float16 h = (_Float16)e;
+                ph[i >> 3][i & 7] = h;
+                pl[i >> 3][i & 7] = (_Float16)(e - (float)h);
+            }
+            ps += __shfl_xor(ps, 32);
+            l_run += ps;
         }
-        ps += __shfl_xor(ps, 32);
-        l_run += ps;
         // ---- O^T += V^T_tile P^T: rows = dv (8 tiles of 32), contraction over the tile's keys (2 k-steps of 16)
         {
-            const char *vb = sV + buf * kFlVSz;
-            fl_f16x8 vh0[2], vl0[2], vh1[2], vl1[2];
-            auto vfrags = [&](fl_f16x8 (&vh)[2], fl_f16x8 (&vl)[2], int mt) {
-                const char *vr = vb + mt * 32 * kFlVRow;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    vh[m] = *reinterpret_cast<const fl_f16x8 *>(vr + vfo[2 * m]);
-                    vl[m] = *reinterpret_cast<const fl_f16x8 *>(vr + vfo[2 * m + 1]);
+            const char *vb = sV + vbuf * kFlVSz;
+            fl_f16x8 vh[4], vl[4];                       // ring of four fragment sets, reads three steps ahead
+            auto vfrags = [&](int c) {                   // c = 2 mt + m
+                const char *vr = vb + (c >> 1) * 32 * kFlVRow;
+                vh[c & 3] = *reinterpret_cast<const fl_f16x8 *>(vr + vfo[2 * (c & 1)]);
+                vl[c & 3] = *reinterpret_cast<const fl_f16x8 *>(vr + vfo[2 * (c & 1) + 1]);
+            };
+            auto vmma = [&](int c) {
+                const int mt = c >> 1, m = c & 1;
+                // blocked form: x = P (A there), W = V^T (B there): x_l w_h, x_h w_l, x_h w_h.  Register file by hand:
+                // the q fragments fill half of the accumulation registers, so only four of the eight output tiles
+                // live there ("+a"), the other four in architectural VGPRs ("+v") - 64 accumulation registers stay
+                // free and hipcc stops shuffling tuples (v_accvgpr_mov) in front of every MFMA
+                if (mt < 4) {
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vh[c & 3]), "v"(pl[m]));
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vl[c & 3]), "v"(ph[m]));
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vh[c & 3]), "v"(ph[m]));
+                } else {
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vh[c & 3]), "v"(pl[m]));
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vl[c & 3]), "v"(ph[m]));
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vh[c & 3]), "v"(ph[m]));
                 }
             };
-            auto vmma = [&](const fl_f16x8 (&vh)[2], const fl_f16x8 (&vl)[2], int mt) {
+            asm volatile("s_nop 1" : "+v"(ph[0]), "+v"(pl[0]), "+v"(ph[1]), "+v"(pl[1]));   // VALU write -> MFMA read
+            vfrags(0);
+            vfrags(1);
+            vfrags(2);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    // blocked form: x = P (A there), W = V^T (B there): x_l w_h, x_h w_l, x_h w_h
-                    oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[m], pl[m], oacc[mt], 0, 0, 0);
-                    oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[m], ph[m], oacc[mt], 0, 0, 0);
-                    oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[m], ph[m], oacc[mt], 0, 0, 0);
-                }
-            };
-            vfrags(vh0, vl0, 0);
-#pragma unroll
-            for (int mt = 0; mt < 8; mt += 2) {
-                vfrags(vh1, vl1, mt + 1);
-                vmma(vh0, vl0, mt);
-                __builtin_amdgcn_sched_barrier(0);
-                if (mt + 2 < 8) vfrags(vh0, vl0, mt + 2);
-                vmma(vh1, vl1, mt + 1);
+            for (int c = 0; c < 16; ++c) {
+                if (c + 3 < 16) vfrags(c + 3);
+                vmma(c);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (t + 1 < nt) lstoreV(buf ^ 1);
-        __syncthreads();
+        if (t + 1 < nt) load_uk((int64_t)(t + 1) * kFlT);   // the next tile's key scales (arrive under the barrier)
+        // V^T(t+1) (and K(t+1), older) must have landed; the 8 instructions of K(t+2) may stay in flight
+        if (more_k) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        kslot = kslot == 2 ? 0 : kslot + 1;
+
     }
 
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");          // last MFMA results -> VALU reads (asm MFMAs: no automatic nops)
     // ---- epilogue: O[q, dv] = O^T acc / l * unscale(vtmax[dv]) through a per-wave LDS transpose, lse = m + log l
     const float inv_l = 1.0f / l_run;
     float *so = reinterpret_cast<float *>(smem) + wid * 32 * kFlORow;
@@ -303,25 +338,59 @@ k_attn_flash_fwd(FlashParams p) {
     }
 }
 
+// the V^T image with the 4-key chunks (8 bytes) of every plane of every 64-byte record in the order (c0, c2, c1, c3)
+__global__ void __launch_bounds__(256)
+k_attn_flash_vt_image(fl_u32x2 *img, int64_t nchunks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 32-byte plane
+    if (4 * i >= nchunks) return;
+    fl_u32x2 *c = img + 4 * i;
+    const fl_u32x2 c1 = c[1], c2 = c[2];
+    c[1] = c2, c[2] = c1;
+}
+
+__global__ void __launch_bounds__(256)
+k_attn_flash_unscale(const float *rowmax, float *uns, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) uns[i] = h2_unscale(rowmax[i]);
+}
+
 }  // namespace dc
 
 using namespace dc;
 
+extern "C" int dc_attn_flash_prep(void *vt_image, int64_t dv, int64_t nr_padded, const float *k_rowmax,
+                                  float *k_unscale, dc_stream_t stream) {
+    DC_REQUIRE(dv >= 0 && nr_padded >= 0 && nr_padded % 16 == 0, "dc_attn_flash_prep: nr_padded must be a multiple of 16");
+    const int64_t nchunks = dv * nr_padded / 2;          // 8-byte chunks: 4 bytes per element
+    if (nchunks > 0) {
+        DC_REQUIRE(vt_image && ((uintptr_t)vt_image & 15) == 0, "dc_attn_flash_prep: null or misaligned image");
+        const int64_t nthreads = nchunks / 4;
+        hipLaunchKernelGGL(k_attn_flash_vt_image, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, (fl_u32x2 *)vt_image, nchunks);
+    }
+    if (nr_padded > 0) {
+        DC_REQUIRE(k_rowmax && k_unscale, "dc_attn_flash_prep: null key maxima / output");
+        hipLaunchKernelGGL(k_attn_flash_unscale, dim3((unsigned)((nr_padded + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, k_rowmax, k_unscale, nr_padded);
+    }
+    return check_launch("dc_attn_flash_prep");
+}
+
 extern "C" int dc_attn_flash_fwd(const float *q, int64_t ldq, const float *q_rowmax, const void *k_image,
-                                 const float *k_rowmax, const void *vt_image, const float *vt_rowmax, int64_t ns,
+                                 const float *k_unscale, const void *vt_image, const float *vt_rowmax, int64_t ns,
                                  int64_t nr, int64_t nr_padded, int64_t d, float *o, int64_t ldo, float *lse,
                                  dc_stream_t stream) {
     DC_REQUIRE(ns >= 0 && nr >= 1 && nr_padded >= nr, "dc_attn_flash_fwd: needs ns >= 0, 1 <= nr <= nr_padded");
     if (ns == 0) return DC_OK;
     DC_REQUIRE(d == kFlD, "dc_attn_flash_fwd: d = dv = %d only (got %lld); use the blocked form", kFlD, (long long)d);
     DC_REQUIRE(nr_padded % kFlT == 0, "dc_attn_flash_fwd: nr_padded must be a multiple of %d", kFlT);
-    DC_REQUIRE(q && q_rowmax && k_image && k_rowmax && vt_image && vt_rowmax && o && lse,
+    DC_REQUIRE(q && q_rowmax && k_image && k_unscale && vt_image && vt_rowmax && o && lse,
                "dc_attn_flash_fwd: null pointer");
     DC_REQUIRE(ldq >= d && ldo >= d && ldq % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)q & 15) == 0 &&
                    ((uintptr_t)o & 15) == 0 && ((uintptr_t)k_image & 15) == 0 && ((uintptr_t)vt_image & 15) == 0,
                "dc_attn_flash_fwd: rows must be 16-byte aligned");
     DC_REQUIRE((ns + kFlQ - 1) / kFlQ < (int64_t)INT32_MAX, "dc_attn_flash_fwd: too many query tiles");
-    FlashParams p{q, ldq, q_rowmax, (const char *)k_image, k_rowmax, (const char *)vt_image, vt_rowmax,
+    FlashParams p{q, ldq, q_rowmax, (const char *)k_image, k_unscale, (const char *)vt_image, vt_rowmax,
                   ns, nr, nr_padded, o, ldo, lse};
     hipLaunchKernelGGL(k_attn_flash_fwd, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0,
                        (hipStream_t)stream, p);

@@ -490,14 +490,22 @@ int dc_tag_pack_weights(const float *const *ws, int nw, float *wcat, int64_t Fo,
  *   o[i,:] = sum_j softmax_j(q[i,:] . k[j,:]) v[j,:],   lse[i] = log sum_j exp(q[i,:] . k[j,:]),  j < nr
  * in ONE launch - the scores of a 128-query tile never leave the compute unit (online softmax over 32-key tiles).
  * Operands as the blocked form hands them to dc_tag_linear_fwd_h2p: q fp32 [ns, ldq] with its row maxima
- * (dc_rowabsmax_f32); k_image / k_rowmax = dc_tag_weight_prep of the keys [nr_padded, d]; vt_image / vt_rowmax = the
- * transposed image of the values (V^T [dv, nr_padded]); nr_padded % 32 == 0, rows nr..nr_padded of k / v are zero
- * padding and are masked.  Same products, same order as the blocked form: score (i, j) is bit-identical to
+ * (dc_rowabsmax_f32); k_image = dc_tag_weight_prep of the keys [nr_padded, d], k_unscale from dc_attn_flash_prep;
+ * vt_image / vt_rowmax = the transposed image of the values (V^T [dv, nr_padded]) AFTER dc_attn_flash_prep; nr_padded % 32 == 0,
+ * rows nr..nr_padded of k / v are zero padding and are masked.  Same products, same order as the blocked form: score (i, j) is bit-identical to
  * dc_tag_linear_fwd_h2p's, so the blocked backward (dc_tag_linear_fwd_h2p_exp with this lse) recomputes exactly
  * the weights that were normalised here. */
 #define DC_ATTN_FLASH_D 256
+/* Operand preparation of dc_attn_flash_fwd, two small launches: (i) rewrites the transposed image of
+ * dc_tag_weight_prep vt_image [dv, nr_padded] IN PLACE into the key order the kernel consumes (the four 4-key chunks of
+ * every plane of every 16-key record in the order 0, 2, 1, 3: a lane of the transposed score tile holds the weights
+ * of keys {4h..4h+3, 8+4h..11+4h}; the rewrite is its own inverse); (ii) k_unscale[j] = the exact power of two that
+ * undoes the scaling of row j of the key image (from k_rowmax of dc_tag_weight_prep), which the kernel fetches with
+ * scalar loads. */
+int dc_attn_flash_prep(void *vt_image, int64_t dv, int64_t nr_padded, const float *k_rowmax, float *k_unscale,
+                       dc_stream_t stream);
 int dc_attn_flash_fwd(const float *q, int64_t ldq, const float *q_rowmax, const void *k_image,
-                      const float *k_rowmax, const void *vt_image, const float *vt_rowmax, int64_t ns,
+                      const float *k_unscale, const void *vt_image, const float *vt_rowmax, int64_t ns,
                       int64_t nr, int64_t nr_padded, int64_t d, float *o, int64_t ldo, float *lse,
                       dc_stream_t stream);
 int dc_attn_softmax_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, float *lse,

@@ -63,15 +63,20 @@ def test_flash_forward_row_statistics_and_heavy_tailed_rows(monkeypatch):
     v = torch.randn(nr, 256, device=DEV)
     v[:, ::9] *= 100.0
     monkeypatch.setattr(attention, "FLASH", True)
-    out = attention_core(q, k, v)
+    out = _np(attention_core(q, k, v))
+    monkeypatch.setattr(attention, "FLASH", False)
+    blk = _np(attention_core(q, k, v))
     qd, kd, vd = (t.double().cpu() for t in (q, k, v))
     kc = kd - kd.mean(dim=0, keepdim=True)                 # attention_core centres the keys (same softmax)
     s = qd @ kc.t()
-    ref = torch.softmax(s, dim=-1) @ vd
-    assert rel_err(_np(out), ref.numpy()) < 5e-6
+    ref = (torch.softmax(s, dim=-1) @ vd).numpy()
+    # scores of a few hundred carry ulp(|s|) ~ 3e-5 of absolute error in fp32 whoever computes them: the yardstick is
+    # the blocked form, which has bit-identical scores
+    e_flash, e_blk = rel_err(out, ref), rel_err(blk, ref)
+    assert e_flash <= max(5e-6, 2 * e_blk), (e_flash, e_blk)
     # every output column separately (the V^T image is scaled per column)
-    err = np.abs(_np(out) - ref.numpy()).max(axis=0) / np.abs(ref.numpy()).max(axis=0)
-    assert err.max() < 2e-5
+    col = lambda a: (np.abs(a - ref).max(axis=0) / np.abs(ref).max(axis=0)).max()
+    assert col(out) <= max(2e-5, 2 * col(blk)), (col(out), col(blk))
 
 
 def test_flash_forward_is_deterministic_and_handles_ragged_query_tiles(monkeypatch):

@@ -45,12 +45,14 @@ def main():
     kp, vp = attention._pad_rows(k - k.mean(dim=0, keepdim=True), nrp), attention._pad_rows(v, nrp)
     kmax, kimg, _, _ = attention._prep(L, kp, False, st)
     _, _, vtimg, vtmax = attention._prep(L, vp, True, st)
+    kuns = torch.empty_like(kmax)
+    _lib.check(L.dc_attn_flash_prep(vtimg.data_ptr(), 256, nrp, kmax.data_ptr(), kuns.data_ptr(), st), "dc_attn_flash_prep")
     qmax = attention._rowabsmax(L, q, st)
     o = torch.empty((ns, 256), device=dev)
     lse = torch.empty(ns, device=dev)
 
     def launch():
-        _lib.check(L.dc_attn_flash_fwd(q.data_ptr(), 256, qmax.data_ptr(), kimg.data_ptr(), kmax.data_ptr(),
+        _lib.check(L.dc_attn_flash_fwd(q.data_ptr(), 256, qmax.data_ptr(), kimg.data_ptr(), kuns.data_ptr(),
                                        vtimg.data_ptr(), vtmax.data_ptr(), ns, nr, nrp, 256, o.data_ptr(), 256,
                                        lse.data_ptr(), st), "dc_attn_flash_fwd")
     launch()
