@@ -193,18 +193,26 @@ k_attn_flash_fwd(FlashParams p) {
             // the fragments of a k-step are read while the three MFMAs of the previous one run (sched_barrier: hipcc
             // otherwise hoists all 32 reads of the tile to the top - 128 registers - and spills); the DMA instructions
             // of the next tiles go one per MFMA group: V^T(t+1) first (it is waited for first), then K(t+2)
-            const char *kb = sK + kslot * kFlKSz;
-            fl_f16x8 kh[4], kl[4];                       // ring of four fragment sets: reads run three k-steps ahead
+            // Fragment reads and their waits are written out (inline asm): with LDS-DMA in the loop hipcc's own counter
+            // bookkeeping falls back to s_waitcnt lgkmcnt(0) - a full drain that exposes the LDS latency every fourth
+            // k-step.  Ring of four fragment sets, reads three k-steps ahead, counted waits (LDS returns in order).
+            unsigned ka[8];
+            {
+                const unsigned kbase = (unsigned)(uintptr_t)DC_FL_LPTR(sK + kslot * kFlKSz);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) ka[c] = kbase + (unsigned)kfo[c];
+            }
+            fl_f16x8 kh[4], kl[4];
             auto kfrags = [&](int ks) {
-                kh[ks & 3] = *reinterpret_cast<const fl_f16x8 *>(kb + (ks >> 2) * 256 + kfo[2 * (ks & 3)]);
-                kl[ks & 3] = *reinterpret_cast<const fl_f16x8 *>(kb + (ks >> 2) * 256 + kfo[2 * (ks & 3) + 1]);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kh[ks & 3]) : "v"(ka[2 * (ks & 3)]), "i"((ks >> 2) * 256));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kl[ks & 3]) : "v"(ka[2 * (ks & 3) + 1]), "i"((ks >> 2) * 256));
             };
             auto kmma = [&](int ks) {
                 // same term order as k_fwd_h2w with x = q (A there) and W = k (B there): x_l w_h, x_h w_l, x_h w_h;
                 // the q fragments are read straight from the accumulation registers ("a")
-                asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kh[ks & 3]), "a"(ql[ks]));
-                asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kl[ks & 3]), "a"(qh[ks]));
-                asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kh[ks & 3]), "a"(qh[ks]));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kh[ks & 3]), "a"(ql[ks]));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kl[ks & 3]), "a"(qh[ks]));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(st) : "v"(kh[ks & 3]), "a"(qh[ks]));
             };
             auto dma1 = [&](int c) {                     // instruction c of this iteration's 16
                 if (c < 8) {
@@ -219,6 +227,11 @@ k_attn_flash_fwd(FlashParams p) {
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 if (ks + 3 < 16) kfrags(ks + 3);
+                // the 2 x (sets read after set ks) youngest reads may still be in flight
+                if (ks < 13) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else if (ks == 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else if (ks == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 kmma(ks);
                 dma1(ks);
                 __builtin_amdgcn_sched_barrier(0);
@@ -269,12 +282,16 @@ k_attn_flash_fwd(FlashParams p) {
         }
         // ---- O^T += V^T_tile P^T: rows = dv (8 tiles of 32), contraction over the tile's keys (2 k-steps of 16)
         {
-            const char *vb = sV + vbuf * kFlVSz;
+            unsigned va[4];
+            {
+                const unsigned vbase = (unsigned)(uintptr_t)DC_FL_LPTR(sV + vbuf * kFlVSz);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) va[c] = vbase + (unsigned)vfo[c];
+            }
             fl_f16x8 vh[4], vl[4];                       // ring of four fragment sets, reads three steps ahead
             auto vfrags = [&](int c) {                   // c = 2 mt + m
-                const char *vr = vb + (c >> 1) * 32 * kFlVRow;
-                vh[c & 3] = *reinterpret_cast<const fl_f16x8 *>(vr + vfo[2 * (c & 1)]);
-                vl[c & 3] = *reinterpret_cast<const fl_f16x8 *>(vr + vfo[2 * (c & 1) + 1]);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vh[c & 3]) : "v"(va[2 * (c & 1)]), "i"((c >> 1) * 32 * kFlVRow));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vl[c & 3]) : "v"(va[2 * (c & 1) + 1]), "i"((c >> 1) * 32 * kFlVRow));
             };
             auto vmma = [&](int c) {
                 const int mt = c >> 1, m = c & 1;
@@ -283,13 +300,13 @@ k_attn_flash_fwd(FlashParams p) {
                 // live there ("+a"), the other four in architectural VGPRs ("+v") - 64 accumulation registers stay
                 // free and hipcc stops shuffling tuples (v_accvgpr_mov) in front of every MFMA
                 if (mt < 4) {
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vh[c & 3]), "v"(pl[m]));
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vl[c & 3]), "v"(ph[m]));
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vh[c & 3]), "v"(ph[m]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vh[c & 3]), "v"(pl[m]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vl[c & 3]), "v"(ph[m]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[mt]) : "v"(vh[c & 3]), "v"(ph[m]));
                 } else {
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vh[c & 3]), "v"(pl[m]));
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vl[c & 3]), "v"(ph[m]));
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vh[c & 3]), "v"(ph[m]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vh[c & 3]), "v"(pl[m]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vl[c & 3]), "v"(ph[m]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(oacc[mt]) : "v"(vh[c & 3]), "v"(ph[m]));
                 }
             };
             asm volatile("s_nop 1" : "+v"(ph[0]), "+v"(pl[0]), "+v"(ph[1]), "+v"(pl[1]));   // VALU write -> MFMA read
@@ -299,6 +316,10 @@ k_attn_flash_fwd(FlashParams p) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 if (c + 3 < 16) vfrags(c + 3);
+                if (c < 13) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else if (c == 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else if (c == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 vmma(c);
                 __builtin_amdgcn_sched_barrier(0);
             }
