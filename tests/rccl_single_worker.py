@@ -1,0 +1,37 @@
+"""One rank on cuda:0 over RCCL (backend "nccl"): the collectives bench.py / train.py issue at N > 1 - parameter
+broadcast, the flat-bucket gradient all-reduce with ReduceOp.AVG, the float64 MAX of the timing, barrier - on the real
+library, so that an unsupported op or dtype shows up on the 1-GPU test box and not first on the 8-GPU node."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from deformcontact_amd import dp
+    from deformcontact_amd.graphnet import ContactEncoder
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256).to(dev)
+    dp.broadcast_parameters(enc)
+    bucket = dp.GradBucket(enc.parameters(), direct=True)
+    bucket.zero()
+    bucket.flat.fill_(3.0)
+    dist.all_reduce(bucket.flat, op=dist.ReduceOp.AVG)            # what GradBucket.all_reduce_mean issues at N > 1
+    t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # bench.py's max-over-ranks of the elapsed time
+    dist.barrier()
+    torch.cuda.synchronize()
+    assert float(bucket.flat.min()) == 3.0 and float(bucket.flat.max()) == 3.0 and float(t) == 1.25
+    assert dist.get_backend() == "nccl" and bucket.flat.numel() * 4 >= 572416 * 4
+    dist.destroy_process_group()
+    print("RCCL_OK", bucket.flat.numel())
+
+
+if __name__ == "__main__":
+    main()

@@ -46,3 +46,21 @@ def test_two_rank_graphed_train_step_equals_single_process_mean_gradient(tmp_pat
     assert r0["losses"] != r1["losses"]                                   # different batches per rank
     # replicas == single process on the mean gradient: same kernels, same order -> the same bits
     assert r0["bit_identical"], f"max |diff| {r0['max_abs_diff']:.3e} at scale {r0['scale']:.3e}"
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_of_the_n_gpu_path_on_one_rank():
+    """backend "nccl" (= RCCL) with world_size 1 on the test box's GPU: init with device_id, broadcast, all_reduce(AVG)
+    on the flat gradient bucket, float64 MAX, barrier - the ops `bench.py --gpus N` and `train.py` issue at N > 1."""
+    if torch.cuda.is_initialized():
+        pytest.skip("HIP already initialised in this process; not starting child processes from it")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_worker.py")], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    assert b"RCCL_OK" in r.stdout
