@@ -32,6 +32,8 @@ _SIGNATURES = {
     "dc_graph_build_segmented": (c_int, [_vp, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64), c_int,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dc_attn_flash_prep": (c_int, [_vp, c_int64, c_int64, _vp, _vp, _vp]),
+    "dc_attn_flash_ds": (c_int, [_vp, c_int64, _vp, _vp, c_int64, _vp, _vp, _vp, _vp, _vp, _vp, c_int64, c_int64,
+                                 c_int64, c_int64, _vp, _vp, c_int64, _vp, _vp]),
     "dc_attn_flash_fwd": (c_int, [_vp, c_int64, _vp, _vp, _vp, _vp, _vp, c_int64, c_int64, c_int64, c_int64, _vp,
                                   c_int64, _vp, _vp]),
     "dc_spmm_f32_window": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,

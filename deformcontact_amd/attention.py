@@ -77,6 +77,12 @@ def _rowabsmax(L, t: torch.Tensor, st) -> torch.Tensor:
 #: Scores are bit-identical between the two (same products, same order), outputs agree to rounding.
 FLASH = os.environ.get("DC_ATTN_FLASH", "1") != "0"
 FLASH_D = 256
+#: backward: P and dS for ALL rows from one two-sweep launch (``dc_attn_flash_ds``) followed by three large GEMMs,
+#: instead of six launches per 2,048-row block; needs 2 x Ns x Nr floats (6.4 GB per head at batch 32).
+#: ``DC_ATTN_FLASH_BWD=0``: the blocked backward.
+FLASH_BWD = os.environ.get("DC_ATTN_FLASH_BWD", "1") != "0"
+#: above this many bytes of P + dS the backward falls back to the blocked form
+FLASH_BWD_MAX_BYTES = int(float(os.environ.get("DC_ATTN_FLASH_BWD_MAX_GB", "16")) * (1 << 30))
 
 #: recompute of a block's weights in the backward: exp(s - lse) in the score GEMM's epilogue (``DC_ATTN_FUSED_EXP=0``:
 #: separate ``dc_attn_exp_rows`` pass; bit-identical)
@@ -191,10 +197,14 @@ class _AttnCoreFn(torch.autograd.Function):
         st = current_stream_ptr(dev)
         nsp, nrp = qp.size(0), kp.size(0)
         gop = _pad_rows(go.contiguous(), nsp)
-        delta = (gop * o).sum(dim=1)
         gomax = _rowabsmax(L, gop, st)
         vmax, vimg, _, _ = _prep(L, vp, False, st)                 # rows of V over dv   (dP = dO V^T)
         _, _, ktimg, ktmax = _prep(L, kp, True, st)                # rows of K^T over keys (dQ = dS K)
+        if (FLASH_BWD and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
+                and DELTA_IN_KERNEL and 8 * nsp * nrp <= FLASH_BWD_MAX_BYTES):
+            return _AttnCoreFn._backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg, vmax,
+                                               ktimg, ktmax, ns, nr, d, dv)
+        delta = (gop * o).sum(dim=1)
         ones = torch.ones(bq, dtype=torch.float32, device=dev)
         gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
         gk = torch.empty((nrp, d), dtype=torch.float32, device=dev)
@@ -261,6 +271,38 @@ class _AttnCoreFn(torch.autograd.Function):
                         _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp,
                         g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
         return gq[:ns], gk[:nr], gv[:nr], None
+
+
+def _backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax, ns, nr, d, dv):
+    """Backward with P and dS of ALL rows from ``dc_attn_flash_ds`` (two sweeps per 128-query tile, delta from the same
+    recomputed P and dP that form dS), then dQ = dS K, dK = dS^T Q, dV = P^T dO as three launches over all rows."""
+    nsp, nrp = qp.size(0), kp.size(0)
+    kuns, vuns = torch.empty_like(kmax), torch.empty_like(vmax)
+    _lib.check(L.dc_attn_flash_prep(None, 0, nrp, kmax.data_ptr(), kuns.data_ptr(), st), "dc_attn_flash_prep")
+    _lib.check(L.dc_attn_flash_prep(None, 0, nrp, vmax.data_ptr(), vuns.data_ptr(), st), "dc_attn_flash_prep")
+    p = torch.empty((nsp, nrp), dtype=torch.float32, device=dev)
+    ds = torch.empty((nsp, nrp), dtype=torch.float32, device=dev)
+    dsmax = torch.empty(nsp, dtype=torch.float32, device=dev)
+    _lib.check(L.dc_attn_flash_ds(qp.data_ptr(), d, qmax.data_ptr(), gop.data_ptr(), dv, gomax.data_ptr(),
+                                  kimg.data_ptr(), kuns.data_ptr(), vimg.data_ptr(), vuns.data_ptr(), lse.data_ptr(),
+                                  nsp, nr, nrp, d, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(), st),
+               "dc_attn_flash_ds")
+    gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
+    gk = torch.empty((nrp, d), dtype=torch.float32, device=dev)
+    gv = torch.empty((nrp, dv), dtype=torch.float32, device=dev)
+    _gemm(L, ds.data_ptr(), nrp, nsp, nrp, ktimg, d, gq.data_ptr(), d, dsmax.data_ptr(), ktmax, st,
+          _splitk_ws(L, nsp, nrp, d, dev))
+    ones = torch.ones(nsp, dtype=torch.float32, device=dev)        # softmax weights are <= 1
+    nb = max(L.dc_tag_linear_bwd_dw_workspace_bytes(nsp, d, nrp, 1), L.dc_tag_linear_bwd_dw_workspace_bytes(nsp, dv, nrp, 1))
+    scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    for g_t, g_max, x_t, x_ld, x_max, out_t, fi in ((ds, dsmax, qp, d, qmax, gk, d), (p, ones, gop, dv, gomax, gv, dv)):
+        _lib.check(L.dc_tag_linear_bwd_dw_h2(
+            g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1, _ptr_array([out_t]), 1, fi, None,
+            0, scratch.data_ptr(), nb, nsp, fi, nrp, g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
+    return gq[:ns], gk[:nr], gv[:nr], None
+
+
+_AttnCoreFn._backward_flash = staticmethod(_backward_flash)
 
 
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,

@@ -359,6 +359,230 @@ k_attn_flash_fwd(FlashParams p) {
     }
 }
 
+// ---- backward producer: P = exp(S - lse), dS = P o (dP - delta) for ALL rows in one launch ---------------------------
+// The blocked backward makes them per 2,048-row block with three launches - score GEMM + exp epilogue (writes P), dP GEMM
+// (writes dP), dc_attn_ds_rows (reads both, writes dS) - each bound by its 200 MB of stores: 442 us per block and head.
+// Here one workgroup owns 128 queries (the forward's skeleton: transposed tiles, q AND dO fragments resident in the 256
+// accumulation registers, K / V row tiles by LDS-DMA) and sweeps the keys twice:
+//   sweep 1: S^T = K_t Q^T, dP^T = V_t dO^T  ->  delta_i = sum_j P_ij dP_ij / sum_j P_ij   (nothing written)
+//   sweep 2: the same products again (bit for bit), dS = P (dP - delta); P and dS tiles go out through a per-wave LDS
+//            transpose as full 128-byte row segments, the row maxima of |dS| at the end.
+// delta comes from the SAME recomputed P and dP that form dS (row sums of dS vanish to rounding - the precision fix of
+// round 2), which is what the second sweep is for.  4 GEMM-equivalents instead of 2, but no score-sized
+// round trip: P and dS are written once.  Downstream (dQ = dS K, dK = dS^T Q, dV = P^T dO) the existing kernels run as
+// three launches over all rows.
+constexpr int kDsTRow = 36;                                   // floats per row of the transpose region (32 + pad, 16-byte rows)
+constexpr int kDsTSz = 32 * kDsTRow * 4;                      // 4,608 B per wave
+constexpr int kDsSmem = 4 * kFlKSz + 4 * kDsTSz;              // 2 K + 2 V row tiles + 4 transpose regions = 149,504 B
+
+struct FlashDsParams {
+    const float *q;        // [ns, ldq]
+    int64_t ldq;
+    const float *qmax;     // [ns]
+    const float *go;       // [ns, ldgo] upstream gradient of the head's output
+    int64_t ldgo;
+    const float *gomax;    // [ns]
+    const char *kimg;      // [nrp, d] image of the (centred) keys
+    const float *kuns;     // [nrp] unscale factors of its rows
+    const char *vimg;      // [nrp, dv] image of the values' ROWS
+    const float *vuns;     // [nrp]
+    const float *lse;      // [ns] row log-sum-exp of the forward
+    int64_t ns, nr, nrp;
+    float *pmat, *dsmat;   // [ns, ldp] each
+    int64_t ldp;
+    float *dsmax;          // [ns] max_j |dS_ij|
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_attn_flash_ds(FlashDsParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[kDsSmem];
+    char *sK = smem, *sV = smem + 2 * kFlKSz;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *sT = reinterpret_cast<float *>(smem + 4 * kFlKSz + wid * kDsTSz);
+    const int64_t q0 = (int64_t)blockIdx.x * kFlQ + wid * 32;
+    int64_t qrow = q0 + fr;
+    qrow = qrow < p.ns ? qrow : p.ns - 1;
+
+    // ---- q and dO rows of this lane's query as B-operand fragments, pinned to the accumulation registers
+    const float uq = h2_unscale(p.qmax[qrow]), ugo = h2_unscale(p.gomax[qrow]);
+    const float lse_q = p.lse[qrow];
+    fl_f16x8 qh[16], ql[16], gh[16], gl[16];
+    {
+        const float sq = h2_scale(p.qmax[qrow]), sg = h2_scale(p.gomax[qrow]);
+        const float *qp = p.q + qrow * p.ldq + 8 * fh, *gp = p.go + qrow * p.ldgo + 8 * fh;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const fl_f32x4 a = *reinterpret_cast<const fl_f32x4 *>(qp + 16 * ks) * sq;
+            const fl_f32x4 b = *reinterpret_cast<const fl_f32x4 *>(qp + 16 * ks + 4) * sq;
+            const fl_f32x4 c = *reinterpret_cast<const fl_f32x4 *>(gp + 16 * ks) * sg;
+            const fl_f32x4 e = *reinterpret_cast<const fl_f32x4 *>(gp + 16 * ks + 4) * sg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const _Float16 ha = (_Float16)a[i], hb = (_Float16)b[i], hc = (_Float16)c[i], he = (_Float16)e[i];
+                qh[ks][i] = ha, qh[ks][4 + i] = hb;
+                ql[ks][i] = (_Float16)(a[i] - (float)ha), ql[ks][4 + i] = (_Float16)(b[i] - (float)hb);
+                gh[ks][i] = hc, gh[ks][4 + i] = he;
+                gl[ks][i] = (_Float16)(c[i] - (float)hc), gl[ks][4 + i] = (_Float16)(e[i] - (float)he);
+            }
+            asm volatile("" : "+a"(qh[ks]), "+a"(ql[ks]), "+a"(gh[ks]), "+a"(gl[ks]));
+        }
+    }
+
+    // ---- staging (as the forward's K tiles; the V image of ROWS has the same 1 KB-per-key layout)
+    unsigned kso[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) kso[jj] = (unsigned)((4 * wid + jj) * kFlKRow + 16 * (lane ^ (4 * wid + jj)));
+    auto dma_rows = [&](const char *img, char *buf, int t, int slot, int c) {   // instruction c (0..7) of this wave
+        const int jj = c & 3, hi = c >> 2;
+        const char *src = img + (int64_t)t * kFlKSz + hi * 16 * kFlKRow;
+        char *dst = buf + slot * kFlKSz + (4 * wid + jj + 16 * hi) * kFlKRow;
+        __builtin_amdgcn_global_load_lds(DC_FL_GPTR(src + kso[jj]), DC_FL_LPTR(dst), 16, 0, 0);
+    };
+    int kfo[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kfo[c] = fr * kFlKRow + 16 * ((4 * (c >> 1) + 2 * (c & 1) + fh) ^ (fr & 15));
+    const float __attribute__((address_space(4))) *kunsc = (const float __attribute__((address_space(4))) *)(uintptr_t)p.kuns;
+    const float __attribute__((address_space(4))) *vunsc = (const float __attribute__((address_space(4))) *)(uintptr_t)p.vuns;
+    auto load_us = [&](const float __attribute__((address_space(4))) *src, int64_t base, f32x16 &u0, f32x16 &u1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (i & 3) + 8 * (i >> 2);
+            u0[i] = src[base + kk], u1[i] = src[base + kk + 4];
+        }
+    };
+    // one product chain: acc = tile rows (A, from LDS) x resident fragments (B, accumulation registers); ring of four
+    // fragment sets, reads three k-steps ahead, counted waits; hook(ks) issues this step's DMA instruction
+    auto chain = [&](f32x16 &acc, const char *tile, fl_f16x8 (&bh)[16], fl_f16x8 (&bl)[16], auto hook) {
+        unsigned ka[8];
+        const unsigned base = (unsigned)(uintptr_t)DC_FL_LPTR(tile);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ka[c] = base + (unsigned)kfo[c];
+        fl_f16x8 ah[4], al[4];
+        auto frags = [&](int ks) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[ks & 3]) : "v"(ka[2 * (ks & 3)]), "i"((ks >> 2) * 256));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[ks & 3]) : "v"(ka[2 * (ks & 3) + 1]), "i"((ks >> 2) * 256));
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        frags(0);
+        frags(1);
+        frags(2);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 3 < 16) frags(ks + 3);
+            if (ks < 13) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else if (ks == 13) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else if (ks == 14) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // x = the resident operand (A in k_fwd_h2w), W = the tile: x_l w_h, x_h w_l, x_h w_h
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[ks & 3]), "a"(bl[ks]));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(al[ks & 3]), "a"(bh[ks]));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(ah[ks & 3]), "a"(bh[ks]));
+            hook(ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));   // MFMA result -> VALU read (asm: no automatic nops)
+    };
+
+    constexpr float kLog2e = 1.4426950408889634f;
+    const int nt1 = (int)((p.nr + kFlT - 1) / kFlT), nt2 = (int)(p.nrp / kFlT);
+    float acc_pd = 0.f, acc_p = 0.f, delta = 0.f, dsm = 0.f;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const int nt = sweep ? nt2 : nt1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dma_rows(p.kimg, sK, 0, 0, c);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dma_rows(p.vimg, sV, 0, 0, c);
+        f32x16 uk0, uk1;
+        load_us(kunsc, 0, uk0, uk1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            const bool more = t + 1 < nt;
+            f32x16 st, dpt;
+            chain(st, sK + buf * kFlKSz, qh, ql, [&](int ks) {
+                if (more && ks < 8) dma_rows(p.kimg, sK, t + 1, buf ^ 1, ks);
+            });
+            float pv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float sv = (st[i] * uq) * (fh ? uk1[i] : uk0[i]);
+                pv[i] = __builtin_amdgcn_exp2f((sv - lse_q) * kLog2e);
+            }
+            if (t >= nt1 - 1) {                          // key padding: weights exactly 0
+                const int64_t kbase = (int64_t)t * kFlT + 4 * fh;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (kbase + (i & 3) + 8 * (i >> 2) >= p.nr) pv[i] = 0.f;
+            }
+            f32x16 uv0, uv1;
+            load_us(vunsc, (int64_t)t * kFlT, uv0, uv1);
+            chain(dpt, sV + buf * kFlKSz, gh, gl, [&](int ks) {
+                if (more && ks < 8) dma_rows(p.vimg, sV, t + 1, buf ^ 1, ks);
+            });
+            float dp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = (dpt[i] * ugo) * (fh ? uv1[i] : uv0[i]);
+            if (!sweep) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    acc_pd += pv[i] * dp[i];
+                    acc_p += pv[i];
+                }
+            } else {
+                float dsv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    dsv[i] = pv[i] * (dp[i] - delta);
+                    dsm = fmaxf(dsm, fabsf(dsv[i]));
+                }
+                // the two tiles out through the wave's transpose region: [query][key] rows of 32 floats (+ pad), then
+                // 8 lanes per row write one 128-byte segment per query
+                const int64_t col0 = (int64_t)t * kFlT + 4 * (lane & 7);
+                const bool full = q0 + 32 <= p.ns;      // wave-uniform: no per-row predicates on whole tiles
+#pragma unroll
+                for (int mtx = 0; mtx < 2; ++mtx) {
+                    const float *v = mtx ? dsv : pv;
+                    float *mat = (mtx ? p.dsmat : p.pmat) + (q0 + (lane >> 3)) * p.ldp + col0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<fl_f32x4 *>(sT + fr * kDsTRow + 8 * g + 4 * fh) =
+                            fl_f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                    asm volatile("" ::: "memory");      // (LDS operations of one wave complete in order)
+                    fl_f32x4 o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = *reinterpret_cast<const fl_f32x4 *>(sT + (8 * j + (lane >> 3)) * kDsTRow + 4 * (lane & 7));
+                    if (full) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<fl_f32x4 *>(mat + 8 * j * p.ldp) = o[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (q0 + 8 * j + (lane >> 3) < p.ns) *reinterpret_cast<fl_f32x4 *>(mat + 8 * j * p.ldp) = o[j];
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+            if (more) load_us(kunsc, (int64_t)(t + 1) * kFlT, uk0, uk1);
+            // the 16 DMA instructions of this iteration must have landed; in sweep 2 the 8 store instructions issued
+            // after them may stay in flight (VMEM operations retire in order)
+            if (sweep) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!sweep) {
+            acc_pd += __shfl_xor(acc_pd, 32);
+            acc_p += __shfl_xor(acc_p, 32);
+            delta = acc_p > 0.f ? acc_pd / acc_p : acc_pd;         // as dc_attn_ds_rows
+        }
+    }
+    dsm = fmaxf(dsm, __shfl_xor(dsm, 32));
+    if (fh == 0 && q0 + fr < p.ns) p.dsmax[q0 + fr] = dsm;
+}
+
 // the V^T image with the 4-key chunks (8 bytes) of every plane of every 64-byte record in the order (c0, c2, c1, c3)
 __global__ void __launch_bounds__(256)
 k_attn_flash_vt_image(fl_u32x2 *img, int64_t nchunks) {
@@ -416,4 +640,27 @@ extern "C" int dc_attn_flash_fwd(const float *q, int64_t ldq, const float *q_row
     hipLaunchKernelGGL(k_attn_flash_fwd, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0,
                        (hipStream_t)stream, p);
     return check_launch("dc_attn_flash_fwd");
+}
+
+extern "C" int dc_attn_flash_ds(const float *q, int64_t ldq, const float *q_rowmax, const float *go, int64_t ldgo,
+                                const float *go_rowmax, const void *k_image, const float *k_unscale,
+                                const void *v_image, const float *v_unscale, const float *lse, int64_t ns, int64_t nr,
+                                int64_t nr_padded, int64_t d, float *p_out, float *ds_out, int64_t ldp, float *ds_rowmax,
+                                dc_stream_t stream) {
+    DC_REQUIRE(ns >= 0 && nr >= 1 && nr_padded >= nr, "dc_attn_flash_ds: needs ns >= 0, 1 <= nr <= nr_padded");
+    if (ns == 0) return DC_OK;
+    DC_REQUIRE(d == kFlD, "dc_attn_flash_ds: d = dv = %d only (got %lld); use the blocked form", kFlD, (long long)d);
+    DC_REQUIRE(nr_padded % kFlT == 0 && ldp >= nr_padded && ldp % 4 == 0,
+               "dc_attn_flash_ds: nr_padded must be a multiple of %d, ldp >= nr_padded and a multiple of 4", kFlT);
+    DC_REQUIRE(q && q_rowmax && go && go_rowmax && k_image && k_unscale && v_image && v_unscale && lse && p_out &&
+                   ds_out && ds_rowmax, "dc_attn_flash_ds: null pointer");
+    DC_REQUIRE(ldq >= d && ldgo >= d && ldq % 4 == 0 && ldgo % 4 == 0 && ((uintptr_t)q & 15) == 0 &&
+                   ((uintptr_t)go & 15) == 0 && ((uintptr_t)k_image & 15) == 0 && ((uintptr_t)v_image & 15) == 0 &&
+                   ((uintptr_t)p_out & 15) == 0 && ((uintptr_t)ds_out & 15) == 0,
+               "dc_attn_flash_ds: rows must be 16-byte aligned");
+    DC_REQUIRE((ns + kFlQ - 1) / kFlQ < (int64_t)INT32_MAX, "dc_attn_flash_ds: too many query tiles");
+    FlashDsParams p{q, ldq, q_rowmax, go, ldgo, go_rowmax, (const char *)k_image, k_unscale, (const char *)v_image,
+                    v_unscale, lse, ns, nr, nr_padded, p_out, ds_out, ldp, ds_rowmax};
+    hipLaunchKernelGGL(k_attn_flash_ds, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("dc_attn_flash_ds");
 }

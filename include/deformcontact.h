@@ -508,6 +508,18 @@ int dc_attn_flash_fwd(const float *q, int64_t ldq, const float *q_rowmax, const 
                       const float *k_unscale, const void *vt_image, const float *vt_rowmax, int64_t ns,
                       int64_t nr, int64_t nr_padded, int64_t d, float *o, int64_t ldo, float *lse,
                       dc_stream_t stream);
+/* The backward's score-sized operands for ALL query rows in one launch (replaces, per 2,048-row block, dc_tag_linear_fwd_h2p_exp
+ * + dc_tag_linear_fwd_h2p + dc_attn_ds_rows):  p_out[i, j] = exp(q_i . k_j - lse[i]),  ds_out[i, j] = p_ij (dp_ij - delta_i)
+ * with dp_ij = go_i . v_j and delta_i = sum_j p_ij dp_ij / sum_j p_ij formed from the SAME recomputed p and dp (two
+ * sweeps over the keys per 128-query tile; nothing score-sized is read back), ds_rowmax[i] = max_j |ds_ij|; columns
+ * nr..nr_padded come out as exact zeros.  q / go fp32 with their row maxima; k_image / v_image = dc_tag_weight_prep images
+ * of the keys' and the values' ROWS [nr_padded, d], k_unscale / v_unscale from dc_attn_flash_prep (dv = 0 skips the
+ * image rewrite); d = dv = DC_ATTN_FLASH_D, nr_padded % 32 == 0, p_out / ds_out [ns, ldp >= nr_padded].  Products as in
+ * the blocked form (scores bit-identical to dc_tag_linear_fwd_h2p's). */
+int dc_attn_flash_ds(const float *q, int64_t ldq, const float *q_rowmax, const float *go, int64_t ldgo,
+                     const float *go_rowmax, const void *k_image, const float *k_unscale, const void *v_image,
+                     const float *v_unscale, const float *lse, int64_t ns, int64_t nr, int64_t nr_padded, int64_t d,
+                     float *p_out, float *ds_out, int64_t ldp, float *ds_rowmax, dc_stream_t stream);
 int dc_attn_softmax_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, float *lse,
                          dc_stream_t stream);
 int dc_attn_exp_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, const float *lse,

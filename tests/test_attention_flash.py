@@ -18,8 +18,9 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def _run(q, k, v, go, flash, monkeypatch, block=2048):
+def _run(q, k, v, go, flash, monkeypatch, block=2048, flash_bwd=None):
     monkeypatch.setattr(attention, "FLASH", flash)
+    monkeypatch.setattr(attention, "FLASH_BWD", flash if flash_bwd is None else flash_bwd)
     q, k, v = (t.detach().clone().requires_grad_() for t in (q, k, v))
     out = attention_core(q, k, v, block_rows=block)
     out.backward(go)
@@ -91,3 +92,63 @@ def test_flash_forward_is_deterministic_and_handles_ragged_query_tiles(monkeypat
     # a query's output does not depend on the other queries of its tile
     c = _np(attention_core(q[100:231], k, v))
     assert np.array_equal(a[100:231], c)
+
+
+@pytest.mark.parametrize("ns,nr", [(300, 130), (1, 1), (1000, 777), (4096, 3048), (515, 70)])
+def test_flash_backward_equals_blocked_backward_to_rounding_and_float64(ns, nr, monkeypatch):
+    """Same forward (flash), backward through ``dc_attn_flash_ds`` + three large GEMMs vs the blocked six-launch form."""
+    torch.manual_seed(3 * ns + nr)
+    q = torch.randn(ns, 256, device=DEV) * 0.5
+    k = torch.randn(nr, 256, device=DEV) * 0.5
+    v = torch.randn(nr, 256, device=DEV)
+    go = torch.randn(ns, 256, device=DEV)
+    got = _run(q, k, v, go, True, monkeypatch, flash_bwd=True)
+    blk = _run(q, k, v, go, True, monkeypatch, flash_bwd=False)
+    assert np.array_equal(got[0], blk[0])                  # same forward
+    qd, kd, vd = (t.double().cpu().requires_grad_() for t in (q, k, v))
+    ref = torch.softmax(qd @ kd.t(), dim=-1) @ vd
+    ref.backward(go.double().cpu())
+    for name, g, b, w in zip(("dq", "dk", "dv"), got[1:], blk[1:], (qd.grad, kd.grad, vd.grad)):
+        assert rel_err(g, w.numpy()) <= max(1e-5, 2 * rel_err(b, w.numpy())), name
+
+
+def test_flash_ds_kernel_outputs_vs_float64():
+    """``dc_attn_flash_ds`` itself: P, dS and the row maxima against float64; padded key columns exactly zero; the rows
+    of dS sum to zero to rounding (delta is formed from the same P and dP)."""
+    from deformcontact_amd import _lib
+    from deformcontact_amd.graph import current_stream_ptr
+    torch.manual_seed(11)
+    ns, nr = 333, 150
+    dev = torch.device(DEV)
+    q = torch.randn(ns, 256, device=dev) * 0.4
+    k = torch.randn(nr, 256, device=dev) * 0.4
+    v = torch.randn(nr, 256, device=dev)
+    go = torch.randn(ns, 256, device=dev)
+    L, st = _lib.lib(), current_stream_ptr(dev)
+    nrp = attention._ceil_keys(nr)
+    kp, vp = attention._pad_rows(k, nrp), attention._pad_rows(v, nrp)
+    kmax, kimg, _, _ = attention._prep(L, kp, False, st)
+    vmax, vimg, _, _ = attention._prep(L, vp, False, st)
+    kuns, vuns = torch.empty_like(kmax), torch.empty_like(vmax)
+    _lib.check(L.dc_attn_flash_prep(None, 0, nrp, kmax.data_ptr(), kuns.data_ptr(), st), "prep")
+    _lib.check(L.dc_attn_flash_prep(None, 0, nrp, vmax.data_ptr(), vuns.data_ptr(), st), "prep")
+    qmax, gomax = attention._rowabsmax(L, q, st), attention._rowabsmax(L, go, st)
+    qd, kd, vd, god = (t.double().cpu() for t in (q, k, v, go))
+    s64 = qd @ kd.t()
+    lse64 = torch.logsumexp(s64, dim=1)
+    lse = lse64.float().to(dev)
+    p = torch.full((ns, nrp), 7.0, device=dev)
+    ds = torch.full((ns, nrp), 7.0, device=dev)
+    dsmax = torch.empty(ns, device=dev)
+    _lib.check(L.dc_attn_flash_ds(q.data_ptr(), 256, qmax.data_ptr(), go.data_ptr(), 256, gomax.data_ptr(),
+                                  kimg.data_ptr(), kuns.data_ptr(), vimg.data_ptr(), vuns.data_ptr(), lse.data_ptr(),
+                                  ns, nr, nrp, 256, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(), st), "ds")
+    p64 = torch.exp(s64 - lse64[:, None])
+    dp64 = god @ vd.t()
+    ds64 = p64 * (dp64 - (p64 * dp64).sum(dim=1, keepdim=True))
+    assert np.all(_np(p)[:, nr:] == 0) and np.all(_np(ds)[:, nr:] == 0)
+    assert rel_err(_np(p)[:, :nr], p64.numpy()) < 5e-6
+    assert rel_err(_np(ds)[:, :nr], ds64.numpy()) < 1e-5
+    assert np.allclose(_np(dsmax), np.abs(_np(ds)).max(axis=1), rtol=0, atol=0)
+    rows = np.abs(_np(ds).astype(np.float64).sum(axis=1))
+    assert rows.max() <= 2e-6 * np.abs(_np(ds)).sum(axis=1).max()
