@@ -152,8 +152,11 @@ class _AttnCoreFn(torch.autograd.Function):
         # ReLU encoder is most of their magnitude
         k = k - k[:nr].mean(dim=0, keepdim=True)
         qp, kp, vp = _pad_rows(q, nsp), _pad_rows(k, nrp), _pad_rows(v, nrp)
-        kmax, kimg, _, _ = _prep(L, kp, False, st)                 # rows of K over d
-        _, _, vtimg, vtmax = _prep(L, vp, True, st)                # rows of V^T over the keys
+        # the images the backward needs (rows of K^T for dQ = dS K, rows of V for dP = dO V^T) come out of the same two
+        # preparation launches
+        need_bwd = any(ctx.needs_input_grad[:3])
+        kmax, kimg, ktimg, ktmax = _prep(L, kp, need_bwd, st)      # rows of K over d (+ rows of K^T over the keys)
+        vmax, vimg, vtimg, vtmax = _prep(L, vp, True, st)          # rows of V over dv, rows of V^T over the keys
         qmax = _rowabsmax(L, qp, st)
         ones = torch.ones(bq, dtype=torch.float32, device=dev)     # softmax weights are <= 1
         o = torch.empty((nsp, dv), dtype=torch.float32, device=dev)
@@ -184,13 +187,14 @@ class _AttnCoreFn(torch.autograd.Function):
             else:
                 _gemm(L, s.data_ptr(), nrp, rows, nrp, vtimg, dv, o[r0:].data_ptr(), dv, ones.data_ptr(), vtmax,
                       st, ws_o)
-        ctx.save_for_backward(qp, kp, vp, o, lse, kimg, kmax, qmax)
+        if need_bwd:
+            ctx.save_for_backward(qp, kp, vp, o, lse, kimg, kmax, qmax, vimg, vmax, ktimg, ktmax)
         ctx.dims = (ns, nr, d, dv, bq)
         return o[:ns]
 
     @staticmethod
     def backward(ctx, go: torch.Tensor):
-        qp, kp, vp, o, lse, kimg, kmax, qmax = ctx.saved_tensors
+        qp, kp, vp, o, lse, kimg, kmax, qmax, vimg, vmax, ktimg, ktmax = ctx.saved_tensors
         ns, nr, d, dv, bq = ctx.dims
         dev = qp.device
         L = _lib.lib()
@@ -198,8 +202,6 @@ class _AttnCoreFn(torch.autograd.Function):
         nsp, nrp = qp.size(0), kp.size(0)
         gop = _pad_rows(go.contiguous(), nsp)
         gomax = _rowabsmax(L, gop, st)
-        vmax, vimg, _, _ = _prep(L, vp, False, st)                 # rows of V over dv   (dP = dO V^T)
-        _, _, ktimg, ktmax = _prep(L, kp, True, st)                # rows of K^T over keys (dQ = dS K)
         if (FLASH_BWD and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
                 and DELTA_IN_KERNEL and 8 * nsp * nrp <= FLASH_BWD_MAX_BYTES):
             return _AttnCoreFn._backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg, vmax,

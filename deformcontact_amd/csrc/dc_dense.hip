@@ -468,6 +468,17 @@ static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_
     int64_t want = target / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
     if (want > maxchunks) want = maxchunks;   // keeps the slab-reduce pass short
+    if (want == 1 && N >= 8192) {
+        // a wide output (the attention's dK / dV: Fo = 24,384 keys -> 191 tiles of 128 x 256 on 256 CUs, 75 % of one
+        // wave of workgroups): cut the rows into the chunk count whose tiles fill whole waves best (4 -> 764 of 768)
+        const int64_t t2 = ((Fo + 127) / 128) * ((Fi + 255) / 256) * nseg;
+        double best = 0.0;
+        for (int64_t c = 1; c <= 8 && N / c >= 2048; ++c) {
+            const int64_t w = (t2 * c + 255) / 256;
+            const double eff = (double)(t2 * c) / (double)(w * 256);
+            if (eff > best + 0.02) best = eff, want = c;
+        }
+    }
     int64_t rows = (N + want - 1) / want;
     if (rows < 256) rows = 256;
     rows = (rows + BK - 1) / BK * BK;
