@@ -456,7 +456,7 @@ def backbone_extra(dev, rest, rig, backbone: str, steps: int = 20):
 def full_step_b4(dev, steps: int = 20, batch: int = 4):
     """Extra, not the headline: the reference's whole train step (train.py:46-58,71-73) at its
     shipped batch size 4 (configs/everyday.json:26) and at the benchmark batch 32 - encoder on the
-    HIP path, unmasked cross-attention (blocked on the library's dense kernels once the score
+    HIP path, unmasked cross-attention (flash-style on the library's kernels once the score
     matrix is large, stock PyTorch below that), decoder on the library's dense block, both losses fused
     (dc_contact_loss), FlatAdam."""
     from deformcontact_amd import synth
@@ -508,7 +508,8 @@ def full_step_b4(dev, steps: int = 20, batch: int = 4):
     return {"ms_per_step": round(ms, 3), "M_edges_per_s": round(edges / ms / 1e3, 2), "batch": batch,
             "loss": round(float(loss_t), 6), "hipgraph": captured,
             "note": "whole model on the library's kernels; attention " +
-                    ("blocked on the fp16x2 dense kernels" if big else "softmax materialised on stock PyTorch") +
+                    ("flash-style forward (dc_attn_flash_fwd), backward = dc_attn_flash_ds + three fp16x2 GEMMs over all rows"
+                     if big else "softmax materialised on stock PyTorch") +
                     "; L1 + gradient-consistency losses and their gradients in one launch (dc_contact_loss); "
                     "Adam = dc_adam_flat"}
 
