@@ -249,3 +249,41 @@ def test_grad_bucket_views_are_16_byte_aligned():
     assert float(bucket.flat.sum()) == used          # the padding elements stay zero
     bucket.zero()
     assert not bucket.flat.any() and all(bucket.owns(p, p.grad) for p in params)
+
+
+def test_batch_records_its_layout_and_drops_it_when_edge_index_is_replaced():
+    """``Batch.segments()``: host-side node / edge offsets of the collated graphs (what the one-launch adjacency build
+    consumes); survives ``clone()``, is dropped when ``edge_index`` is assigned, can be re-declared."""
+    import torch
+    from deformcontact_amd.data import Batch, Data
+    gs = [Data(x=torch.zeros(n, 2), edge_index=torch.randint(0, n, (2, e))) for n, e in ((5, 7), (3, 0), (4, 9))]
+    b = Batch.from_data_list(gs)
+    assert b.segments() == ((0, 5, 8, 12), (0, 7, 7, 16))
+    assert b.clone().segments() == b.segments()
+    seg = b.segments()
+    b.edge_index = b.edge_index.clone()
+    assert b.segments() is None
+    b.assume_segments(seg)
+    assert b.segments() == seg
+    # every edge of graph i stays inside graph i's node range (the property the build relies on)
+    n, e = seg
+    for i in range(3):
+        part = b.edge_index[:, e[i]:e[i + 1]]
+        assert part.numel() == 0 or (int(part.min()) >= n[i] and int(part.max()) < n[i + 1])
+
+
+def test_segment_layout_validation_is_host_side():
+    """``graph._segment_arrays``: layouts that do not cover [0, N] / [0, E], descend, or exceed the per-graph caps are
+    refused (the caller then runs the global pipeline) - decided on host data, before anything is launched."""
+    import torch
+    from deformcontact_amd import graph
+    dev = torch.device("cpu")
+    ok = graph._segment_arrays(((0, 5, 8), (0, 7, 16)), 8, 16, dev)
+    assert ok is not None and ok[2] == 2 and list(ok[0]) == [0, 5, 8] and list(ok[1]) == [0, 7, 16]
+    for bad in (((0, 5, 8), (0, 7, 15)), ((0, 5, 9), (0, 7, 16)), ((1, 5, 8), (0, 7, 16)), ((0, 5), (0, 7, 16)),
+                ((0, 6, 5, 8), (0, 7, 9, 16)), ((0, 8), (0,))):
+        assert graph._segment_arrays(bad[:2], 8, 16, dev) is None
+    caps = graph._segment_arrays(((0, graph.SEG_MAX_NODES + 1), (0, 10)), graph.SEG_MAX_NODES + 1, 10, dev)
+    assert caps is None
+    assert graph._segment_arrays(((0, 4), (0, graph.SEG_MAX_EDGES + 1)), 4, graph.SEG_MAX_EDGES + 1, dev) is None
+    assert graph._segment_arrays(((0, 4), (0, 0)), 4, 0, dev) is None          # no edges: nothing to sort
