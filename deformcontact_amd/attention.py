@@ -204,8 +204,8 @@ class _AttnCoreFn(torch.autograd.Function):
         gomax = _rowabsmax(L, gop, st)
         if (FLASH_BWD and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
                 and DELTA_IN_KERNEL and 8 * nsp * nrp <= FLASH_BWD_MAX_BYTES):
-            return _AttnCoreFn._backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg, vmax,
-                                               ktimg, ktmax, ns, nr, d, dv)
+            return _backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax,
+                                   ns, nr, d, dv)
         delta = (gop * o).sum(dim=1)
         ones = torch.ones(bq, dtype=torch.float32, device=dev)
         gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
@@ -302,9 +302,6 @@ def _backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg,
             g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1, _ptr_array([out_t]), 1, fi, None,
             0, scratch.data_ptr(), nb, nsp, fi, nrp, g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
     return gq[:ns], gk[:nr], gv[:nr], None
-
-
-_AttnCoreFn._backward_flash = staticmethod(_backward_flash)
 
 
 def attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,

@@ -5,7 +5,8 @@
 
 TAGConv: random N (incl. 1 and non-multiples of the tile), Fi, Fo (incl. 3, 21, 260), K, random
 multigraphs - forward, input gradient and every weight gradient vs a dense float64 evaluation.
-attention_core: ragged Ns / Nr / d / dv / block sizes - output and the three gradients.  (With a
+attention_core: ragged Ns / Nr / d / dv / block sizes - output and the three gradients; then d = dv = 256 (the flash-style
+kernels) with query / key counts around the tile edges and score scales from nearly uniform to nearly one-hot weights.  (With a
 single key the softmax is constant and dK is exactly zero: its "relative" error is noise / 0.)"""
 import sys, os, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -66,3 +67,18 @@ for it in range(12):
     worst = max(worst, max(errs))
     if max(errs) > 2e-5: print("ATTN FAIL", ns, nr, d, dv, errs)
 print("attention fuzz worst rel err", worst)
+# the flash-style kernels (d = dv = 256): ragged query / key counts around the 128-query and 32-key tile edges
+worst = 0.0
+for it in range(16):
+    ns = random.choice([1, 31, 127, 128, 129, 255, 700, 2049, 5000]); nr = random.choice([1, 31, 32, 33, 95, 1023, 1024, 1500, 3100])
+    sc = random.choice([0.05, 0.3, 1.0])
+    q = (torch.randn(ns, 256, device=DEV) * sc).requires_grad_(); kk = (torch.randn(nr, 256, device=DEV) * sc).requires_grad_()
+    v = torch.randn(nr, 256, device=DEV).requires_grad_(); go = torch.randn(ns, 256, device=DEV)
+    o = attention_core(q, kk, v); o.backward(go)
+    qd, kd, vd = (t.detach().double().cpu().requires_grad_() for t in (q, kk, v))
+    r = torch.softmax(qd @ kd.t(), -1) @ vd; r.backward(go.double().cpu())
+    errs = [rel(o.detach(), r.detach()), rel(q.grad, qd.grad), rel(kk.grad, kd.grad), rel(v.grad, vd.grad)]
+    if nr == 1: errs = [errs[0], errs[1], 0.0, errs[3]]      # constant softmax: dK is exactly zero
+    worst = max(worst, max(errs))
+    if max(errs) > 5e-5: print("FLASH FAIL", ns, nr, sc, errs)
+print("flash attention fuzz worst rel err", worst)
