@@ -36,6 +36,7 @@ _SIGNATURES = {
                                  c_int64, c_int64, _vp, _vp, c_int64, _vp, _vp]),
     "dc_attn_flash_fwd": (c_int, [_vp, c_int64, _vp, _vp, _vp, _vp, _vp, c_int64, c_int64, c_int64, c_int64, _vp,
                                   c_int64, _vp, _vp]),
+    "dc_spmm_f32_pack": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, c_int64, c_int64, c_int64, c_int64, _vp]),
     "dc_spmm_f32_window": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                                    c_int64, c_int64, _vp]),
     "dc_spmm_f32_rowmax_window": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,

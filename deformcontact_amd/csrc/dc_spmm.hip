@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256)
 k_spmm_sub(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
            const float *__restrict__ w, const float *__restrict__ x, int64_t ldx,
            const float *addend, int64_t ldadd, float *y, int64_t ldy,
-           int64_t N, int F, int src_off) {
+           int64_t N, int F, int src_off, float *self_dst = nullptr, int pad_beg = 0, int pad_end = 0) {
     using V = typename Vec<VEC>::T;
     constexpr int kRows = 256 / L;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -190,6 +190,12 @@ k_spmm_sub(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
     if (row >= N) return;
     const int sub = threadIdx.x % L;
     const int beg = ptr[row], end = ptr[row + 1];
+    if (self_dst) {
+        // fused dc_tag_pack_input (first hop of a layer's own input): the row itself goes into column block 0 of the
+        // slab row (self_dst has y's leading dimension), the slab's K padding [pad_beg, pad_end) is zeroed
+        for (int c = sub; c < F; c += L) self_dst[row * ldy + c] = x[row * ldx + c];
+        for (int c = pad_beg + sub; c < pad_end; c += L) self_dst[row * ldy + c] = 0.f;
+    }
 
     // the column loop is uniform across the row's lane group (lanes past F idle inside it): the
     // shuffles below need their source lanes - the first U of the group - in the loop
@@ -229,11 +235,12 @@ k_spmm_sub(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
 template <int VEC, int L, int U>
 static void launch_sub(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
                        int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
-                       int64_t N, int F, int src_off, hipStream_t stream) {
+                       int64_t N, int F, int src_off, hipStream_t stream, float *self_dst = nullptr,
+                       int pad_beg = 0, int pad_end = 0) {
     constexpr int kRows = 256 / L;
     const unsigned grid = (unsigned)((N + kRows - 1) / kRows);
     hipLaunchKernelGGL((k_spmm_sub<VEC, L, U>), dim3(grid), dim3(256), 0, stream, ptr, other, w, x,
-                       ldx, addend, ldadd, y, ldy, N, F, src_off);
+                       ldx, addend, ldadd, y, ldy, N, F, src_off, self_dst, pad_beg, pad_end);
 }
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -569,6 +576,26 @@ extern "C" int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float
                            const float *x, int64_t ldx, const float *addend, int64_t ldadd,
                            float *y, int64_t ldy, int64_t N, int64_t F, dc_stream_t stream) {
     return spmm_f32_impl(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, 0, stream);
+}
+
+extern "C" int dc_spmm_f32_pack(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
+                                int64_t ldx, float *slab, int64_t lds, int64_t N, int64_t F, int64_t width,
+                                int64_t wpad, dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(N >= 0 && F >= 1 && F <= 32, "dc_spmm_f32_pack: rows of 1..32 floats (got F=%lld)", (long long)F);
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(ptr && x && slab && (other || true), "dc_spmm_f32_pack: null pointer");
+    DC_REQUIRE(N < (int64_t)INT32_MAX / 8 && ldx >= F && width >= 2 * F && wpad >= width && lds >= wpad,
+               "dc_spmm_f32_pack: needs ldx >= F, width >= 2 F (block 1 exists), wpad >= width, lds >= wpad");
+    DC_REQUIRE((const void *)x != (const void *)slab, "dc_spmm_f32_pack: the slab must not alias x");
+    float *y = slab + F;
+    if (F > 16)
+        launch_sub<1, 32, 8>(ptr, other, w, x, ldx, nullptr, 0, y, lds, N, (int)F, 0, stream, slab, (int)width, (int)wpad);
+    else if (F > 8)
+        launch_sub<1, 16, 8>(ptr, other, w, x, ldx, nullptr, 0, y, lds, N, (int)F, 0, stream, slab, (int)width, (int)wpad);
+    else
+        launch_sub<1, 8, 8>(ptr, other, w, x, ldx, nullptr, 0, y, lds, N, (int)F, 0, stream, slab, (int)width, (int)wpad);
+    return check_launch("dc_spmm_f32_pack");
 }
 
 extern "C" int dc_spmm_f32_window(const int32_t *ptr, const int32_t *other, const float *w,

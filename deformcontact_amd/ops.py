@@ -265,6 +265,10 @@ def _hop_cache_put(g, key, x, slab, rowmax, dev):
     cache[key] = (slab, rowmax, capture_id(dev), x, x._version)
 
 
+#: pack + first hop of a narrow layer's input in one launch (``dc_spmm_f32_pack``); ``DC_FUSED_PACK=0``: two launches
+FUSED_PACK = os.environ.get("DC_FUSED_PACK", "1") != "0"
+
+
 def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool, into=None):
     """Pack ``x`` into block 0 of a ``[N, wpad]`` slab (fresh, or the buffers ``into`` = (slab,
     rowmax) of an earlier call) and run the K hops (+ row maxima)."""
@@ -273,6 +277,16 @@ def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool,
     dev = x.device
     slab = into[0] if into is not None else _alloc_slab(n, wpad, dev)
     xin = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
+    adj = g.fwd if (g is not None and k >= 1) else None
+    if (FUSED_PACK and adj is not None and not want_rowmax and fi <= 32 and not adj.row_offset and g.normalize
+            and adj.ptr.numel() == n + 1):
+        # the packing pass and the first hop in one launch (the chain of small dependent kernels a new batch starts with)
+        _lib.check(_lib.lib().dc_spmm_f32_pack(adj.ptr.data_ptr(), adj.other.data_ptr(), adj.w.data_ptr(),
+                                               xin.data_ptr(), xin.stride(0), slab.data_ptr(), slab.stride(0), n, fi,
+                                               width, wpad, current_stream_ptr(dev)), "dc_spmm_f32_pack")
+        for j in range(1, k):
+            hop(adj, slab[:, j * fi:(j + 1) * fi], out=slab[:, (j + 1) * fi:(j + 2) * fi], weighted=True)
+        return slab, None
     _lib.check(_lib.lib().dc_tag_pack_input(xin.data_ptr(), xin.stride(0), slab.data_ptr(), slab.stride(0), n,
                                             fi, width, wpad, current_stream_ptr(dev)),
                "dc_tag_pack_input")

@@ -165,6 +165,14 @@ int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float *w, const 
                 int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
                 int64_t N, int64_t F, dc_stream_t stream);
 
+/* dc_tag_pack_input + the FIRST hop of a narrow layer's own input in one launch (F <= 32: the encoder's first TAGConv,
+ * models/model.py:71,77 with the raw graph.x): slab[i, 0:F] = x[i, 0:F], slab[i, F:2F] = sum_p w[p] x[other[p], 0:F]
+ * (terms and order of dc_spmm_f32), slab[i, width:wpad] = 0.  One launch less on the chain of small dependent kernels
+ * a new batch starts with. */
+int dc_spmm_f32_pack(const int32_t *ptr, const int32_t *other, const float *w, const float *x, int64_t ldx,
+                     float *slab, int64_t lds, int64_t N, int64_t F, int64_t width, int64_t wpad,
+                     dc_stream_t stream);
+
 /* dc_spmm_f32 over a ROW WINDOW of a merged adjacency (dc_graph_build_parts): `ptr` points at the
  * window's first row (N + 1 entries; its values index the full other / w arrays), neighbour ids are
  * ids of the merged node space, and x / addend / y hold only the window's N rows: the neighbour
