@@ -83,6 +83,10 @@ FLASH_D = 256
 FLASH_BWD = os.environ.get("DC_ATTN_FLASH_BWD", "1") != "0"
 #: above this many bytes of P + dS the backward falls back to the blocked form
 FLASH_BWD_MAX_BYTES = int(float(os.environ.get("DC_ATTN_FLASH_BWD_MAX_GB", "16")) * (1 << 30))
+#: one sweep instead of two in ``dc_attn_flash_ds``: dS' is formed with delta = rowsum(dO * O), the kernel returns by how
+#: much the consistent delta differs (eps), and dK - the product that is sensitive to rows of dS not summing to zero -
+#: takes dS' - eps o P at load time (``dc_tag_linear_bwd_dw_h2_corr``).  ``DC_ATTN_FLASH_BWD_SINGLE=0``: two sweeps.
+FLASH_BWD_SINGLE = os.environ.get("DC_ATTN_FLASH_BWD_SINGLE", "1") != "0"
 
 #: recompute of a block's weights in the backward: exp(s - lse) in the score GEMM's epilogue (``DC_ATTN_FUSED_EXP=0``:
 #: separate ``dc_attn_exp_rows`` pass; bit-identical)
@@ -143,7 +147,7 @@ class _AttnCoreFn(torch.autograd.Function):
         dev = q.device
         L = _lib.lib()
         st = current_stream_ptr(dev)
-        nsp, nrp = _ceil16(ns), _ceil_keys(nr)
+        nsp, nrp = (ns + 31) // 32 * 32, _ceil_keys(nr)     # (32: whole stages of the dW-shaped kernels)
         bq = max(16, min(_ceil16(block_rows), nsp))
         # softmax over the keys is invariant to adding one vector c to every key (every score of a
         # row shifts by q.c): the whole computation runs on keys centred at their mean.  Same function,
@@ -204,7 +208,7 @@ class _AttnCoreFn(torch.autograd.Function):
         gomax = _rowabsmax(L, gop, st)
         if (FLASH_BWD and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
                 and DELTA_IN_KERNEL and 8 * nsp * nrp <= FLASH_BWD_MAX_BYTES):
-            return _backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax,
+            return _backward_flash(L, st, dev, qp, kp, gop, o, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax,
                                    ns, nr, d, dv)
         delta = (gop * o).sum(dim=1)
         ones = torch.ones(bq, dtype=torch.float32, device=dev)
@@ -275,19 +279,26 @@ class _AttnCoreFn(torch.autograd.Function):
         return gq[:ns], gk[:nr], gv[:nr], None
 
 
-def _backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax, ns, nr, d, dv):
-    """Backward with P and dS of ALL rows from ``dc_attn_flash_ds`` (two sweeps per 128-query tile, delta from the same
-    recomputed P and dP that form dS), then dQ = dS K, dK = dS^T Q, dV = P^T dO as three launches over all rows."""
+def _backward_flash(L, st, dev, qp, kp, gop, o, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax, ns, nr, d, dv):
+    """Backward with P and dS of ALL rows from ``dc_attn_flash_ds``, then dQ = dS K, dK = dS^T Q, dV = P^T dO as three
+    launches over all rows.  Two sweeps per 128-query tile (delta from the same recomputed P and dP that form dS), or
+    ONE (``FLASH_BWD_SINGLE``): dS' with delta = rowsum(dO * O) + the per-row difference eps to the consistent delta,
+    which dK takes into account at load time (dS' - eps o P); dQ uses dS' as it is (the keys are centred: what eps
+    adds to dQ_i is eps_i times the attention-weighted mean of the centred keys)."""
     nsp, nrp = qp.size(0), kp.size(0)
+    single = FLASH_BWD_SINGLE and nsp % 32 == 0 and nrp % 128 == 0
     kuns, vuns = torch.empty_like(kmax), torch.empty_like(vmax)
     _lib.check(L.dc_attn_flash_prep(None, 0, nrp, kmax.data_ptr(), kuns.data_ptr(), st), "dc_attn_flash_prep")
     _lib.check(L.dc_attn_flash_prep(None, 0, nrp, vmax.data_ptr(), vuns.data_ptr(), st), "dc_attn_flash_prep")
     p = torch.empty((nsp, nrp), dtype=torch.float32, device=dev)
     ds = torch.empty((nsp, nrp), dtype=torch.float32, device=dev)
     dsmax = torch.empty(nsp, dtype=torch.float32, device=dev)
+    delta = (gop * o).sum(dim=1) if single else None
+    eps = torch.empty(nsp, dtype=torch.float32, device=dev) if single else None
     _lib.check(L.dc_attn_flash_ds(qp.data_ptr(), d, qmax.data_ptr(), gop.data_ptr(), dv, gomax.data_ptr(),
                                   kimg.data_ptr(), kuns.data_ptr(), vimg.data_ptr(), vuns.data_ptr(), lse.data_ptr(),
-                                  nsp, nr, nrp, d, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(), st),
+                                  nsp, nr, nrp, d, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(),
+                                  delta.data_ptr() if single else None, eps.data_ptr() if single else None, st),
                "dc_attn_flash_ds")
     gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
     gk = torch.empty((nrp, d), dtype=torch.float32, device=dev)
@@ -298,6 +309,12 @@ def _backward_flash(L, st, dev, qp, kp, gop, lse, kimg, kmax, qmax, gomax, vimg,
     nb = max(L.dc_tag_linear_bwd_dw_workspace_bytes(nsp, d, nrp, 1), L.dc_tag_linear_bwd_dw_workspace_bytes(nsp, dv, nrp, 1))
     scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
     for g_t, g_max, x_t, x_ld, x_max, out_t, fi in ((ds, dsmax, qp, d, qmax, gk, d), (p, ones, gop, dv, gomax, gv, dv)):
+        if single and g_t is ds:
+            _lib.check(L.dc_tag_linear_bwd_dw_h2_corr(
+                ds.data_ptr(), nrp, p.data_ptr(), eps.data_ptr(), _ptr_array([x_t]), _i64_array([x_ld]), 1,
+                _ptr_array([out_t]), 1, fi, 0, scratch.data_ptr(), nb, nsp, fi, nrp, g_max.data_ptr(), x_max.data_ptr(), st),
+                "dc_tag_linear_bwd_dw_h2_corr")
+            continue
         _lib.check(L.dc_tag_linear_bwd_dw_h2(
             g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1, _ptr_array([out_t]), 1, fi, None,
             0, scratch.data_ptr(), nb, nsp, fi, nrp, g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")

@@ -391,6 +391,11 @@ struct FlashDsParams {
     float *pmat, *dsmat;   // [ns, ldp] each
     int64_t ldp;
     float *dsmax;          // [ns] max_j |dS_ij|
+    // single-sweep mode (delta_in != null): dS' = P (dP - delta_in) with the caller's delta (rowsum(dO o O)), and
+    // eps_out[i] = sum_j dS'_ij / sum_j P_ij - the amount by which the consistent delta differs from delta_in; the
+    // consumers that need rows of dS to sum to zero take dS' - eps_i P (dc_tag_linear_bwd_dw_h2_corr)
+    const float *delta_in;
+    float *eps_out;
 };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -487,8 +492,8 @@ k_attn_flash_ds(FlashDsParams p) {
 
     constexpr float kLog2e = 1.4426950408889634f;
     const int nt1 = (int)((p.nr + kFlT - 1) / kFlT), nt2 = (int)(p.nrp / kFlT);
-    float acc_pd = 0.f, acc_p = 0.f, delta = 0.f, dsm = 0.f;
-    for (int sweep = 0; sweep < 2; ++sweep) {
+    float acc_pd = 0.f, acc_p = 0.f, delta = p.delta_in ? p.delta_in[qrow] : 0.f, dsm = 0.f;
+    for (int sweep = p.delta_in ? 1 : 0; sweep < 2; ++sweep) {
         const int nt = sweep ? nt2 : nt1;
 #pragma unroll
         for (int c = 0; c < 8; ++c) dma_rows(p.kimg, sK, 0, 0, c);
@@ -537,6 +542,8 @@ k_attn_flash_ds(FlashDsParams p) {
                 for (int i = 0; i < 16; ++i) {
                     dsv[i] = pv[i] * (dp[i] - delta);
                     dsm = fmaxf(dsm, fabsf(dsv[i]));
+                    acc_pd += dsv[i];                    // (single-sweep mode: row sums of dS' and of P)
+                    acc_p += pv[i];
                 }
                 // the two tiles out through the wave's transpose region: [query][key] rows of 32 floats (+ pad), then
                 // 8 lanes per row write one 128-byte segment per query
@@ -581,6 +588,11 @@ k_attn_flash_ds(FlashDsParams p) {
     }
     dsm = fmaxf(dsm, __shfl_xor(dsm, 32));
     if (fh == 0 && q0 + fr < p.ns) p.dsmax[q0 + fr] = dsm;
+    if (p.delta_in) {
+        acc_pd += __shfl_xor(acc_pd, 32);
+        acc_p += __shfl_xor(acc_p, 32);
+        if (fh == 0 && q0 + fr < p.ns) p.eps_out[q0 + fr] = acc_p > 0.f ? acc_pd / acc_p : 0.f;
+    }
 }
 
 // the V^T image with the 4-key chunks (8 bytes) of every plane of every 64-byte record in the order (c0, c2, c1, c3)
@@ -646,7 +658,8 @@ extern "C" int dc_attn_flash_ds(const float *q, int64_t ldq, const float *q_rowm
                                 const float *go_rowmax, const void *k_image, const float *k_unscale,
                                 const void *v_image, const float *v_unscale, const float *lse, int64_t ns, int64_t nr,
                                 int64_t nr_padded, int64_t d, float *p_out, float *ds_out, int64_t ldp, float *ds_rowmax,
-                                dc_stream_t stream) {
+                                const float *delta_in, float *eps_out, dc_stream_t stream) {
+    DC_REQUIRE((delta_in == nullptr) == (eps_out == nullptr), "dc_attn_flash_ds: delta_in and eps_out go together");
     DC_REQUIRE(ns >= 0 && nr >= 1 && nr_padded >= nr, "dc_attn_flash_ds: needs ns >= 0, 1 <= nr <= nr_padded");
     if (ns == 0) return DC_OK;
     DC_REQUIRE(d == kFlD, "dc_attn_flash_ds: d = dv = %d only (got %lld); use the blocked form", kFlD, (long long)d);
@@ -660,7 +673,7 @@ extern "C" int dc_attn_flash_ds(const float *q, int64_t ldq, const float *q_rowm
                "dc_attn_flash_ds: rows must be 16-byte aligned");
     DC_REQUIRE((ns + kFlQ - 1) / kFlQ < (int64_t)INT32_MAX, "dc_attn_flash_ds: too many query tiles");
     FlashDsParams p{q, ldq, q_rowmax, go, ldgo, go_rowmax, (const char *)k_image, k_unscale, (const char *)v_image,
-                    v_unscale, lse, ns, nr, nr_padded, p_out, ds_out, ldp, ds_rowmax};
+                    v_unscale, lse, ns, nr, nr_padded, p_out, ds_out, ldp, ds_rowmax, delta_in, eps_out};
     hipLaunchKernelGGL(k_attn_flash_ds, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_attn_flash_ds");
 }

@@ -195,6 +195,9 @@ struct DwParams {
     int nseg, nchunks;
     H2Scales h2;
     DwGroups grp;
+    // k_dw_h2w only: the gradient operand is g[i, :] - g2_coef[i] * g2[i, :] (g2 with g's leading dimension) - the
+    // attention backward's row-sum correction of dS (dc_tag_linear_bwd_dw_h2_corr); null = plain g
+    const float *g2, *g2_coef;
 };
 
 

@@ -688,7 +688,8 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
                    const float *const *xs, const int64_t *ldxs, int nseg, float *const *gws, int ngw,
                    int64_t gw_cols, float *gbias, int accumulate, void *partials,
                    int64_t partials_bytes, int64_t N, int64_t Fi, int64_t Fo, dc_stream_t stream,
-                   int products, H2Scales h2 = H2Scales{}) {
+                   int products, H2Scales h2 = H2Scales{}, const float *g2 = nullptr,
+                   const float *g2_coef = nullptr) {
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg, "dc_tag_linear_bwd_dw: nseg must be 1..%d", kMaxSeg);
     DC_REQUIRE(N >= 0 && Fi >= 1 && Fo >= 1, "dc_tag_linear_bwd_dw: bad sizes");
     DC_REQUIRE(g && xs && ldxs && gws && partials && ldg >= Fo,
@@ -733,6 +734,21 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     if (!p.has_mask) p.mask = p.g;
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
+    if (g2) {
+        // corrected gradient operand: only the 128 x 256 tile kernel forms it
+        DC_REQUIRE(g2_coef && products == 2 && vec && !ragged && (((uintptr_t)g2) & 15) == 0,
+                   "dc_tag_linear_bwd_dw_h2_corr: needs the coefficient vector, aligned operands and N %% 16 == 0");
+        p.g2 = g2, p.g2_coef = g2_coef;
+        DC_REQUIRE(dw_h2w_launch(p, hs), "dc_tag_linear_bwd_dw_h2_corr: shape not eligible for the 128 x 256 tile kernel "
+                   "(needs Fo %% 128 == 0, Fi == 256, N %% 32 == 0; N=%lld Fi=%lld Fo=%lld)", (long long)N,
+                   (long long)Fi, (long long)Fo);
+        r.partial = p.partial, r.bias_partial = p.bias_partial, r.gbias = gbias;
+        r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = nslots;
+        r.cols = gw_cols, r.ngw = ngw, r.bps = ngw / nseg, r.accumulate = accumulate;
+        const int64_t total_c = (int64_t)ngw * Fo * gw_cols + (gbias ? Fo : 0);
+        hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total_c + 255) / 256)), dim3(256), 0, hs, r);
+        return check_launch("dc_tag_linear_bwd_dw_h2_corr");
+    }
     if (ragged) {
         DwParams t = p;                                  // the trailing rows: one chunk of the generic kernel
         const int64_t n0 = N - tail;
@@ -888,6 +904,19 @@ extern "C" int dc_tag_linear_bwd_dw_h2(const float *g, int64_t ldg, const float 
     h.a_rowmax = g_rowmax, h.b_rowmax = x_rowmax;
     return dw_impl(g, ldg, out_for_mask, ldo, xs, ldxs, nseg, gws, ngw, gw_cols, gbias, accumulate,
                    partials, partials_bytes, N, Fi, Fo, stream, 2, h);
+}
+
+extern "C" int dc_tag_linear_bwd_dw_h2_corr(const float *g, int64_t ldg, const float *g2, const float *g2_coef,
+                                            const float *const *xs, const int64_t *ldxs, int nseg,
+                                            float *const *gws, int ngw, int64_t gw_cols, int accumulate,
+                                            void *partials, int64_t partials_bytes, int64_t N, int64_t Fi,
+                                            int64_t Fo, const float *g_rowmax, const float *x_rowmax,
+                                            dc_stream_t stream) {
+    DC_REQUIRE(g2 && g2_coef && g_rowmax && x_rowmax, "dc_tag_linear_bwd_dw_h2_corr: null g2 / coefficients / row maxima");
+    H2Scales h2{};
+    h2.a_rowmax = g_rowmax, h2.b_rowmax = x_rowmax;
+    return dw_impl(g, ldg, nullptr, 0, xs, ldxs, nseg, gws, ngw, gw_cols, nullptr, accumulate, partials,
+                   partials_bytes, N, Fi, Fo, stream, 2, h2, g2, g2_coef);
 }
 
 namespace dc {

@@ -630,10 +630,22 @@ k_dw_h2w(DwParams p) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     f32x4 vg0[2], vg1[2], vx0[4], vx1[4];
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const float *baseg2 = p.g2 ? p.g2 + n_beg * ldg + o0 : nullptr;      // correction operand (same layout as g)
+    const float *basec = p.g2 ? p.g2_coef + n_beg + krg : nullptr;
 
     auto gload = [&](f32x4 (&vg)[2], f32x4 (&vx)[4]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) vg[j] = *reinterpret_cast<const f32x4 *>(baseg + offg[j]);
+        if (baseg2) {                                                     // g - coef[row] * g2, formed at load time
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 v2 = *reinterpret_cast<const f32x4 *>(baseg2 + offg[j]);
+                const float c = basec[16 * j];
+                vg[j] = vg[j] - v2 * c;
+            }
+            baseg2 += kDwK * ldg;
+            basec += kDwK;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) vx[j] = *reinterpret_cast<const f32x4 *>(basex + offx[j]);
         baseg += kDwK * ldg;

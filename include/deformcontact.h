@@ -346,6 +346,14 @@ int dc_tag_linear_bwd_dw_h2(const float *g, int64_t ldg, const float *out_for_ma
                             int accumulate, void *partials, int64_t partials_bytes, int64_t N,
                             int64_t Fi, int64_t Fo, const float *g_rowmax, const float *x_rowmax,
                             dc_stream_t stream);
+/* dc_tag_linear_bwd_dw_h2 (no mask, no bias) with the gradient operand g[i, :] - g2_coef[i] * g2[i, :] formed at load
+ * time (g2 with g's leading dimension): the attention backward's dK = (dS' - eps o P)^T Q without materialising the
+ * corrected dS.  128 x 256 tile kernel only: Fo % 128 == 0, Fi == 256 per segment, N % 32 == 0. */
+int dc_tag_linear_bwd_dw_h2_corr(const float *g, int64_t ldg, const float *g2, const float *g2_coef,
+                                 const float *const *xs, const int64_t *ldxs, int nseg, float *const *gws, int ngw,
+                                 int64_t gw_cols, int accumulate, void *partials, int64_t partials_bytes, int64_t N,
+                                 int64_t Fi, int64_t Fo, const float *g_rowmax, const float *x_rowmax,
+                                 dc_stream_t stream);
 /* Backward in the forward's shape (used with the h2 entries):  the input gradient of a TAGConv layer
  *   gx = sum_k (A^T)^k (gm W_k),  gm = g * relu'
  * equals  sum_k ((A^T)^k gm) W_k  (A acts on rows, W_k on columns), i.e. K transposed hops on gm
@@ -523,11 +531,15 @@ int dc_attn_flash_fwd(const float *q, int64_t ldq, const float *q_rowmax, const 
  * nr..nr_padded come out as exact zeros.  q / go fp32 with their row maxima; k_image / v_image = dc_tag_weight_prep images
  * of the keys' and the values' ROWS [nr_padded, d], k_unscale / v_unscale from dc_attn_flash_prep (dv = 0 skips the
  * image rewrite); d = dv = DC_ATTN_FLASH_D, nr_padded % 32 == 0, p_out / ds_out [ns, ldp >= nr_padded].  Products as in
- * the blocked form (scores bit-identical to dc_tag_linear_fwd_h2p's). */
+ * the blocked form (scores bit-identical to dc_tag_linear_fwd_h2p's).
+ * SINGLE-SWEEP mode (delta_in / eps_out not NULL, both [ns]): ds_out = p (dp - delta_in) with the caller's delta
+ * (rowsum(dO o O)) and eps_out[i] = sum_j ds_ij / sum_j p_ij, i.e. consistent delta = delta_in + eps: half the matrix
+ * work; consumers whose result is sensitive to sum_j ds_ij != 0 take ds - eps_i p (dc_tag_linear_bwd_dw_h2_corr). */
 int dc_attn_flash_ds(const float *q, int64_t ldq, const float *q_rowmax, const float *go, int64_t ldgo,
                      const float *go_rowmax, const void *k_image, const float *k_unscale, const void *v_image,
                      const float *v_unscale, const float *lse, int64_t ns, int64_t nr, int64_t nr_padded, int64_t d,
-                     float *p_out, float *ds_out, int64_t ldp, float *ds_rowmax, dc_stream_t stream);
+                     float *p_out, float *ds_out, int64_t ldp, float *ds_rowmax, const float *delta_in,
+                     float *eps_out, dc_stream_t stream);
 int dc_attn_softmax_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, float *lse,
                          dc_stream_t stream);
 int dc_attn_exp_rows(float *s, int64_t ld, int64_t rows, int64_t n, int64_t npad, const float *lse,

@@ -18,9 +18,10 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def _run(q, k, v, go, flash, monkeypatch, block=2048, flash_bwd=None):
+def _run(q, k, v, go, flash, monkeypatch, block=2048, flash_bwd=None, single=True):
     monkeypatch.setattr(attention, "FLASH", flash)
     monkeypatch.setattr(attention, "FLASH_BWD", flash if flash_bwd is None else flash_bwd)
+    monkeypatch.setattr(attention, "FLASH_BWD_SINGLE", single)
     q, k, v = (t.detach().clone().requires_grad_() for t in (q, k, v))
     out = attention_core(q, k, v, block_rows=block)
     out.backward(go)
@@ -103,13 +104,19 @@ def test_flash_backward_equals_blocked_backward_to_rounding_and_float64(ns, nr, 
     v = torch.randn(nr, 256, device=DEV)
     go = torch.randn(ns, 256, device=DEV)
     got = _run(q, k, v, go, True, monkeypatch, flash_bwd=True)
+    two = _run(q, k, v, go, True, monkeypatch, flash_bwd=True, single=False)
     blk = _run(q, k, v, go, True, monkeypatch, flash_bwd=False)
-    assert np.array_equal(got[0], blk[0])                  # same forward
+    assert np.array_equal(got[0], blk[0]) and np.array_equal(two[0], blk[0])     # same forward
     qd, kd, vd = (t.double().cpu().requires_grad_() for t in (q, k, v))
     ref = torch.softmax(qd @ kd.t(), dim=-1) @ vd
     ref.backward(go.double().cpu())
-    for name, g, b, w in zip(("dq", "dk", "dv"), got[1:], blk[1:], (qd.grad, kd.grad, vd.grad)):
-        assert rel_err(g, w.numpy()) <= max(1e-5, 2 * rel_err(b, w.numpy())), name
+    for name, g, t, b, w in zip(("dq", "dk", "dv"), got[1:], two[1:], blk[1:], (qd.grad, kd.grad, vd.grad)):
+        assert rel_err(g, w.numpy()) <= max(1e-5, 2 * rel_err(b, w.numpy())), ("single sweep", name)
+        assert rel_err(t, w.numpy()) <= max(1e-5, 2 * rel_err(b, w.numpy())), ("two sweeps", name)
+    # the sum over the keys of dK is mathematically zero (rows of dS sum to zero): the single-sweep form must keep it
+    # as small as the two-sweep form does (this is what the eps correction of dK is for)
+    kscale = np.abs(got[2]).sum(axis=0).max() + 1e-30
+    assert np.abs(got[2].sum(axis=0)).max() <= 4 * np.abs(two[2].sum(axis=0)).max() + 2e-6 * kscale
 
 
 def test_flash_ds_kernel_outputs_vs_float64():
@@ -142,7 +149,7 @@ def test_flash_ds_kernel_outputs_vs_float64():
     dsmax = torch.empty(ns, device=dev)
     _lib.check(L.dc_attn_flash_ds(q.data_ptr(), 256, qmax.data_ptr(), go.data_ptr(), 256, gomax.data_ptr(),
                                   kimg.data_ptr(), kuns.data_ptr(), vimg.data_ptr(), vuns.data_ptr(), lse.data_ptr(),
-                                  ns, nr, nrp, 256, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(), st), "ds")
+                                  ns, nr, nrp, 256, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(), None, None, st), "ds")
     p64 = torch.exp(s64 - lse64[:, None])
     dp64 = god @ vd.t()
     ds64 = p64 * (dp64 - (p64 * dp64).sum(dim=1, keepdim=True))

@@ -37,7 +37,7 @@ def main():
     def launch():
         _lib.check(L.dc_attn_flash_ds(q.data_ptr(), 256, qmax.data_ptr(), go.data_ptr(), 256, gomax.data_ptr(),
                                       kimg.data_ptr(), kuns.data_ptr(), vimg.data_ptr(), vuns.data_ptr(), lse.data_ptr(),
-                                      ns, nr, nrp, 256, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(), st), "ds")
+                                      ns, nr, nrp, 256, p.data_ptr(), ds.data_ptr(), nrp, dsmax.data_ptr(), None, None, st), "ds")
     launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -50,8 +50,8 @@ def main():
     flop = 4 * 2 * ns * nr * 256 * 3
     print(f"dc_attn_flash_ds alone: {ms:8.3f} ms   ({flop / ms / 1e12:6.3f} PFLOP/s of fp16 products = {flop / ms / 1e12 / 2.5:.3f} of 2.5 PF)")
     del p, ds
-    for fb in (True, False):
-        attention.FLASH_BWD = fb
+    for fb, single in ((True, True), (True, False), (False, False)):
+        attention.FLASH_BWD, attention.FLASH_BWD_SINGLE = fb, single
         qq, kk, vv = (t.clone().requires_grad_() for t in (q, k, v))
         for it in range(3):
             o = attention.attention_core(qq, kk, vv)
@@ -61,7 +61,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             qq.grad = kk.grad = vv.grad = None
-        print(f"whole backward, {'flash  ' if fb else 'blocked'}: {e0.elapsed_time(e1):8.3f} ms")
+        print(f"whole backward, {('flash, one sweep ' if single else 'flash, two sweeps') if fb else 'blocked          '}: {e0.elapsed_time(e1):8.3f} ms")
 
 
 if __name__ == "__main__":
