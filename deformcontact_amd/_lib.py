@@ -34,6 +34,8 @@ _SIGNATURES = {
     "dc_attn_flash_prep": (c_int, [_vp, c_int64, c_int64, _vp, _vp, _vp]),
     "dc_attn_flash_ds": (c_int, [_vp, c_int64, _vp, _vp, c_int64, _vp, _vp, _vp, _vp, _vp, _vp, c_int64, c_int64,
                                  c_int64, c_int64, _vp, _vp, c_int64, _vp, _vp, _vp, _vp]),
+    "dc_tag_linear_fwd_h2p_corr": (c_int, [_vp, c_int64, _vp, _vp, _vp, _vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp,
+                                           _vp]),
     "dc_tag_linear_bwd_dw_h2_corr": (c_int, [_vp, c_int64, _vp, _vp, POINTER(_vp), POINTER(c_int64), c_int, POINTER(_vp),
                                              c_int, c_int64, c_int, _vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp,
                                              _vp]),

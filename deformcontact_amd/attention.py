@@ -87,6 +87,11 @@ FLASH_BWD_MAX_BYTES = int(float(os.environ.get("DC_ATTN_FLASH_BWD_MAX_GB", "16")
 #: much the consistent delta differs (eps), and dK - the product that is sensitive to rows of dS not summing to zero -
 #: takes dS' - eps o P at load time (``dc_tag_linear_bwd_dw_h2_corr``).  ``DC_ATTN_FLASH_BWD_SINGLE=0``: two sweeps.
 FLASH_BWD_SINGLE = os.environ.get("DC_ATTN_FLASH_BWD_SINGLE", "1") != "0"
+#: one-sweep form: dQ = (dS' - eps o P) K as well (``dc_tag_linear_fwd_h2p_corr``).  What eps adds to an uncorrected dQ_i is
+#: eps_i times the attention-weighted mean of the centred keys - small next to dQ_i unless dP is nearly constant over the
+#: keys (values with a large common component: |delta_i| >> spread of dP_i.), which is exactly what post-ReLU features
+#: look like; ``DC_ATTN_CORRECT_DQ=0`` skips it (one operand stream less)
+CORRECT_DQ = os.environ.get("DC_ATTN_CORRECT_DQ", "1") != "0"
 
 #: recompute of a block's weights in the backward: exp(s - lse) in the score GEMM's epilogue (``DC_ATTN_FUSED_EXP=0``:
 #: separate ``dc_attn_exp_rows`` pass; bit-identical)
@@ -283,8 +288,7 @@ def _backward_flash(L, st, dev, qp, kp, gop, o, lse, kimg, kmax, qmax, gomax, vi
     """Backward with P and dS of ALL rows from ``dc_attn_flash_ds``, then dQ = dS K, dK = dS^T Q, dV = P^T dO as three
     launches over all rows.  Two sweeps per 128-query tile (delta from the same recomputed P and dP that form dS), or
     ONE (``FLASH_BWD_SINGLE``): dS' with delta = rowsum(dO * O) + the per-row difference eps to the consistent delta,
-    which dK takes into account at load time (dS' - eps o P); dQ uses dS' as it is (the keys are centred: what eps
-    adds to dQ_i is eps_i times the attention-weighted mean of the centred keys)."""
+    which dK and dQ take into account at load time (dS' - eps o P)."""
     nsp, nrp = qp.size(0), kp.size(0)
     single = FLASH_BWD_SINGLE and nsp % 32 == 0 and nrp % 128 == 0
     kuns, vuns = torch.empty_like(kmax), torch.empty_like(vmax)
@@ -303,8 +307,13 @@ def _backward_flash(L, st, dev, qp, kp, gop, o, lse, kimg, kmax, qmax, gomax, vi
     gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
     gk = torch.empty((nrp, d), dtype=torch.float32, device=dev)
     gv = torch.empty((nrp, dv), dtype=torch.float32, device=dev)
-    _gemm(L, ds.data_ptr(), nrp, nsp, nrp, ktimg, d, gq.data_ptr(), d, dsmax.data_ptr(), ktmax, st,
-          _splitk_ws(L, nsp, nrp, d, dev))
+    if single and CORRECT_DQ:
+        _lib.check(L.dc_tag_linear_fwd_h2p_corr(ds.data_ptr(), nrp, p.data_ptr(), eps.data_ptr(), ktimg.data_ptr(),
+                                                gq.data_ptr(), d, nsp, nrp, d, dsmax.data_ptr(), ktmax.data_ptr(), st),
+                   "dc_tag_linear_fwd_h2p_corr")
+    else:
+        _gemm(L, ds.data_ptr(), nrp, nsp, nrp, ktimg, d, gq.data_ptr(), d, dsmax.data_ptr(), ktmax, st,
+              _splitk_ws(L, nsp, nrp, d, dev))
     ones = torch.ones(nsp, dtype=torch.float32, device=dev)        # softmax weights are <= 1
     nb = max(L.dc_tag_linear_bwd_dw_workspace_bytes(nsp, d, nrp, 1), L.dc_tag_linear_bwd_dw_workspace_bytes(nsp, dv, nrp, 1))
     scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)

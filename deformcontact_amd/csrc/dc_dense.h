@@ -163,6 +163,9 @@ struct FwdParams {
     const float *exp_lse;
     int64_t exp_ncols;
     FwdGroups grp;
+    // k_fwd_h2w only: the left operand is x[i, :] - x2_coef[i] * x2[i, :] (x2 with x's leading dimension) - the attention
+    // backward's dQ = (dS' - eps o P) K (dc_tag_linear_fwd_h2p_corr); null = plain x
+    const float *x2, *x2_coef;
 };
 
 struct DxParams {

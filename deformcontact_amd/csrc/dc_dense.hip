@@ -860,6 +860,27 @@ extern "C" int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_
                     workspace ? workspace_bytes : 0);
 }
 
+extern "C" int dc_tag_linear_fwd_h2p_corr(const float *x, int64_t ldx, const float *x2, const float *x2_coef,
+                                          const void *w_image, float *out, int64_t ldo, int64_t N, int64_t K,
+                                          int64_t Fo, const float *x_rowmax, const float *w_rowmax,
+                                          dc_stream_t stream) {
+    DC_REQUIRE(N >= 0 && K >= 32 && K % 32 == 0 && Fo >= 1, "dc_tag_linear_fwd_h2p_corr: K must be a multiple of 32");
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(x && x2 && x2_coef && w_image && out && x_rowmax && w_rowmax && ldx >= K && ldo >= Fo &&
+                   (((uintptr_t)x2) & 15) == 0, "dc_tag_linear_fwd_h2p_corr: null / short / misaligned operand");
+    FwdParams p{};
+    bool vec = true;
+    p.x[0] = make_mat(x, ldx, &vec);
+    p.w[0] = make_mat((const float *)w_image, K, &vec);
+    p.out = out, p.ldo = ldo, p.N = N, p.Fi = K, p.Fo = Fo, p.nseg = 1;
+    p.h2.a_rowmax = x_rowmax, p.h2.b_rowmax = w_rowmax, p.h2.b_presplit = 1;
+    p.x2 = x2, p.x2_coef = x2_coef;
+    DC_REQUIRE(vec && fwd_h2w_launch(p, (hipStream_t)stream),
+               "dc_tag_linear_fwd_h2p_corr: shape not eligible for the 128 x 256 tile kernel (N=%lld K=%lld Fo=%lld: "
+               "needs 16-byte aligned rows)", (long long)N, (long long)K, (long long)Fo);
+    return check_launch("dc_tag_linear_fwd_h2p_corr");
+}
+
 extern "C" int dc_tag_linear_fwd_h2p_exp(const float *x, int64_t ldx, const void *w_image, float *out,
                                          int64_t ldo, int64_t N, int64_t K, int64_t Fo, const float *x_rowmax,
                                          const float *w_rowmax, const float *row_lse, int64_t ncols_valid,

@@ -40,7 +40,9 @@ constexpr int kWSzA = kWBM * kWRow, kWSzB = kWBN * kWRow;
 
 __device__ __forceinline__ int hw_swz(int row) { return ((row >> 1) & 7) ^ ((row & 1) << 1); }
 
-template <bool FULL>
+// CORR: the left operand is x - x2_coef[row] * x2 (dc_tag_linear_fwd_h2p_corr); a template parameter so that the plain
+// kernel keeps its register allocation
+template <bool FULL, bool CORR = false>
 __global__ void __launch_bounds__(512)
 k_fwd_h2w(FwdParams p) {
     __shared__ __attribute__((aligned(16))) char sA[3 * kWSzA];      // ring of three stages: 144 KB
@@ -68,7 +70,7 @@ k_fwd_h2w(FwdParams p) {
 
     unsigned offA[2], offB[4];
     int ldsAh[2], ldsAl[2], ldsB[4];
-    float scA[2];
+    float scA[2], cA[2] = {0.f, 0.f};               // cA: coefficient of the correction operand x2 for this thread's rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int rl = r + 64 * j;
@@ -82,6 +84,7 @@ k_fwd_h2w(FwdParams p) {
         const float m = p.h2.a_rowmax[row];
         scA[j] = h2_scale(m);
         if (k8 == 0) s_inv[rl] = h2_unscale(m);
+        if (CORR) cA[j] = p.x2_coef[row];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -99,13 +102,20 @@ k_fwd_h2w(FwdParams p) {
     const int nst = st_beg >= nst_all ? 0 : (nst_all - st_beg < per ? nst_all - st_beg : per);
     const float *baseA = p.x[0].p + row0 * lda + (int64_t)st_beg * kWBK;      // wave-uniform running bases
     const float *baseB = wimg + col0 * p.Fi + (int64_t)st_beg * kWBK;
+    const float *baseA2 = CORR ? p.x2 + row0 * lda + (int64_t)st_beg * kWBK : nullptr;
     hw_f32x4 va0[2], va1[2];                                          // two register sets, named: no runtime index
+    hw_f32x4 vc0[2], vc1[2];                                          // (CORR) the correction operand's pieces
     hw_u32x4 vb0[4], vb1[4];
 
-    auto gload_set = [&](hw_f32x4 (&va)[2], hw_u32x4 (&vb)[4]) {
+    auto gload_set = [&](hw_f32x4 (&va)[2], hw_f32x4 (&vc)[2], hw_u32x4 (&vb)[4]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             va[j] = *reinterpret_cast<const hw_f32x4 *>(baseA + offA[j]);
+        if (CORR) {                                                       // (combined at LDS-store time: stays in flight)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) vc[j] = *reinterpret_cast<const hw_f32x4 *>(baseA2 + offA[j]);
+            baseA2 += kWBK;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) vb[j] = *reinterpret_cast<const hw_u32x4 *>(baseB + offB[j]);
         baseA += kWBK;
@@ -115,10 +125,10 @@ k_fwd_h2w(FwdParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<hw_u32x4 *>(sB + b * kWSzB + ldsB[j]) = vb[j];
     };
-    auto lstore_a = [&](const hw_f32x4 (&va)[2], int b) {
+    auto lstore_a = [&](const hw_f32x4 (&va)[2], const hw_f32x4 (&vc)[2], int b) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const hw_f32x4 v = va[j] * scA[j];
+            const hw_f32x4 v = (CORR ? va[j] - vc[j] * cA[j] : va[j]) * scA[j];
             hw_f16x4 h, l;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -131,13 +141,13 @@ k_fwd_h2w(FwdParams p) {
         }
     };
     auto gload = [&](int set) {
-        if (set == 0) gload_set(va0, vb0); else gload_set(va1, vb1);
+        if (set == 0) gload_set(va0, vc0, vb0); else gload_set(va1, vc1, vb1);
     };
     auto lstoreB = [&](int set, int b) {
         if (set == 0) lstore_b(vb0, b); else lstore_b(vb1, b);
     };
     auto lstoreA = [&](int set, int b) {
-        if (set == 0) lstore_a(va0, b); else lstore_a(va1, b);
+        if (set == 0) lstore_a(va0, vc0, b); else lstore_a(va1, vc1, b);
     };
     auto lstore = [&](int set, int b) {
         lstoreB(set, b);
@@ -297,7 +307,7 @@ static inline int hw_env_int(const char *name, int dflt) {
 bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     static const int wide = hw_env_int("DC_H2_WIDE", 1);
     if (!p.h2.a_rowmax || !p.h2.b_rowmax || !p.h2.b_presplit || p.nseg != 1) return false;
-    if (!wide && p.grp.n < 1) return false;
+    if (!wide && p.grp.n < 1 && !p.x2) return false;
     const int64_t ks = p.ksplit > 1 ? p.ksplit : 1;
     if (ks > 1 && (!p.kpartial || p.bias || p.relu || p.exp_lse)) return false;
     if (p.Fi % kWBK != 0 || p.Fi < kWBK) return false;
@@ -305,8 +315,16 @@ bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     if (!hw_al16(p.x[0].p) || !hw_al16(p.w[0].p) || p.x[0].ld % 4 != 0) return false;
     const int64_t tiles = ((p.N + kWBM - 1) / kWBM) * ((p.Fo + kWBN - 1) / kWBN);
     static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
-    if ((tiles * ks < min_tiles && p.grp.n < 1) || tiles * ks >= (int64_t)INT32_MAX) return false;
+    if ((tiles * ks < min_tiles && p.grp.n < 1 && !p.x2) || tiles * ks >= (int64_t)INT32_MAX) return false;
     const dim3 gd((unsigned)(tiles * ks)), bd(512);
+    if (p.x2) {
+        if (!p.x2_coef || ks > 1 || !hw_al16(p.x2)) return false;
+        if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
+            hipLaunchKernelGGL((k_fwd_h2w<true, true>), gd, bd, 0, hs, p);
+        else
+            hipLaunchKernelGGL((k_fwd_h2w<false, true>), gd, bd, 0, hs, p);
+        return true;
+    }
     if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
         hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);
     else

@@ -561,6 +561,9 @@ template <int COLS> struct TrImage32 {
     static constexpr int BYTES = 2 * PLANE;
 };
 
+// CORR: the gradient operand is g - g2_coef[row] * g2 (dc_tag_linear_bwd_dw_h2_corr); a template parameter so that the
+// plain kernel keeps its register allocation
+template <bool CORR = false>
 __global__ void __launch_bounds__(512)
 k_dw_h2w(DwParams p) {
     using IA = TrImage32<128>;
@@ -629,19 +632,20 @@ k_dw_h2w(DwParams p) {
     const float *basex = p.x[s].p + n_beg * ldx;
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     f32x4 vg0[2], vg1[2], vx0[4], vx1[4];
+    f32x4 vc0[2], vc1[2];                                                 // (CORR) pieces of the correction operand
+    float cc0[2], cc1[2];                                                 //        and their rows' coefficients
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    const float *baseg2 = p.g2 ? p.g2 + n_beg * ldg + o0 : nullptr;      // correction operand (same layout as g)
-    const float *basec = p.g2 ? p.g2_coef + n_beg + krg : nullptr;
+    const float *baseg2 = CORR ? p.g2 + n_beg * ldg + o0 : nullptr;       // correction operand (same layout as g)
+    const float *basec = CORR ? p.g2_coef + n_beg + krg : nullptr;
 
-    auto gload = [&](f32x4 (&vg)[2], f32x4 (&vx)[4]) {
+    auto gload_c = [&](f32x4 (&vg)[2], f32x4 (&vx)[4], f32x4 (&vc)[2], float (&cc)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) vg[j] = *reinterpret_cast<const f32x4 *>(baseg + offg[j]);
-        if (baseg2) {                                                     // g - coef[row] * g2, formed at load time
+        if (CORR) {                                                       // (combined at LDS-store time: stays in flight)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x4 v2 = *reinterpret_cast<const f32x4 *>(baseg2 + offg[j]);
-                const float c = basec[16 * j];
-                vg[j] = vg[j] - v2 * c;
+                vc[j] = *reinterpret_cast<const f32x4 *>(baseg2 + offg[j]);
+                cc[j] = basec[16 * j];
             }
             baseg2 += kDwK * ldg;
             basec += kDwK;
@@ -650,6 +654,10 @@ k_dw_h2w(DwParams p) {
         for (int j = 0; j < 4; ++j) vx[j] = *reinterpret_cast<const f32x4 *>(basex + offx[j]);
         baseg += kDwK * ldg;
         basex += kDwK * ldx;
+    };
+    // the register set of a stage is identified by its g array (two sets, named)
+    auto gload = [&](f32x4 (&vg)[2], f32x4 (&vx)[4]) {
+        if (&vg == &vg0) gload_c(vg, vx, vc0, cc0); else gload_c(vg, vx, vc1, cc1);
     };
     auto split_store = [&](char *dst, int plane, f32x4 v, float sc) {
         v = v * sc;
@@ -665,9 +673,12 @@ k_dw_h2w(DwParams p) {
     };
     auto lstore = [&](const f32x4 (&vg)[2], const f32x4 (&vx)[4], int b) {
         char *buf = lds + b * kStage;
+        const bool set0 = &vg == &vg0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            split_store(buf + ldsg[j], IA::PLANE, vg[j], sca);
+            f32x4 gv = vg[j];
+            if (CORR) gv = set0 ? gv - vc0[j] * cc0[j] : gv - vc1[j] * cc1[j];
+            split_store(buf + ldsg[j], IA::PLANE, gv, sca);
             if (do_bias) bsum += vg[j];
         }
 #pragma unroll
@@ -755,7 +766,8 @@ bool dw_h2w_launch(const DwParams &p, hipStream_t hs) {
     const int64_t grid = (p.Fo / 128) * p.nseg * p.nchunks;
     if (grid >= (int64_t)INT32_MAX) return false;
     const dim3 gd((unsigned)grid), bd(512);
-    hipLaunchKernelGGL(k_dw_h2w, gd, bd, 0, hs, p);
+    if (p.g2) hipLaunchKernelGGL((k_dw_h2w<true>), gd, bd, 0, hs, p);
+    else hipLaunchKernelGGL((k_dw_h2w<false>), gd, bd, 0, hs, p);
     return true;
 }
 

@@ -397,6 +397,12 @@ int dc_tag_linear_fwd_h2p(const float *x, int64_t ldx, const void *w_image, cons
 int dc_tag_linear_fwd_h2p_exp(const float *x, int64_t ldx, const void *w_image, float *out, int64_t ldo,
                               int64_t N, int64_t K, int64_t Fo, const float *x_rowmax, const float *w_rowmax,
                               const float *row_lse, int64_t ncols_valid, dc_stream_t stream);
+/* dc_tag_linear_fwd_h2p (no bias, no relu, no split reduction) with the left operand x[i, :] - x2_coef[i] * x2[i, :]
+ * formed at load time (x2 with x's leading dimension): the attention backward's dQ = (dS' - eps o P) K without
+ * materialising the corrected dS.  128 x 256 tile kernel only (K % 32 == 0, 16-byte aligned rows). */
+int dc_tag_linear_fwd_h2p_corr(const float *x, int64_t ldx, const float *x2, const float *x2_coef, const void *w_image,
+                               float *out, int64_t ldo, int64_t N, int64_t K, int64_t Fo, const float *x_rowmax,
+                               const float *w_rowmax, dc_stream_t stream);
 /* ---- grouped launches: both encoder branches as ONE block-diagonal launch ----
  * The reference runs its two branches as 2 x 2 conv calls (models/model.py:69-78).  Over a merged node
  * space (dc_graph_build_parts) the second layers of both branches - same widths, different weights -

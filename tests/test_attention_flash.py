@@ -159,3 +159,29 @@ def test_flash_ds_kernel_outputs_vs_float64():
     assert np.allclose(_np(dsmax), np.abs(_np(ds)).max(axis=1), rtol=0, atol=0)
     rows = np.abs(_np(ds).astype(np.float64).sum(axis=1))
     assert rows.max() <= 2e-6 * np.abs(_np(ds)).sum(axis=1).max()
+
+
+def test_one_sweep_backward_when_the_values_share_a_large_common_component(monkeypatch):
+    """Post-ReLU features: every value row = a large common vector + a small individual part, so dP = dO V^T is nearly
+    constant over the keys and |delta_i| is ~100x the spread of dP_i. - the regime in which an inconsistent delta shows
+    (round 2's precision fix).  The one-sweep backward (delta = rowsum(dO * O), eps correction in dK AND dQ) must stay
+    as close to float64 as the two-sweep form."""
+    torch.manual_seed(21)
+    ns, nr = 700, 260
+    q = torch.randn(ns, 256, device=DEV) * 0.4
+    k = torch.randn(nr, 256, device=DEV) * 0.4 + 1.5                 # keys with a common component as well
+    v = 10.0 + 0.1 * torch.randn(nr, 256, device=DEV)
+    go = torch.randn(ns, 256, device=DEV)
+    one = _run(q, k, v, go, True, monkeypatch, flash_bwd=True, single=True)
+    two = _run(q, k, v, go, True, monkeypatch, flash_bwd=True, single=False)
+    qd, kd, vd = (t.double().cpu().requires_grad_() for t in (q, k, v))
+    ref = torch.softmax(qd @ kd.t(), dim=-1) @ vd
+    ref.backward(go.double().cpu())
+    for name, a, b, w in zip(("dq", "dk", "dv"), one[1:], two[1:], (qd.grad, kd.grad, vd.grad)):
+        ea, eb = rel_err(a, w.numpy()), rel_err(b, w.numpy())
+        assert ea <= max(1e-5, 2 * eb), (name, ea, eb)
+    # and the head-weight-like reduction that carried the bias: sum over the keys of dK, sum over the queries of dQ
+    for a, b, w in ((one[2], two[2], kd.grad), (one[1], two[1], qd.grad)):
+        sa, sb, sw = a.sum(axis=0), b.sum(axis=0), w.numpy().sum(axis=0)
+        scale = np.abs(w.numpy()).sum(axis=0).max()
+        assert np.abs(sa - sw).max() <= max(2 * np.abs(sb - sw).max(), 2e-6 * scale)
