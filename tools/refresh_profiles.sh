@@ -37,6 +37,7 @@ done
 (cd "$R" && timeout -s KILL 300 python tools/exp/gap_parts.py > "$O/new_batch_gap_parts.txt" 2>&1)
 (cd "$R" && timeout -s KILL 300 python tools/exp/attn_flash.py > "$O/attn_flash_fwd.txt" 2>&1; timeout -s KILL 300 python tools/exp/attn_flash_bwd.py > "$O/attn_flash_bwd.txt" 2>&1)
 (cd "$R" && timeout -s KILL 300 python tools/exp/hop_colsplit.py > "$O/hop_column_split.txt" 2>&1)
+(cd "$R" && timeout -s KILL 300 python tools/exp/attn_flash_stress.py 40 > "$O/attn_flash_stress.txt" 2>&1)
 (cd "$R" && for b in 32 16; do timeout -s KILL 300 python tools/full_step.py --batch $b --steps 5 --graph 2>&1 | tail -1; done > "$O/full_step_graph.txt"; timeout -s KILL 300 python tools/full_step.py --batch 32 --steps 3 2>&1 | tail -1 >> "$O/full_step_graph.txt")
 # keep the summaries, drop the bulky per-dispatch traces (gpurun_out/ travels back, 64 MiB cap)
 find "$R/$O" -name "*kernel_trace.csv" -delete
