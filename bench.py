@@ -514,6 +514,40 @@ def full_step_b4(dev, steps: int = 20, batch: int = 4):
                     "Adam = dc_adam_flat"}
 
 
+def full_forward(dev, batch: int = 32, steps: int = 10):
+    """Extra: the reference's inference path (eval.py: model(rest, rigid) under no_grad) at the benchmark batch - encoder,
+    unmasked cross-attention (dc_attn_flash_fwd), decoder - one hipGraph, ms per forward."""
+    from deformcontact_amd import synth
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
+    rest, _, rig = (b.to(dev) for b in synth.make_batch(batch))
+    torch.manual_seed(0)
+    model = load_model(EVERYDAY_NETWORK).to(dev).eval()
+    for e in model.topology(rest, rig) if hasattr(model, "topology") else []:
+        e._static_ok = True
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                out = model(rest, rig)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = model(rest, rig)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    edges = rest.edge_index.shape[1] + rig.edge_index.shape[1]
+    return {"ms_per_forward": round(el / steps * 1e3, 3), "M_edges_per_s": round(edges * steps / el / 1e6, 2),
+            "batch": batch, "finite": bool(torch.isfinite(out.pos).all()),
+            "note": "whole model forward under no_grad (eval.py), topology cached, one hipGraph"}
+
+
 def train_loop(dev, batch: int = 4, steps: int = 40):
     """BASELINE.json configs[2]: the REAL loop - `train.train()`'s inner loop on the synthetic dataset: a
     new batch every step from `loaders.PrefetchLoader` (worker-thread assembly, pinned upload on a side
@@ -1166,6 +1200,10 @@ def main():
                 out["train_loop_b4"] = {"error": f"{type(e).__name__}: {e}"}
             out["full_train_step_b4"] = full_step_b4(dev)
             out["full_train_step_b32"] = full_step_b4(dev, steps=5, batch=32)
+            try:
+                out["full_forward_b32"] = full_forward(dev, 32)
+            except Exception as e:  # pragma: no cover
+                out["full_forward_b32"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_seconds)
         print(json.dumps(out), flush=True)
