@@ -134,8 +134,13 @@ class GraphIndex:
         self._pos_fwd = None
         self._bwd_to_fwd = None
         self._num_edges = None if self_loops else self.num_input_edges
+        #: nodes of the largest graph of the batch (``ops.chained_hops`` picks ``dc_hop_chain_f32`` by it)
+        self._seg_max_nodes = 0
         if segments is not None and parts is None and not self_loops:
             self._segments = _segment_arrays(segments, self.num_nodes, self.num_input_edges, self.device)
+            if self._segments is not None:
+                nodes = self._segments[0]
+                self._seg_max_nodes = max(nodes[i + 1] - nodes[i] for i in range(self._segments[2]))
         self.rebuild()
         if validate:
             self.validate()

@@ -206,6 +206,39 @@ DENSE_PRODUCTS = int(os.environ.get("DC_DENSE_PRODUCTS", "6"))
 DENSE_F16X2 = os.environ.get("DC_DENSE_F16X2", "1") != "0"
 
 
+#: K chained hops of a batch with a known layout as ONE launch with every graph's slice resident in LDS
+#: (``dc_hop_chain_f32``, bit-identical to the K single hops); ``DC_HOP_CHAIN=0``: hop by hop.
+HOP_CHAIN = os.environ.get("DC_HOP_CHAIN", "1") != "0"
+_CHAIN_MAX_NODES = None
+
+
+def hop_chain_eligible(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int) -> bool:
+    """Can ``dc_hop_chain_f32`` run this chain?  Needs the batch layout (``graph_index(..., segments=)``), graphs
+    of at most ``dc_hop_chain_max_nodes()`` nodes, F % 32 == 0 and 16-byte aligned slab rows."""
+    global _CHAIN_MAX_NODES
+    seg = getattr(g, "_segments", None)
+    if not HOP_CHAIN or seg is None or k < 1 or f % 32 != 0 or adj.row_offset:
+        return False
+    if _CHAIN_MAX_NODES is None:
+        _CHAIN_MAX_NODES = int(_lib.lib().dc_hop_chain_max_nodes())
+    return (0 < g._seg_max_nodes <= _CHAIN_MAX_NODES and slab.dtype == torch.float32 and slab.dim() == 2
+            and slab.stride(1) == 1 and slab.stride(0) % 4 == 0 and slab.data_ptr() % 16 == 0
+            and adj.ptr.numel() == slab.size(0) + 1)
+
+
+def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weighted: bool = True,
+              rowmax: Optional[torch.Tensor] = None, rowmax_mode: int = 0, src_block: int = 0, direction: int = 1) -> None:
+    """``dc_hop_chain_f32``: blocks ``src_block + direction .. src_block + k * direction`` of ``slab`` from block
+    ``src_block``, one launch (see ``hop_chain_eligible``)."""
+    nptr, _, nseg = g._segments
+    w = adj.w if weighted else None
+    rc = _lib.lib().dc_hop_chain_f32(
+        adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None, adj.other.numel(),
+        nptr, nseg, slab.data_ptr(), slab.stride(0), slab.size(0), f, k, int(src_block), int(direction),
+        rowmax.data_ptr() if rowmax is not None else None, int(rowmax_mode), current_stream_ptr(slab.device))
+    _lib.check(rc, "dc_hop_chain_f32")
+
+
 def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool,
                  rowmax: Optional[torch.Tensor] = None, transposed: bool = False,
                  rowmax_has_block0: bool = False) -> None:
@@ -221,6 +254,9 @@ def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bo
     if backward:
         for j in range(k, 0, -1):
             hop(adj, blocks[j], out=blocks[j - 1], addend=blocks[j - 1], weighted=g.normalize)
+    elif hop_chain_eligible(g, adj, slab, f, k):
+        hop_chain(g, adj, slab, f, k, weighted=g.normalize, rowmax=rowmax,
+                  rowmax_mode=2 if rowmax_has_block0 else 1)
     else:
         for j in range(k):
             hop(adj, blocks[j], out=blocks[j + 1], weighted=g.normalize, rowmax=rowmax,

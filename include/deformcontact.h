@@ -206,6 +206,27 @@ int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
                        int64_t ldx, const float *addend, int64_t ldadd, float *y, int64_t ldy,
                        int64_t N, int64_t F, float *rowmax, int mode, dc_stream_t stream);
 
+/* ---- K chained hops of a batch of small graphs in ONE launch (dc_hopchain.hip) ---------------
+ * TAGConv.forward's K dependent propagate calls (PyG nn/conv/tag_conv.py, reached from
+ * models/model.py:71,77) over a batch whose layout is known (Batch.from_data_list, train.py:36-38):
+ * graph i owns the contiguous node range [node_ptr_host[i], node_ptr_host[i+1]) and none of its
+ * edges leaves it (the layout dc_graph_build_segmented takes).  `slab` is the [N, ld] hop slab of a
+ * layer, column block j = slab[:, j*F : (j+1)*F]; the call computes, for k = 1..K,
+ *     block (src_block + k*dir)  =  A_hat . block (src_block + (k-1)*dir)
+ * with every graph's 32-column slice resident in LDS for the whole chain - memory traffic: block
+ * src_block in once, K blocks out once - and terms, order and rounding of dc_spmm_f32, so every
+ * block is bit-identical to K dc_spmm_f32 calls.  rowmax != NULL: rowmax[i] = max over the K
+ * produced blocks of max |block[i, :]|, joined with block src_block's when mode & 1 and with the
+ * value rowmax[i] already holds when mode & 2 (what K dc_spmm_f32_rowmax calls leave there).
+ * `cap` = number of elements `other` / `w` hold (16-byte id / weight loads are range-checked
+ * against it).  Needs F % 32 == 0, ld % 4 == 0, a 16-byte aligned slab and at most
+ * dc_hop_chain_max_nodes() (1024) nodes per graph; DC_EINVAL otherwise (use dc_spmm_f32). */
+int64_t dc_hop_chain_max_nodes(void);
+int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, int64_t cap,
+                     const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
+                     int64_t F, int K, int src_block, int dir, float *rowmax, int mode,
+                     dc_stream_t stream);
+
 /* ---- the dense block over bf16-STORED features (BASELINE.json configs[4]) ------------------
  * out[N,Fo] = act(A[N,K] . W[Fo,K]^T + bias) with A and W bf16 (uint16 bit patterns, K-contiguous,
  * K % 32 == 0, 16-byte aligned, lda % 8 == 0), fp32 accumulate on v_mfma_f32_32x32x16_bf16, out

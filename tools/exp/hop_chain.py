@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""dc_hop_chain_f32 (one launch per 3-hop chain, graph slices resident in LDS) against three dc_spmm_f32_rowmax
+launches: bit-identity on the B=32 batch, then the F=256 hop chains of a step (forward + transposed chain per branch,
+row maxima; four slabs = 0.5 GB alive, as in a step) timed graph-replayed with HIP events, per chain and in all."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from deformcontact_amd import ops, synth  # noqa: E402
+from deformcontact_amd.graph import GraphIndex  # noqa: E402
+
+F = 256
+
+
+def chain(g, slab, rm, bwd, fused):
+    adj = g.bwd if bwd else g.fwd
+    if fused:
+        ops.hop_chain(g, adj, slab, F, 3, rowmax=rm, rowmax_mode=2 if bwd else 1)
+        return
+    for j in range(3):
+        ops.hop(adj, slab[:, j * F:(j + 1) * F], out=slab[:, (j + 1) * F:(j + 2) * F], rowmax=rm,
+                rowmax_mode=2 if (bwd or j > 0) else 1)
+
+
+def timed(fn, reps=20, inner=5):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(inner):
+            fn()
+    gr.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        gr.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * inner) * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    rest, _, rig = synth.make_batch(batch)
+    graphs = [GraphIndex(b.edge_index.to(dev), b.x.shape[0], segments=b.segments()) for b in (rest, rig)]
+    for g in graphs:
+        n = g.num_nodes
+        a = ops._alloc_slab(n, 4 * F, dev)
+        a.normal_()
+        b = a.clone()
+        ra, rb = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        for bwd in (False, True):
+            chain(g, a, ra, bwd, False)
+            chain(g, b, rb, bwd, True)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b) and torch.equal(ra, rb), "fused chain differs from three hops"
+    print("bit-identical on both graphs, both directions")
+    seq = [(g, ops._alloc_slab(g.num_nodes, 4 * F, dev).normal_(), torch.zeros(g.num_nodes, device=dev), bwd)
+           for g in graphs for bwd in (False, True)]
+    n = sum(g.num_nodes for g in graphs)
+    e = sum(g.num_input_edges for g in graphs)
+    comp_hop = e * 8 + n * (8 * F + 4)                       # compulsory bytes of ONE hop over both graphs
+    fused_min = e * 8 + n * (4 * F * 4 + 4)                  # what a 3-hop chain must move: 1 block in, 3 out
+    for fused in (False, True):
+        us = timed(lambda: [chain(g, s, r, b, fused) for g, s, r, b in seq])
+        print(f"{'fused chain (4 launches)' if fused else 'hop by hop (12 launches)':26s}: {us:7.1f} us per step's F=256 hops; "
+              f"per-hop compulsory bytes / time = {6 * comp_hop / us / 1e6:.2f} TB/s = {6 * comp_hop / us / 1e6 / 8:.3f} of 8 TB/s"
+              + (f"; chain's own minimum traffic / time = {2 * fused_min / us / 1e6:.2f} TB/s" if fused else ""))
+        for (g, s, r, b) in seq:
+            u1 = timed(lambda: chain(g, s, r, b, fused))
+            print(f"    {'soft ' if g is graphs[0] else 'rigid'} {'transposed' if b else 'forward   '} chain alone "
+                  f"(slab stays cached): {u1:6.1f} us")
+
+
+if __name__ == "__main__":
+    main()
