@@ -1114,31 +1114,62 @@ def main():
         # the forward chain block0 -> 1 -> 2 -> 3 of the layer-2 slab (each hop reads what the previous one
         # wrote) and the same chain over the transposed adjacency on the gradient slab, all with the row-maxima
         # side output; merged encoder path: 6 launches over the merged adjacency of both branches, else 12
-        in_step_sequence, nlaunch, comp_bytes, gath_bytes = pmc_hop.hop_sequence(dev, parts, merged, f)
+        seg_list = None if merged else [rest.segments() if callable(getattr(rest, "segments", None)) else None,
+                                        rig.segments() if callable(getattr(rig, "segments", None)) else None]
+        if not args.segmented_build:
+            seg_list = None
+        in_step_sequence, nlaunch, comp_bytes, gath_bytes = pmc_hop.hop_sequence(dev, parts, merged, f, segments=seg_list)
+        nhops = 6 if merged else 12                             # F=256 hops of a step, whatever the launch count
+        chained = nlaunch < nhops
         tot_ms = graph_time(in_step_sequence, nlaunch, calls=5) * nlaunch
-        achieved = comp_bytes / tot_ms / 1e6                     # GB/s of compulsory bytes
+        achieved = comp_bytes / tot_ms / 1e6                     # GB/s of per-hop compulsory bytes
+        # what a fused 3-hop launch itself has to move: the source block in once, three blocks out, the adjacency once
+        fused_min = sum(2 * (e_ * 8 + n_ * (4 * 4 * f + 4)) for n_, e_ in ((n_s, e_s), (n_r, e_r)))
         out["roofline"] = {
-            "bound": "hbm", "kernel": "dc::k_spmm_wave<4,8,true> (F=256 hop + row maxima, as launched in a step" +
-                                      (": ONE launch for both branches over the merged adjacency)" if merged else ")"),
+            "bound": "hbm",
+            "kernel": ("dc::k_hop_chain<true,8> / <true,6> (dc_hop_chain_f32: the 3 F=256 hops of a chain + row maxima as ONE "
+                       "launch, every graph's 32-column slice resident in LDS; forward and transposed chain of both branches)")
+            if chained else
+            ("dc::k_spmm_wave<4,8,true> (F=256 hop + row maxima, as launched in a step" +
+             (": ONE launch for both branches over the merged adjacency)" if merged else ")")),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
-            "bytes_model": "compulsory: E*8 + N*(2*4F + 4) per launch (each index / weight once, each "
-                           "feature row in once and out once; SURVEY.md 8(d) strict lower bound; N, E = real "
-                           "nodes / edges of the batch, padding rows of the merged node space not counted)",
-            "launches_per_step": nlaunch,
+            "bytes_model": "compulsory bytes PER HOP, E*8 + N*(2*4F + 4) (each index / weight once, each feature row in "
+                           "once and out once; SURVEY.md 8(d) strict lower bound; N, E = real nodes / edges of the "
+                           "batch), times the hops a launch performs" +
+                           (" (3 per dc_hop_chain_f32 launch: the unit SURVEY.md 8(d) prices is the edge-hop)" if chained else ""),
+            "launches_per_step": nlaunch, "hops_per_launch": nhops // nlaunch,
             "compulsory_bytes_per_launch": int(comp_bytes / nlaunch),
             "avg_launch_us": round(tot_ms / nlaunch * 1e3, 2),
+            "avg_us_per_hop": round(tot_ms / nhops * 1e3, 2),
             "frac_of_measured_copy_peak_6290GBps": round(achieved / 6290.0, 4),
             "l2_served_algorithmic_GBps": round(gath_bytes / tot_ms / 1e6, 1),
             "l2_served_algorithmic_bytes_per_launch": int(gath_bytes / nlaunch),
-            "l2_served_note": "SURVEY.md 8(d) gather model (every neighbour row counted per edge); most of "
-                              "these reads are L2 hits, so this figure is NOT an HBM fraction",
-            "measured": f"the {nlaunch} F=256 hop launches of a step in step order on step-shaped slabs (forward "
-                        "chain and transposed chain" + (" over the merged adjacency" if merged else "s of both branches") +
+            "l2_served_note": "SURVEY.md 8(d) gather model (every neighbour row counted per edge); the chain kernel serves "
+                              "these reads from LDS, the per-hop kernel from L2 - NOT an HBM fraction either way",
+            "measured": f"the {nlaunch} launches that perform the {nhops} F=256 hops of a step, in step order on step-shaped "
+                        "slabs (forward chain and transposed chain" + (" over the merged adjacency" if merged else "s of both branches") +
                         "), replayed from a hipGraph as the step is (no host launch cost), HIP events on the launch "
                         "stream, launch gaps included",
             "cases_isolated": per_case,
         }
+        if chained:
+            # the fused launch against what IT must move (1 block in + 3 out per chain): the honest HBM fraction of the
+            # kernel that ships; `frac` above stays on the per-hop model so that rounds compare
+            out["roofline"]["fused_chain_min_bytes_per_launch"] = int(fused_min / nlaunch)
+            out["roofline"]["fused_chain_min_GBps"] = round(fused_min / tot_ms / 1e6, 1)
+            out["roofline"]["fused_chain_min_frac"] = round(fused_min / tot_ms / 1e6 / HBM_PEAK_GBS, 4)
+            # and the same hops hop by hop (the r01-r03 kernel), same slabs, same method
+            keep_chain = ops.HOP_CHAIN
+            ops.HOP_CHAIN = False
+            try:
+                fn1, nl1, comp1, _ = pmc_hop.hop_sequence(dev, parts, merged, f, segments=seg_list)
+                t1 = graph_time(fn1, nl1, calls=5) * nl1
+                out["roofline"]["hop_by_hop"] = {"kernel": "dc::k_spmm_wave<4,8,true>", "launches_per_step": nl1,
+                                                 "avg_launch_us": round(t1 / nl1 * 1e3, 2),
+                                                 "frac": round(comp1 / t1 / 1e6 / HBM_PEAK_GBS, 4)}
+            finally:
+                ops.HOP_CHAIN = keep_chain
         gs, gr = GraphIndex(rest.edge_index, n_s), GraphIndex(rig.edge_index, n_r)
         if merged and ops.DENSE_SPLIT_BF16 and ops.DENSE_F16X2:
             out["roofline_mfma"] = dense_roofline_grouped(dev, parts, args.kernel_reps // 4 or 1)

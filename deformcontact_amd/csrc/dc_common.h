@@ -35,6 +35,12 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return base + idx;
 }
 
+// gcn_norm's deg.pow(-0.5) with inf -> 0 (PyG gcn_conv.py: gcn_norm): ONE definition, so that every kernel that
+// forms a weight dis[source] * dis[destination] (dc_csr.hip writes them, dc_hopchain.hip re-forms them) gets the same bits
+__device__ __forceinline__ float inv_sqrt_count(int d) {
+    return d > 0 ? 1.0f / sqrtf((float)d) : 0.0f;
+}
+
 }  // namespace dc
 
 #define DC_REQUIRE(cond, ...)            \

@@ -341,8 +341,7 @@ k_fill(Build b, int nsides) {
 }
 
 __device__ __forceinline__ float inv_sqrt_deg(const int32_t *deg_ptr, int64_t v) {
-    const int d = deg_ptr[v + 1] - deg_ptr[v];
-    return d > 0 ? 1.0f / sqrtf((float)d) : 0.0f;   // deg.pow(-0.5), inf -> 0
+    return inv_sqrt_count(deg_ptr[v + 1] - deg_ptr[v]);   // deg.pow(-0.5), inf -> 0
 }
 
 __device__ __forceinline__ void emit_one(const Build &b, const Side &sd, int32_t eid, int64_t k,
@@ -463,10 +462,6 @@ struct SegBuild {
     float *w[2];
     int32_t *status;
 };
-
-__device__ __forceinline__ float inv_sqrt_count(int d) {
-    return d > 0 ? 1.0f / sqrtf((float)d) : 0.0f;      // as inv_sqrt_deg
-}
 
 __global__ void __launch_bounds__(1024)
 k_build_segment(SegBuild b) {

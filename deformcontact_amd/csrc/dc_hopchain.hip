@@ -20,6 +20,15 @@
 
 #pragma clang fp contract(off)
 
+// timing-only ablations (tools/exp/hop_chain_abl.py builds this file with -DDC_CHAIN_ABL=<bits>; results are wrong by
+// construction): 1 no block stores, 2 no neighbour slots at all, 4 no LDS write-back / barriers between hops,
+// 8 no source-block staging, 16 no id / weight loads, 32 LDS gathers but no arithmetic, 64 block stores to a
+// contiguous 128 KiB region per workgroup and hop (is the row-strided 128-byte store pattern what costs?), 128 ids /
+// weights made up in registers instead of loaded (do the in-loop VMEM loads couple the compute to the stores?)
+#ifndef DC_CHAIN_ABL
+#define DC_CHAIN_ABL 0
+#endif
+
 namespace dc {
 
 constexpr int kChainCols = 32;        // columns per slice: 128-byte row pieces, one full cache line per store
@@ -29,6 +38,7 @@ constexpr int kChainGraphs = 96;      // graphs per launch (their node offsets t
 struct ChainParams {
     const int32_t *ptr, *other;
     const float *w;
+    const int32_t *deg_ptr;           // k_hop_chain_gcn: in-degree offsets, w[p] = d(dst)^-1/2 * d(src)^-1/2
     float *slab;
     int64_t ld;
     float *rowmax;
@@ -39,11 +49,6 @@ struct ChainParams {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int CTRL>
-__device__ __forceinline__ float chain_dpp_max(float v) {
-    const int i = __float_as_int(v);
-    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, false)));
-}
 __device__ __forceinline__ float chain_absmax(const float4 &v) {
     return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
@@ -53,12 +58,42 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// maximum of m over the 8 lanes of a row piece, joined into the lane that `keep` selects
-__device__ __forceinline__ float group_max_into(float run, float m, bool keep) {
-    m = chain_dpp_max<0xB1>(m);                                  // quad_perm [1,0,3,2]
-    m = chain_dpp_max<0x4E>(m);                                  // quad_perm [2,3,0,1]
-    m = chain_dpp_max<0x141>(m);                                 // row_half_mirror: all 8 lanes hold the maximum
-    return keep ? fmaxf(run, m) : run;
+// LDS through plain 32-bit byte addresses (base + offsets folded by hand: one v_lshl_add_u32 per neighbour piece)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_read4(unsigned addr) {
+    const f32x4 v = *(const __attribute__((address_space(3))) f32x4 *)(uintptr_t)addr;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// a produced 16-byte piece leaves through a buffer descriptor over the graph's own rows: ONE unconditional instruction
+// (rows past the graph's end fall outside the descriptor and are dropped by the range check), which hipcc can count -
+// behind a store under a branch it waits for vmcnt(0), i.e. for the store itself, before every later use of a load
+__device__ __forceinline__ void store_piece(const float4 &a, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    u32x4 av;
+    av.x = __float_as_uint(a.x), av.y = __float_as_uint(a.y), av.z = __float_as_uint(a.z), av.w = __float_as_uint(a.w);
+    if (DC_CHAIN_ABL & 1)
+        asm volatile("" ::"v"(av.x), "v"(av.y), "v"(av.z), "v"(av.w));
+    else
+        __builtin_amdgcn_raw_buffer_store_b128(av, rs, off, 0, 0);
+}
+
+// 8 lanes x 8 rows of per-lane maxima -> lane `sub` holds the maximum of the row of step `sub` (a transposing
+// butterfly); the slices of a row then meet in rowmax[row]: non-negative floats order like their bit patterns
+__device__ __forceinline__ void publish_rowmax(const float (&pm)[8], int sub, int steps, int row, int nn, float *rowmax) {
+    float q[4], r[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = (sub & 1) ? pm[2 * i + 1] : pm[2 * i], send = (sub & 1) ? pm[2 * i] : pm[2 * i + 1];
+        q[i] = fmaxf(keep, __shfl_xor(send, 1));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = (sub & 2) ? q[2 * i + 1] : q[2 * i], send = (sub & 2) ? q[2 * i] : q[2 * i + 1];
+        r[i] = fmaxf(keep, __shfl_xor(send, 2));
+    }
+    const float keep = (sub & 4) ? r[1] : r[0], send = (sub & 4) ? r[0] : r[1];
+    const float rm = fmaxf(keep, __shfl_xor(send, 4));
+    if (sub < steps && row < nn) atomicMax(reinterpret_cast<int *>(rowmax + row), __float_as_int(rm));
 }
 
 struct Chunk {                        // ids and weights of 8 consecutive edges
@@ -68,6 +103,17 @@ struct Chunk {                        // ids and weights of 8 consecutive edges
 template <bool W>
 __device__ __forceinline__ void load_chunk(Chunk &c, __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rw, int p) {
     // 4-byte aligned 16-byte loads, range-checked per dword against the arrays' size (past the end: 0)
+    if (DC_CHAIN_ABL & 16) {
+        c.i0 = c.i1 = c.w0 = c.w1 = u32x4{(unsigned)p, (unsigned)p, (unsigned)p, (unsigned)p} & 0u;
+        return;
+    }
+    if (DC_CHAIN_ABL & 128) {                                    // ids made up from the edge offset: no VMEM load, spread rows
+        const unsigned q = (unsigned)p / 6u;
+        c.i0 = u32x4{(q + 1) & 511u, (q + 14) & 511u, (q + 27) & 511u, (q + 40) & 511u};
+        c.i1 = u32x4{(q + 53) & 511u, (q + 66) & 511u, (q + 79) & 511u, (q + 92) & 511u};
+        c.w0 = c.w1 = u32x4{0x3e000000u, 0x3e000000u, 0x3e000000u, 0x3e000000u};
+        return;
+    }
     c.i0 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * p, 0, 0);
     c.i1 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * p + 16, 0, 0);
     if (W) {
@@ -76,34 +122,66 @@ __device__ __forceinline__ void load_chunk(Chunk &c, __amdgpu_buffer_rsrc_t ro, 
     }
 }
 
-template <bool W>
-__device__ __forceinline__ void slot(float4 &acc, unsigned id, unsigned wbits, bool valid, int lbase, int zsub,
-                                     const char *smem) {
-    const int off = valid ? (int)(id * 128u) + lbase : zsub;
-    const float ww = valid ? (W ? __uint_as_float(wbits) : 1.0f) : 0.0f;
-    const float4 v = *reinterpret_cast<const float4 *>(smem + off);
-    const float mx = ww * v.x, my = ww * v.y, mz = ww * v.z, mw = ww * v.w;
-    acc.x = acc.x + mx;
-    acc.y = acc.y + my;
-    acc.z = acc.z + mz;
-    acc.w = acc.w + mw;
+// NS neighbour slots of a chunk for the wave's 8 rows: every piece is requested from LDS before the first is used
+// (one exposed LDS latency per step, not one per slot).  Slots >= MFROM are tested against `rem`, the neighbours the
+// lane's row still has: past its end a slot reads the row of zeros with weight 0.  Slots < MFROM are known - by a
+// wave-wide vote of the caller - to exist in all 8 rows: no test, one address instruction per piece.
+template <bool W, int NS, int MFROM, int J0 = 0>
+__device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem, unsigned lbase, unsigned zsub) {
+    const unsigned id[8] = {c.i0.x, c.i0.y, c.i0.z, c.i0.w, c.i1.x, c.i1.y, c.i1.z, c.i1.w};
+    const unsigned wb[8] = {c.w0.x, c.w0.y, c.w0.z, c.w0.w, c.w1.x, c.w1.y, c.w1.z, c.w1.w};
+    float4 v[NS];
+    float ww[NS];
+    if (DC_CHAIN_ABL & 2) return;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        unsigned off = id[J0 + j] * 128u + lbase;
+        float wt = W ? __uint_as_float(wb[J0 + j]) : 1.0f;
+        if (J0 + j >= MFROM) {
+            const bool valid = J0 + j < rem;
+            off = valid ? off : zsub;
+            wt = valid ? wt : 0.0f;
+        }
+        v[j] = lds_read4(off);
+        ww[j] = wt;
+    }
+    if (DC_CHAIN_ABL & 32) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) asm volatile("" ::"v"(v[j].x), "v"(v[j].y), "v"(v[j].z), "v"(v[j].w), "v"(ww[j]));
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const float mx = ww[j] * v[j].x, my = ww[j] * v[j].y, mz = ww[j] * v[j].z, mw = ww[j] * v[j].w;
+        acc.x = acc.x + mx;
+        acc.y = acc.y + my;
+        acc.z = acc.z + mz;
+        acc.w = acc.w + mw;
+    }
 }
 
-// the up-to-8 neighbours of a chunk for the wave's 8 rows (rem = neighbours the lane's row still has)
+// one step: the wave's 8 rows against the chunk of their first 8 neighbours, specialised by a wave-wide vote on the
+// rows' degrees (triangle meshes: 5, 6 or 7 almost everywhere), and the rare longer rows chunk by chunk
 template <bool W>
-__device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem, int lbase, int zsub,
-                                            const char *smem) {
-    slot<W>(acc, c.i0.x, c.w0.x, 0 < rem, lbase, zsub, smem);
-    slot<W>(acc, c.i0.y, c.w0.y, 1 < rem, lbase, zsub, smem);
-    slot<W>(acc, c.i0.z, c.w0.z, 2 < rem, lbase, zsub, smem);
-    slot<W>(acc, c.i0.w, c.w0.w, 3 < rem, lbase, zsub, smem);
-    slot<W>(acc, c.i1.x, c.w1.x, 4 < rem, lbase, zsub, smem);
-    if (__any(rem > 5)) {
-        slot<W>(acc, c.i1.y, c.w1.y, 5 < rem, lbase, zsub, smem);
-        if (__any(rem > 6)) {
-            slot<W>(acc, c.i1.z, c.w1.z, 6 < rem, lbase, zsub, smem);
-            if (__any(rem > 7)) slot<W>(acc, c.i1.w, c.w1.w, 7 < rem, lbase, zsub, smem);
-        }
+__device__ __forceinline__ void step_rows(float4 &a, const Chunk &c, int pbeg, int rem, unsigned lbase, unsigned zsub,
+                                          __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rw) {
+    if (__all(rem >= 5) && !__any(rem > 7)) {
+        if (__any(rem > 6))
+            chunk_slots<W, 7, 5>(a, c, rem, lbase, zsub);
+        else
+            chunk_slots<W, 6, 5>(a, c, rem, lbase, zsub);
+        return;
+    }
+    // the general path (padding rows, short or long rows) runs rarely: four pieces in flight keep its registers
+    // below what the common paths need
+    chunk_slots<W, 4, 0, 0>(a, c, rem, lbase, zsub);
+    if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, c, rem, lbase, zsub);
+    while (__any(rem > 8)) {                                     // rows with more than 8 neighbours (mesh poles, hubs)
+        pbeg += 8, rem -= 8;
+        Chunk n;
+        load_chunk<W>(n, ro, rw, pbeg);
+        chunk_slots<W, 4, 0, 0>(a, n, rem, lbase, zsub);
+        if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, n, rem, lbase, zsub);
     }
 }
 
@@ -131,7 +209,7 @@ k_hop_chain(ChainParams p) {
         for (int s = 0; s < STEPS; ++s)
             if (s < steps) {
                 const int row = rwave + 8 * s + grp;
-                if (row < nn)
+                if (row < nn && !(DC_CHAIN_ABL & 8))
                     __builtin_amdgcn_global_load_lds(
                         (const void __attribute__((address_space(1))) *)(src + (int64_t)row * p.ld),
                         (void __attribute__((address_space(3))) *)(smem + (rwave + 8 * s) * 128), 16, 0, 0);
@@ -153,23 +231,20 @@ k_hop_chain(ChainParams p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): the slice has landed (a wait hipcc can see:
     lds_barrier();                                               // behind an asm wait it drains vmcnt before every ds_read)
 
-    // row maxima: lane `sub` of a row's lane group keeps the running maximum of the group's row of step `sub`
+    // row maxima: every lane keeps the running maximum of ITS four columns of each of its 8 rows; the 8 lanes of a
+    // row piece are joined once, at the end
     const bool want_rm = p.rowmax != nullptr;
-    float rm = 0.f;
-    if (want_rm && (p.rm_mode & 1)) {
+    float pm[8];
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s)
-            if (s < steps)                                       // the row's own piece of the source block
-                rm = group_max_into(rm, chain_absmax(*reinterpret_cast<const float4 *>(
-                                            smem + (rwave + 8 * s + grp) * 128 + 16 * sub)), sub == s);
+    for (int s = 0; s < 8; ++s) {
+        pm[s] = 0.f;
+        if (s < STEPS && want_rm && (p.rm_mode & 1))             // the row's own piece of the source block
+            pm[s] = chain_absmax(*reinterpret_cast<const float4 *>(smem + (rwave + 8 * s + grp) * 128 + 16 * sub));
     }
 
-    const int lbase = 16 * sub - n0 * 128;                      // LDS byte offset of neighbour id: id * 128 + lbase
-    const int zsub = zoff + 16 * sub;
-    // the produced rows leave through a buffer descriptor over the graph's own rows: a store is ONE unconditional
-    // instruction (rows past the graph's end fall outside the descriptor and are dropped by the range check), so
-    // hipcc can count it: behind a store under a branch it waits for vmcnt(0) - i.e. for the store - before every
-    // use of the next step's ids
+    const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned lbase = sbase + 16u * sub - ((DC_CHAIN_ABL & 128) ? 0u : (unsigned)n0 * 128u);   // LDS address of a neighbour's piece: id * 128 + lbase
+    const unsigned zsub = sbase + zoff + 16u * sub;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.slab + (int64_t)n0 * p.ld, 0, (int)((unsigned)nn * (unsigned)p.ld * 4u), 0x00020000);
     const unsigned ldb = (unsigned)p.ld * 4u;
@@ -181,43 +256,196 @@ k_hop_chain(ChainParams p) {
         bd[0] = bounds[rwave + grp];
         load_chunk<W>(ck[0], ro, rw, bd[0].x);
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s)
-            if (s < steps) {
-                const int pbeg = bd[s & 1].x;
-                int rem = bd[s & 1].y;
-                if (s + 1 < STEPS) {                             // one step ahead
-                    bd[(s + 1) & 1] = bounds[rwave + 8 * (s + 1) + grp];
-                    load_chunk<W>(ck[(s + 1) & 1], ro, rw, bd[(s + 1) & 1].x);
-                }
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                chunk_slots<W>(a, ck[s & 1], rem, lbase, zsub, smem);
-                if (__any(rem > 8)) {                            // rows with more than 8 neighbours (mesh poles, hubs)
-                    int pb = pbeg;
-                    do {
-                        pb += 8, rem -= 8;
-                        Chunk c;
-                        load_chunk<W>(c, ro, rw, pb);
-                        chunk_slots<W>(a, c, rem, lbase, zsub, smem);
-                    } while (__any(rem > 8));
-                }
-                acc[s] = a;
-                const unsigned row = (unsigned)(rwave + 8 * s + grp);
-                u32x4 av;
-                av.x = __float_as_uint(a.x), av.y = __float_as_uint(a.y), av.z = __float_as_uint(a.z), av.w = __float_as_uint(a.w);
-                __builtin_amdgcn_raw_buffer_store_b128(av, rs, row * ldb + dcol, 0, 0);      // streams out meanwhile
-                if (want_rm) rm = group_max_into(rm, chain_absmax(a), sub == s);
+        for (int s = 0; s < STEPS; ++s) {
+            const int pbeg = bd[s & 1].x, rem = bd[s & 1].y;
+            if (s + 1 < STEPS) {                                 // one step ahead
+                bd[(s + 1) & 1] = bounds[rwave + 8 * (s + 1) + grp];
+                load_chunk<W>(ck[(s + 1) & 1], ro, rw, bd[(s + 1) & 1].x);
             }
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            step_rows<W>(a, ck[s & 1], pbeg, rem, lbase, zsub, ro, rw);
+            acc[s] = a;
+            pm[s] = fmaxf(pm[s], chain_absmax(a));
+            store_piece(a, rs, (unsigned)(rwave + 8 * s + grp) * ldb + dcol);               // streams out meanwhile
+        }
         if (h + 1 == p.K) break;
+        if (DC_CHAIN_ABL & 4) continue;
         lds_barrier();                                           // every wave has read what it needs of block h
 #pragma unroll
         for (int s = 0; s < STEPS; ++s)
-            if (s < steps) *reinterpret_cast<float4 *>(smem + (rwave + 8 * s + grp) * 128 + 16 * sub) = acc[s];
+            *reinterpret_cast<float4 *>(smem + (rwave + 8 * s + grp) * 128 + 16 * sub) = acc[s];
         lds_barrier();
     }
-    if (want_rm) {
-        // the slices of a row meet in rowmax[row]: non-negative floats order like their bit patterns
-        const int row = rwave + 8 * sub + grp;
-        if (sub < steps && row < nn) atomicMax(reinterpret_cast<int *>(p.rowmax + n0 + row), __float_as_int(rm));
+    if (want_rm) publish_rowmax(pm, sub, STEPS, rwave + 8 * sub + grp, nn, p.rowmax + n0);
+}
+
+// ---- gcn_norm weights: adjacency resident in LDS too -------------------------------------------------------------------
+// With w[p] = dis[source] * dis[destination], dis = in-degree^-1/2 (gcn_norm without self loops: what TAGConv hops
+// with, PyG tag_conv.py), the weights need not be loaded: dis (4 B per node) and the first 8 neighbour ids of every row
+// (2 B each, local to the graph, rows shorter than 8 padded with the index of the row of zeros, whose dis is 0) fit
+// behind the slice.  The hop loop then issues NO vector-memory load: vmcnt retires in order, so with the ids arriving
+// by buffer loads every step's id wait also waited for the older block stores, and the compute ran in series with
+// the write path (r04 ablation: stores and slots cost 54 + 47 us of a 148 us step and did not overlap; without
+// in-loop loads 108 us).  Rows with more than 8 neighbours (mesh poles, hubs) take their tail from global memory.
+template <int NS, int J0 = 0>
+__device__ __forceinline__ void gcn_slots(float4 &acc, const uint4 &iv, float di, unsigned lbase, unsigned dbase) {
+    const unsigned pk[4] = {iv.x, iv.y, iv.z, iv.w};
+    float4 v[NS];
+    float ww[NS];
+    if (DC_CHAIN_ABL & 2) return;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const unsigned id = ((J0 + j) & 1) ? pk[(J0 + j) >> 1] >> 16 : pk[(J0 + j) >> 1] & 0xffffu;
+        v[j] = lds_read4(id * 128u + lbase);
+        const float dj = *(const __attribute__((address_space(3))) float *)(uintptr_t)(id * 4u + dbase);
+        ww[j] = dj * di;                                         // dis[source] * dis[destination] (a row's ids are its sources
+    }                                                            // in the forward set, its destinations in the transposed one)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const float mx = ww[j] * v[j].x, my = ww[j] * v[j].y, mz = ww[j] * v[j].z, mw = ww[j] * v[j].w;
+        acc.x = acc.x + mx;
+        acc.y = acc.y + my;
+        acc.z = acc.z + mz;
+        acc.w = acc.w + mw;
+    }
+}
+
+template <int STEPS>
+__global__ void __launch_bounds__(1024)
+k_hop_chain_gcn(ChainParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int R = 128 * STEPS;                              // rows of the LDS slice; row R is the row of zeros
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = (int)(lb / (unsigned)p.nslices), slice = (int)(lb - (unsigned)seg * (unsigned)p.nslices);
+    const int n0 = p.node_ptr[seg], nn = p.node_ptr[seg + 1] - n0;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, grp = lane >> 3, sub = lane & 7;
+    const int rwave = wid * 8 * STEPS;
+    float *blk = p.slab + (int64_t)n0 * p.ld + slice * kChainCols + 4 * sub;
+    // LDS: slice [R][128 B] | zeros [128 B] | ids [R][8] u16 | dis [R + 1] f32 (16-byte padded) | {first edge, degree} [R]
+    constexpr int kIds = (R + 1) * 128, kDis = kIds + R * 16, kBounds = kDis + ((R + 1) * 4 + 15) / 16 * 16;
+    {
+        const float *src = blk + (int64_t)p.src0 * p.F;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int row = rwave + 8 * s + grp;
+            if (row < nn && !(DC_CHAIN_ABL & 8))
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1))) *)(src + (int64_t)row * p.ld),
+                    (void __attribute__((address_space(3))) *)(smem + (rwave + 8 * s) * 128), 16, 0, 0);
+        }
+    }
+    if (threadIdx.x < 8) *reinterpret_cast<float4 *>(smem + R * 128 + 16 * threadIdx.x) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.other), 0, p.cap * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.cap * 4, 0x00020000);
+    for (int r = threadIdx.x; r <= R; r += 1024) {              // one row per thread: bounds, dis, padded local ids
+        const bool live = r < nn;
+        const int b = live ? p.ptr[n0 + r] : 0, d = (live ? p.ptr[n0 + r + 1] : 0) - b;
+        const int din = live ? p.deg_ptr[n0 + r + 1] - p.deg_ptr[n0 + r] : 0;
+        *reinterpret_cast<float *>(smem + kDis + 4 * r) = inv_sqrt_count(din);
+        if (r == R) break;
+        *reinterpret_cast<int2 *>(smem + kBounds + 8 * r) = make_int2(b, d);
+        const u32x4 i0 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * b, 0, 0);
+        const u32x4 i1 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * b + 16, 0, 0);
+        const unsigned g[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+        unsigned l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                            // a neighbour outside the graph (flagged by the build)
+            const unsigned loc = g[j] - (unsigned)n0;           // must not leave the LDS tables: it reads the zeros
+            l[j] = (j < d && loc < (unsigned)R) ? loc : (unsigned)R;
+        }
+        *reinterpret_cast<uint4 *>(smem + kIds + 16 * r) =
+            make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): slice and tables have landed
+    lds_barrier();
+
+    const bool want_rm = p.rowmax != nullptr;
+    float pm[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        pm[s] = 0.f;
+        if (s < STEPS && want_rm && (p.rm_mode & 1))
+            pm[s] = chain_absmax(*reinterpret_cast<const float4 *>(smem + (rwave + 8 * s + grp) * 128 + 16 * sub));
+    }
+    const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned lbase = sbase + 16u * sub, dbase = sbase + kDis;
+    const unsigned gbase = lbase - (unsigned)n0 * 128u, zsub = lbase + R * 128u;    // global-id addressing of the tail path
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.slab + (int64_t)n0 * p.ld, 0, (int)((unsigned)nn * (unsigned)p.ld * 4u), 0x00020000);
+    const unsigned ldb = (unsigned)p.ld * 4u;
+    for (int h = 0; h < p.K; ++h) {
+        const unsigned dcol = (unsigned)((p.src0 + (h + 1) * p.dir) * p.F + slice * kChainCols + 4 * sub) * 4u;
+        float4 acc[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            int row = rwave + 8 * s + grp;
+            // (the tables never change, and hipcc knows: it would keep all 8 steps' entries - 56 registers - live across
+            // the hops and spill; an opaque row index keeps the three reads where they are)
+            asm volatile("" : "+v"(row));
+            const uint4 iv = *reinterpret_cast<const uint4 *>(smem + kIds + 16 * row);
+            const int2 bd = *reinterpret_cast<const int2 *>(smem + kBounds + 8 * row);
+            const float di = *reinterpret_cast<const float *>(smem + kDis + 4 * row);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!__any(bd.y > 6))
+                gcn_slots<6>(a, iv, di, lbase, dbase);
+            else if (!__any(bd.y > 7))
+                gcn_slots<7>(a, iv, di, lbase, dbase);
+            else {
+                gcn_slots<4, 0>(a, iv, di, lbase, dbase);        // (rare: two halves keep the registers of this path
+                gcn_slots<4, 4>(a, iv, di, lbase, dbase);        // below those of the common ones)
+                int pbeg = bd.x, rem = bd.y;
+                while (__any(rem > 8)) {                         // the tail of long rows: ids and weights from memory
+                    pbeg += 8, rem -= 8;
+                    Chunk n;
+                    load_chunk<true>(n, ro, rw, pbeg);
+                    chunk_slots<true, 4, 0, 0>(a, n, rem, gbase, zsub);
+                    if (__any(rem > 4)) chunk_slots<true, 4, 0, 4>(a, n, rem, gbase, zsub);
+                }
+            }
+            acc[s] = a;
+            pm[s] = fmaxf(pm[s], chain_absmax(a));
+            store_piece(a, rs, (unsigned)row * ldb + dcol);      // streams out while the next steps compute
+        }
+        if (h + 1 == p.K) break;
+        if (DC_CHAIN_ABL & 4) continue;
+        lds_barrier();
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+            *reinterpret_cast<float4 *>(smem + (rwave + 8 * s + grp) * 128 + 16 * sub) = acc[s];
+        lds_barrier();
+    }
+    if (want_rm) publish_rowmax(pm, sub, STEPS, rwave + 8 * sub + grp, nn, p.rowmax + n0);
+}
+
+template <int STEPS>
+static bool launch_chain_gcn_steps(unsigned grid, hipStream_t stream, const ChainParams &p) {
+    constexpr int R = 128 * STEPS;
+    constexpr size_t lds = (size_t)(R + 1) * 128 + (size_t)R * 16 + ((size_t)(R + 1) * 4 + 15) / 16 * 16 + (size_t)R * 8;
+    static_assert(lds <= 160 * 1024, "k_hop_chain_gcn: tables do not fit the LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain_gcn<STEPS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_hop_chain_gcn<STEPS>), dim3(grid), dim3(1024), lds, stream, p);
+    return true;
+}
+
+static bool launch_chain_gcn(int steps, unsigned grid, hipStream_t stream, const ChainParams &p) {
+    switch (steps) {
+    case 1: return launch_chain_gcn_steps<1>(grid, stream, p);
+    case 2: return launch_chain_gcn_steps<2>(grid, stream, p);
+    case 3: return launch_chain_gcn_steps<3>(grid, stream, p);
+    case 4: return launch_chain_gcn_steps<4>(grid, stream, p);
+    case 5: return launch_chain_gcn_steps<5>(grid, stream, p);
+    case 6: return launch_chain_gcn_steps<6>(grid, stream, p);
+    case 7: return launch_chain_gcn_steps<7>(grid, stream, p);
+    default: return launch_chain_gcn_steps<8>(grid, stream, p);
     }
 }
 
@@ -256,8 +484,8 @@ using namespace dc;
 
 extern "C" int64_t dc_hop_chain_max_nodes(void) { return 128 * kChainSteps; }
 
-extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, int64_t cap,
-                                const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
+extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
+                                int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
                                 int64_t F, int K, int src_block, int dir, float *rowmax, int mode,
                                 dc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -287,7 +515,8 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
             return check_launch("dc_hop_chain_f32 (memset)");
     }
     ChainParams p{};
-    p.ptr = ptr, p.other = other, p.w = w, p.slab = slab, p.ld = ld, p.rowmax = rowmax, p.cap = (int32_t)cap;
+    DC_REQUIRE(!deg_ptr || w, "dc_hop_chain_f32: deg_ptr describes the weights w - it cannot come without them");
+    p.ptr = ptr, p.other = other, p.w = w, p.deg_ptr = deg_ptr, p.slab = slab, p.ld = ld, p.rowmax = rowmax, p.cap = (int32_t)cap;
     p.F = (int)F, p.nslices = (int)(F / kChainCols), p.K = K, p.src0 = src_block, p.dir = dir, p.rm_mode = mode;
     for (int s0 = 0; s0 < nseg; s0 += kChainGraphs) {
         const int cnt = nseg - s0 < kChainGraphs ? nseg - s0 : kChainGraphs;
@@ -301,7 +530,9 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
         p.nseg = cnt;
         const int smax = (int)((big + 127) / 128);
         const unsigned grid = (unsigned)cnt * (unsigned)p.nslices;
-        const bool ok = w ? launch_chain<true>(smax, grid, stream, p) : launch_chain<false>(smax, grid, stream, p);
+        const bool ok = deg_ptr ? launch_chain_gcn(smax, grid, stream, p)
+                        : w     ? launch_chain<true>(smax, grid, stream, p)
+                                : launch_chain<false>(smax, grid, stream, p);
         DC_REQUIRE(ok, "dc_hop_chain_f32: cannot reserve the kernel's LDS");
     }
     return check_launch("dc_hop_chain_f32");

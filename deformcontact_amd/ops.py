@@ -226,14 +226,22 @@ def hop_chain_eligible(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: i
             and adj.ptr.numel() == slab.size(0) + 1)
 
 
+#: re-form gcn_norm weights from an LDS-resident degree table inside ``dc_hop_chain_f32`` (no vector-memory loads in its
+#: hop loop) instead of loading ``w``; same bits.  ``DC_HOP_CHAIN_GCN=0``: always load them.
+HOP_CHAIN_GCN = os.environ.get("DC_HOP_CHAIN_GCN", "1") != "0"
+
+
 def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weighted: bool = True,
               rowmax: Optional[torch.Tensor] = None, rowmax_mode: int = 0, src_block: int = 0, direction: int = 1) -> None:
     """``dc_hop_chain_f32``: blocks ``src_block + direction .. src_block + k * direction`` of ``slab`` from block
     ``src_block``, one launch (see ``hop_chain_eligible``)."""
     nptr, _, nseg = g._segments
     w = adj.w if weighted else None
+    # the adjacency's weights are gcn_norm's (graph.GraphIndex builds nothing else): tell the kernel so
+    deg = g.fwd.ptr if (HOP_CHAIN_GCN and w is not None and g.normalize and not g.self_loops) else None
     rc = _lib.lib().dc_hop_chain_f32(
-        adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None, adj.other.numel(),
+        adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+        deg.data_ptr() if deg is not None else None, adj.other.numel(),
         nptr, nseg, slab.data_ptr(), slab.stride(0), slab.size(0), f, k, int(src_block), int(direction),
         rowmax.data_ptr() if rowmax is not None else None, int(rowmax_mode), current_stream_ptr(slab.device))
     _lib.check(rc, "dc_hop_chain_f32")

@@ -219,11 +219,15 @@ int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
  * produced blocks of max |block[i, :]|, joined with block src_block's when mode & 1 and with the
  * value rowmax[i] already holds when mode & 2 (what K dc_spmm_f32_rowmax calls leave there).
  * `cap` = number of elements `other` / `w` hold (16-byte id / weight loads are range-checked
- * against it).  Needs F % 32 == 0, ld % 4 == 0, a 16-byte aligned slab and at most
+ * against it).  deg_ptr != NULL (int32 [N+1]) states that the weights are gcn_norm's without self
+ * loops, w[p] = d(source)^-1/2 * d(destination)^-1/2 with d(v) = deg_ptr[v+1] - deg_ptr[v] (the
+ * in-degree: ptr of the by-destination set, for BOTH sets of dc_graph_build*): the kernel then
+ * re-forms them from an LDS-resident table instead of loading them (same bits) and its hop loop
+ * is free of vector-memory loads.  Needs F % 32 == 0, ld % 4 == 0, a 16-byte aligned slab and at most
  * dc_hop_chain_max_nodes() (1024) nodes per graph; DC_EINVAL otherwise (use dc_spmm_f32). */
 int64_t dc_hop_chain_max_nodes(void);
-int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, int64_t cap,
-                     const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
+int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
+                     int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
                      int64_t F, int K, int src_block, int dir, float *rowmax, int mode,
                      dc_stream_t stream);
 

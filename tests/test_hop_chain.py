@@ -44,7 +44,9 @@ def reference_chain(adj, slab, f, k, rowmax, mode, weighted=True, src=0, directi
                 rowmax_mode=(mode if j == 0 else 2) if rowmax is not None else 0)
 
 
-def run_both(g, adj, n, f, k, mode, weighted=True, src=0, direction=1, with_rowmax=True, seed=0):
+def run_both(g, adj, n, f, k, mode, weighted=True, src=0, direction=1, with_rowmax=True, seed=0, gcn=True):
+    """``gcn``: let the kernel re-form the gcn_norm weights from its LDS degree table (the default for the adjacencies
+    ``GraphIndex`` builds) instead of loading ``w`` - the other kernel behind the same entry point."""
     torch.manual_seed(seed)
     nblk = k + 1
     a = ops._alloc_slab(n, nblk * f, DEV)
@@ -57,7 +59,11 @@ def run_both(g, adj, n, f, k, mode, weighted=True, src=0, direction=1, with_rowm
         rb = ra.clone()
     reference_chain(adj, a, f, k, ra, mode, weighted, src, direction)
     assert ops.hop_chain_eligible(g, adj, b, f, k)
-    ops.hop_chain(g, adj, b, f, k, weighted=weighted, rowmax=rb, rowmax_mode=mode, src_block=src, direction=direction)
+    keep, ops.HOP_CHAIN_GCN = ops.HOP_CHAIN_GCN, gcn
+    try:
+        ops.hop_chain(g, adj, b, f, k, weighted=weighted, rowmax=rb, rowmax_mode=mode, src_block=src, direction=direction)
+    finally:
+        ops.HOP_CHAIN_GCN = keep
     torch.cuda.synchronize()
     assert torch.equal(a, b), f"blocks differ: {(a != b).sum().item()} elements"
     if with_rowmax:
@@ -65,13 +71,14 @@ def run_both(g, adj, n, f, k, mode, weighted=True, src=0, direction=1, with_rowm
     return a
 
 
+@pytest.mark.parametrize("gcn", [True, False])
 @pytest.mark.parametrize("bwd", [False, True])
-def test_everyday_batch_chains_equal_three_hops_bitwise(bwd):
+def test_everyday_batch_chains_equal_three_hops_bitwise(bwd, gcn):
     rest, _, rig = synth.make_batch(8)
     for b in (rest, rig):
         g = GraphIndex(b.edge_index.to(DEV), b.x.shape[0], segments=b.segments())
         assert g._segments is not None
-        run_both(g, g.bwd if bwd else g.fwd, b.x.shape[0], 256, 3, 2 if bwd else 1)
+        run_both(g, g.bwd if bwd else g.fwd, b.x.shape[0], 256, 3, 2 if bwd else 1, gcn=gcn)
 
 
 @pytest.mark.parametrize("sizes,degs,f,k,hub", [
@@ -87,7 +94,8 @@ def test_ragged_batches_hubs_and_caps(sizes, degs, f, k, hub):
     g = GraphIndex(ei.to(DEV), n, segments=segs)
     assert g._segments is not None and g._seg_max_nodes == max(sizes)
     for adj, mode in ((g.fwd, 1), (g.bwd, 2), (g.fwd, 0), (g.bwd, 3)):
-        run_both(g, adj, n, f, k, mode, seed=mode)
+        for gcn in (True, False):
+            run_both(g, adj, n, f, k, mode, seed=mode, gcn=gcn)
     run_both(g, g.fwd, n, f, k, 0, with_rowmax=False)
     run_both(g, g.fwd, n, f, k, 1, weighted=False)
     run_both(g, g.bwd, n, f, k, 1, src=k, direction=-1)
@@ -101,6 +109,7 @@ def test_last_rows_of_the_edge_arrays_and_the_c_oracle():
     ei, segs = batch_of_graphs(sizes, degs, seed=5)
     n = segs[0][-1]
     g = GraphIndex(ei.to(DEV), n, segments=segs)
+    run_both(g, g.fwd, n, 32, 2, 1, gcn=False)
     slab = run_both(g, g.fwd, n, 32, 2, 1)
     ref = slab[:, :32].cpu().numpy().copy()
     w = hop_c.gcn_norm(ei.numpy(), n)
@@ -119,8 +128,9 @@ def test_c_abi_rejects_what_it_cannot_run():
         slab = ops._alloc_slab(n, 2 * 32, DEV).normal_()
         return g, slab, n, (ctypes.c_int64 * 3)(*segs[0])
 
-    def call(g, slab, n, nptr, f=32, k=1, src=0, direction=1):
-        return L.dc_hop_chain_f32(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr(), g.fwd.other.numel(),
+    def call(g, slab, n, nptr, f=32, k=1, src=0, direction=1, deg=False, w=True):
+        return L.dc_hop_chain_f32(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), g.fwd.w.data_ptr() if w else None,
+                                  g.fwd.ptr.data_ptr() if deg else None, g.fwd.other.numel(),
                                   nptr, 2, slab.data_ptr(), slab.stride(0), n, f, k, src, direction, None, 0,
                                   current_stream_ptr(slab.device))
     g, slab, n, nptr = setup((1025, 10))
@@ -132,6 +142,7 @@ def test_c_abi_rejects_what_it_cannot_run():
     assert call(g, slab, n, nptr, k=2) != 0                         # block 2 is outside the 2-block slab
     assert call(g, slab, n, nptr, src=1, direction=-1) == 0 and call(g, slab, n, nptr, src=0, direction=-1) != 0
     assert call(g, slab, n, (ctypes.c_int64 * 3)(0, 1024, n - 1)) != 0     # offsets must cover [0, N]
+    assert call(g, slab, n, nptr, deg=True) == 0 and call(g, slab, n, nptr, deg=True, w=False) != 0
     torch.cuda.synchronize()
 
 

@@ -20,25 +20,34 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def hop_sequence(dev, parts, merged: bool, f: int = 256):
+#: kernels the hop launches of a step run on: the per-hop gather kernel and the fused 3-hop chain (dc_hopchain.hip)
+HOP_KERNELS = ("k_spmm_wave", "k_hop_chain")
+
+
+def hop_sequence(dev, parts, merged: bool, f: int = 256, segments=None):
     """The F=256 hop launches of ONE encoder step in step order on step-shaped slabs - what `roofline` prices
-    and what the --pmc passes measure.  `parts` = [(edge_index, n), ...] (soft, rigid).  merged (the default
-    encoder path): ONE adjacency over both graphs, 3 forward hops on the merged layer-2 slab + 3 transposed
-    hops on the merged gradient slab = 6 launches; else the same chains per branch = 12 launches.
-    -> (fn, launches, compulsory bytes of all launches, gather-model bytes of all launches)."""
+    and what the --pmc passes measure.  `parts` = [(edge_index, n), ...] (soft, rigid); `segments` = the batches'
+    `Batch.segments()` (one per part, as the encoder passes them to `graph_index`): with them the default path runs
+    every 3-hop chain as ONE `dc_hop_chain_f32` launch (4 launches per step), without them hop by hop (12).
+    merged (opt-in encoder path): ONE adjacency over both graphs, 3 forward hops on the merged layer-2 slab + 3
+    transposed hops on the merged gradient slab = 6 launches.
+    -> (fn, launches, per-hop compulsory bytes of all hops, gather-model bytes of all hops)."""
     import torch
     from deformcontact_amd import ops
     from deformcontact_amd.graph import GraphIndex
-    seq, comp, gath = [], 0, 0
+    seq, comp, gath, launches = [], 0, 0, 0
     n_real = sum(n for _, n in parts)
     e_all = sum(int(ei.shape[1]) for ei, _ in parts)
+    segments = segments or [None] * len(parts)
     graphs = [(GraphIndex.from_parts(parts), n_real, e_all)] if merged else \
-        [(GraphIndex(ei, n), n, int(ei.shape[1])) for ei, n in parts]
+        [(GraphIndex(ei, n, segments=sg), n, int(ei.shape[1])) for (ei, n), sg in zip(parts, segments)]
     for g, n, e in graphs:
         for bwd in (False, True):
-            seq.append((g, ops._alloc_slab(g.num_nodes, 4 * f, dev).normal_(), torch.zeros(g.num_nodes, device=dev), bwd))
+            slab = ops._alloc_slab(g.num_nodes, 4 * f, dev).normal_()
+            seq.append((g, slab, torch.zeros(g.num_nodes, device=dev), bwd))
             comp += 3 * (e * 8 + n * (8 * f + 4))                   # rows of padding nodes are not counted
             gath += 3 * (e * (8 + 4 * f) + n * (4 * f + 4))
+            launches += 1 if ops.hop_chain_eligible(g, g.bwd if bwd else g.fwd, slab, f, 3) else 3
 
     def fn():
         for g, slab, rm, bwd in seq:             # forward / transposed chains of 3 hops + row maxima
@@ -47,7 +56,7 @@ def hop_sequence(dev, parts, merged: bool, f: int = 256):
                                  rowmax_has_block0=True)
             else:
                 ops.chained_hops(g, slab, f, 3, backward=False, rowmax=rm)
-    return fn, 3 * len(seq), comp, gath
+    return fn, launches, comp, gath
 
 
 def run():
@@ -57,7 +66,8 @@ def run():
     rest, _, rig = synth.make_batch(32)
     merged = os.environ.get("DC_MERGE_BRANCHES", "0") == "1"
     fn, _, _, _ = hop_sequence(dev, [(rest.edge_index.to(dev), rest.x.shape[0]),
-                                     (rig.edge_index.to(dev), rig.x.shape[0])], merged)
+                                     (rig.edge_index.to(dev), rig.x.shape[0])], merged,
+                               segments=None if merged else [rest.segments(), rig.segments()])
     for _ in range(10):                          # the launches bench.py prices, in the same order
         fn()
     torch.cuda.synchronize()
@@ -67,11 +77,12 @@ def parse(fetch_dir, write_dir):
     def mean_counter(d, name):
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if "k_spmm_wave" in r["Kernel_Name"] and r["Counter_Name"] == name]
+                if any(k in r["Kernel_Name"] for k in HOP_KERNELS) and r["Counter_Name"] == name]
         return sum(vals) / len(vals), len(vals)
     fetch_kb, nf = mean_counter(fetch_dir, "FETCH_SIZE")
     write_kb, nw = mean_counter(write_dir, "WRITE_SIZE")
-    out = {"kernel": "dc::k_spmm_wave<4,8,true>", "launches_averaged": [nf, nw],
+    out = {"kernel": "the step's F=256 hop launches (dc::k_hop_chain<true,STEPS> / dc::k_spmm_wave<4,8,true>)",
+           "launches_averaged": [nf, nw],
            "FETCH_SIZE_KiB_raw": round(fetch_kb, 1), "WRITE_SIZE_KiB": round(write_kb, 1),
            "correction": "FETCH_SIZE x2: gfx950 tallies 128-B requests of 16 B/lane reads at 64 B",
            "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024),
@@ -87,9 +98,13 @@ def parse_l2(d):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     acc = {}
     for r in csv.DictReader(open(f)):
-        if "k_spmm_wave" in r["Kernel_Name"]:
-            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    print(json.dumps({k: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for k, v in acc.items()}, indent=1))
+        if any(k in r["Kernel_Name"] for k in HOP_KERNELS):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            e = acc.setdefault(name, {})
+            e.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            e.setdefault("_dur_us_profiled", []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print(json.dumps({n: {k: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for k, v in e.items()}
+                      for n, e in acc.items()}, indent=1))
 
 
 if __name__ == "__main__":
