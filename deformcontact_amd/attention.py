@@ -83,6 +83,19 @@ FLASH_D = 256
 FLASH_BWD = os.environ.get("DC_ATTN_FLASH_BWD", "1") != "0"
 #: above this many bytes of P + dS the backward falls back to the blocked form
 FLASH_BWD_MAX_BYTES = int(float(os.environ.get("DC_ATTN_FLASH_BWD_MAX_GB", "16")) * (1 << 30))
+
+
+def _flash_bwd_budget(dev) -> int:
+    """Bytes the P + dS matrices of the one-launch backward may take: the configured cap, and never more than half
+    of what the device (driver + this process' caching allocator) can still hand out - beyond it the blocked backward
+    (1.4 GiB at batch 32) runs instead of an out-of-memory error.  Under stream capture the query is
+    skipped (it would be baked in anyway): the cap alone decides."""
+    if torch.cuda.is_current_stream_capturing():
+        return FLASH_BWD_MAX_BYTES
+    free, _ = torch.cuda.mem_get_info(dev)
+    st = torch.cuda.memory_stats(dev)
+    cached = st.get("reserved_bytes.all.current", 0) - st.get("allocated_bytes.all.current", 0)
+    return min(FLASH_BWD_MAX_BYTES, (free + max(cached, 0)) // 2)
 #: one sweep instead of two in ``dc_attn_flash_ds``: dS' is formed with delta = rowsum(dO * O), the kernel returns by how
 #: much the consistent delta differs (eps), and dK - the product that is sensitive to rows of dS not summing to zero -
 #: takes dS' - eps o P at load time (``dc_tag_linear_bwd_dw_h2_corr``).  ``DC_ATTN_FLASH_BWD_SINGLE=0``: two sweeps.
@@ -170,11 +183,10 @@ class _AttnCoreFn(torch.autograd.Function):
         ones = torch.ones(bq, dtype=torch.float32, device=dev)     # softmax weights are <= 1
         o = torch.empty((nsp, dv), dtype=torch.float32, device=dev)
         lse = torch.empty(nsp, dtype=torch.float32, device=dev)
-        flash_ok = FLASH and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
-        s = None if flash_ok else torch.empty((bq, nrp), dtype=torch.float32, device=dev)
-        ws_o = None if flash_ok else _splitk_ws(L, bq, nrp, dv, dev)
-        vt = vp.t().contiguous() if EXACT_ALL else None
         flash = FLASH and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
+        s = None if flash else torch.empty((bq, nrp), dtype=torch.float32, device=dev)
+        ws_o = None if flash else _splitk_ws(L, bq, nrp, dv, dev)
+        vt = vp.t().contiguous() if EXACT_ALL else None
         if flash:
             kuns = torch.empty_like(kmax)
             _lib.check(L.dc_attn_flash_prep(vtimg.data_ptr(), dv, nrp, kmax.data_ptr(), kuns.data_ptr(), st),
@@ -212,7 +224,7 @@ class _AttnCoreFn(torch.autograd.Function):
         gop = _pad_rows(go.contiguous(), nsp)
         gomax = _rowabsmax(L, gop, st)
         if (FLASH_BWD and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
-                and DELTA_IN_KERNEL and 8 * nsp * nrp <= FLASH_BWD_MAX_BYTES):
+                and DELTA_IN_KERNEL and 8 * nsp * nrp <= _flash_bwd_budget(dev)):
             return _backward_flash(L, st, dev, qp, kp, gop, o, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax,
                                    ns, nr, d, dv)
         delta = (gop * o).sum(dim=1)

@@ -493,6 +493,7 @@ k_attn_flash_ds(FlashDsParams p) {
     constexpr float kLog2e = 1.4426950408889634f;
     const int nt1 = (int)((p.nr + kFlT - 1) / kFlT), nt2 = (int)(p.nrp / kFlT);
     float acc_pd = 0.f, acc_p = 0.f, delta = p.delta_in ? p.delta_in[qrow] : 0.f, dsm = 0.f;
+    const bool full_tile = q0 + 32 <= p.ns;              // all 32 queries of this wave exist (q0: blockIdx + readfirstlane)
     for (int sweep = p.delta_in ? 1 : 0; sweep < 2; ++sweep) {
         const int nt = sweep ? nt2 : nt1;
 #pragma unroll
@@ -548,7 +549,7 @@ k_attn_flash_ds(FlashDsParams p) {
                 // the two tiles out through the wave's transpose region: [query][key] rows of 32 floats (+ pad), then
                 // 8 lanes per row write one 128-byte segment per query
                 const int64_t col0 = (int64_t)t * kFlT + 4 * (lane & 7);
-                const bool full = q0 + 32 <= p.ns;      // wave-uniform: no per-row predicates on whole tiles
+                const bool full = full_tile;            // wave-uniform: no per-row predicates on whole tiles
 #pragma unroll
                 for (int mtx = 0; mtx < 2; ++mtx) {
                     const float *v = mtx ? dsv : pv;
@@ -575,8 +576,10 @@ k_attn_flash_ds(FlashDsParams p) {
             }
             if (more) load_us(kunsc, (int64_t)(t + 1) * kFlT, uk0, uk1);
             // the 16 DMA instructions of this iteration must have landed; in sweep 2 the 8 store instructions issued
-            // after them may stay in flight (VMEM operations retire in order)
-            if (sweep) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+            // after them may stay in flight (VMEM operations retire in order) - but only a wave whose 32 queries all
+            // exist issues exactly 8: in a ragged last tile a predicated store with no live lane is branched around,
+            // and vmcnt(8) would then leave DMA pieces of V(t+1) / K(t+1) in flight past the barrier
+            if (sweep && full_tile) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
             else __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_s_barrier();
         }

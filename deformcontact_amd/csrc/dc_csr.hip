@@ -779,10 +779,15 @@ extern "C" int dc_graph_build_segmented(const int64_t *edge_index, int64_t E, in
     for (int i = 0; i < nseg; ++i) {
         const int64_t dn = node_ptr_host[i + 1] - node_ptr_host[i], de = edge_ptr_host[i + 1] - edge_ptr_host[i];
         DC_REQUIRE(dn >= 0 && de >= 0, "dc_graph_build_segmented: offsets of graph %d descend", i);
+        DC_REQUIRE(dn > 0 || de == 0, "dc_graph_build_segmented: graph %d has %lld edges but no node: use dc_graph_build",
+                   i, (long long)de);
         DC_REQUIRE(dn <= kSegNodes && de <= kSegEdges,
                    "dc_graph_build_segmented: graph %d (%lld nodes, %lld edges) exceeds the per-graph caps (%d / %d): "
                    "use dc_graph_build", i, (long long)dn, (long long)de, kSegNodes, kSegEdges);
     }
+    // NOTE: the kernel only ORs flags into *status (workgroups of one launch cannot order a clear before their ORs, and a
+    // memset node per build would sit on the critical path of every training step): the word is STICKY across rebuilds
+    // into the same buffers until the caller clears it (GraphIndex.validate() does after reporting) - see the header
     SegBuild b{};
     b.src = edge_index, b.dst = edge_index + E, b.E = E, b.N = N, b.status = status;
     b.ptr[0] = ptr_f, b.other[0] = other_f, b.perm[0] = perm_f, b.w[0] = w_f;

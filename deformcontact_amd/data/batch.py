@@ -130,8 +130,10 @@ class Batch(Data):
 
     def __setattr__(self, name, value):
         # a replaced edge_index (radius graph, re-meshing) no longer follows the recorded layout
-        if name == "edge_index" and "_segments" in self.__dict__:
-            del self.__dict__["_segments"]
+        # - and what was known about its equality with another batch's edges (train.losses picks the fused loss by it)
+        if name == "edge_index":
+            for k in ("_segments", "_dc_edges_equal", "_dc_cloned_edges"):
+                self.__dict__.pop(k, None)
         object.__setattr__(self, name, value)
 
     def assume_segments(self, segments) -> None:

@@ -220,7 +220,7 @@ class GraphIndex:
     def validate(self) -> None:
         """Raise if any endpoint was outside ``[0, num_nodes)`` (synchronises)."""
         if int(self._status.item()) != 0:
-            self._status.zero_()          # (the segmented build only ORs into the word)
+            self._status.zero_()
             raise IndexError(
                 f"edge_index contains node ids outside [0, {self.num_nodes}) "
                 "(PyG/ATen would raise an index error here)")
@@ -282,8 +282,8 @@ def _segment_arrays(segments, num_nodes: int, num_edges: int, device):
         return None
     for i in range(nseg):
         dn, de = nodes[i + 1] - nodes[i], edges[i + 1] - edges[i]
-        if not (0 <= dn <= SEG_MAX_NODES and 0 <= de <= SEG_MAX_EDGES):
-            return None
+        if not (0 <= dn <= SEG_MAX_NODES and 0 <= de <= SEG_MAX_EDGES) or (dn == 0 and de > 0):
+            return None                      # (edges without nodes: the global pipeline flags them)
     import ctypes
     return ((ctypes.c_int64 * (nseg + 1))(*nodes), (ctypes.c_int64 * (nseg + 1))(*edges), nseg)
 
@@ -497,3 +497,4 @@ def register(edge_index: torch.Tensor, g: GraphIndex) -> None:
 
 def clear_cache() -> None:
     _CACHE.clear()
+    _PENDING_VALIDATION.clear()          # (DC_VALIDATE=1 graphs of captures that were never replayed)

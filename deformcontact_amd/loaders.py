@@ -87,7 +87,8 @@ def mark_edge_equality(rest, deff) -> None:
                                    (not a.is_cuda and not b.is_cuda and bool(torch.equal(a, b))))
     if a.is_cuda or b.is_cuda:
         same = a.shape == b.shape and a.data_ptr() == b.data_ptr()     # never read device memory here
-    deff.__dict__["_dc_edges_equal"] = (bool(same),)
+    # the mark names the tensors it was decided on (address + version): train._edges_known_equal re-checks them
+    deff.__dict__["_dc_edges_equal"] = (bool(same), b.data_ptr(), b._version, a.shape)
 
 
 def to_batches(collated, device=None) -> Tuple[Batch, Batch, Batch]:

@@ -52,7 +52,13 @@ def _edges_known_equal(batch, ei: torch.Tensor) -> bool:
     if src is not None and src[0] is ei and src[1] == ei._version and other.shape == ei.shape:
         return True
     mark = getattr(batch, "_dc_edges_equal", None)
-    return bool(mark is not None and mark[0] and other.shape == ei.shape)
+    if mark is None or not mark[0] or other.shape != ei.shape:
+        return False
+    # a mark made before .to(device) cannot name the device copy; one that does name a tensor must still match it
+    # (an in-place rewrite bumps the version, a replaced edge_index drops the mark in Batch.__setattr__)
+    if len(mark) >= 4 and mark[1] == other.data_ptr():
+        return mark[2] == other._version and tuple(mark[3]) == tuple(other.shape)
+    return True
 
 
 def losses(model, rest, deff, rig, lambda_gradient: float = 1.0) -> Dict[str, torch.Tensor]:

@@ -95,7 +95,7 @@ def test_flash_forward_is_deterministic_and_handles_ragged_query_tiles(monkeypat
     assert np.array_equal(a[100:231], c)
 
 
-@pytest.mark.parametrize("ns,nr", [(300, 130), (1, 1), (1000, 777), (4096, 3048), (515, 70)])
+@pytest.mark.parametrize("ns,nr", [(300, 130), (1, 1), (1000, 777), (4096, 3048), (515, 70), (5000, 130), (33, 64)])
 def test_flash_backward_equals_blocked_backward_to_rounding_and_float64(ns, nr, monkeypatch):
     """Same forward (flash), backward through ``dc_attn_flash_ds`` + three large GEMMs vs the blocked six-launch form."""
     torch.manual_seed(3 * ns + nr)

@@ -287,3 +287,29 @@ def test_segment_layout_validation_is_host_side():
     assert caps is None
     assert graph._segment_arrays(((0, 4), (0, graph.SEG_MAX_EDGES + 1)), 4, graph.SEG_MAX_EDGES + 1, dev) is None
     assert graph._segment_arrays(((0, 4), (0, 0)), 4, 0, dev) is None          # no edges: nothing to sort
+    # a graph with edges but no node: the one-launch build would index uninitialised LDS counters
+    assert graph._segment_arrays(((0, 0, 8), (0, 3, 16)), 8, 16, dev) is None
+    assert graph._segment_arrays(((0, 0, 8), (0, 0, 16)), 8, 16, dev) is not None       # an EMPTY graph is fine
+
+
+def test_edge_equality_marks_do_not_outlive_the_edges_they_describe():
+    """``train.losses`` takes the fused loss kernel only when the deformed batch's edges are KNOWN (on the host) to equal
+    the rest batch's (``loaders.mark_edge_equality``, ``Batch.clone``); replacing or rewriting ``edge_index`` must drop
+    that knowledge - the reference's ``models/losses.py:12-13`` uses each batch's own edges."""
+    import torch
+    from deformcontact_amd import loaders, train
+    from deformcontact_amd.data import Batch, Data
+    gs = [Data(x=torch.zeros(n, 2), pos=torch.zeros(n, 3), edge_index=torch.randint(0, n, (2, 6))) for n in (5, 4)]
+    rest, deff = Batch.from_data_list(gs), Batch.from_data_list([g.clone() for g in gs])
+    loaders.mark_edge_equality(rest, deff)
+    assert train._edges_known_equal(deff, rest.edge_index)
+    pred = rest.clone()
+    assert train._edges_known_equal(pred, rest.edge_index)
+    deff.edge_index = deff.edge_index.flip(1)                    # re-meshed: the mark goes with the old tensor
+    assert not train._edges_known_equal(deff, rest.edge_index)
+    pred.edge_index = pred.edge_index.clone()
+    assert "_dc_cloned_edges" not in pred.__dict__ and not train._edges_known_equal(pred, rest.edge_index)
+    deff2 = Batch.from_data_list([g.clone() for g in gs])
+    loaders.mark_edge_equality(rest, deff2)
+    deff2.edge_index.add_(0)                                     # rewritten in place: the version the mark names is gone
+    assert not train._edges_known_equal(deff2, rest.edge_index)

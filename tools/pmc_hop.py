@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Run ONLY the F=256 hop launches bench.py prices in its `roofline` object (the hop launches of a B=32
-step in step order: forward and transposed chains - 6 launches over the merged adjacency of both
-branches, or 12 per-branch launches with DC_MERGE_BRANCHES=0), so rocprofv3 --pmc passes can attribute
-HBM traffic to dc::k_spmm_wave.
+"""Run ONLY the launches that perform the F=256 hops of a B=32 step, in step order - what bench.py prices in its
+`roofline` object: by default 4 `dc_hop_chain_f32` launches (forward and transposed 3-hop chain of each branch;
+DC_HOP_CHAIN=0: 12 `dc_spmm_f32_rowmax` launches), with DC_MERGE_BRANCHES=1 (opt-in encoder path) 6 hop launches over
+the merged adjacency - so that rocprofv3 --pmc passes can attribute HBM traffic to dc::k_hop_chain* / dc::k_spmm_wave.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 tools/pmc_hop.py
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d out/write -- python3 tools/pmc_hop.py
