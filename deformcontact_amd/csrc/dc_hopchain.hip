@@ -324,40 +324,45 @@ k_hop_chain_gcn(ChainParams p) {
     float *blk = p.slab + (int64_t)n0 * p.ld + slice * kChainCols + 4 * sub;
     // LDS: slice [R][128 B] | zeros [128 B] | ids [R][8] u16 | dis [R + 1] f32 (16-byte padded) | {first edge, degree} [R]
     constexpr int kIds = (R + 1) * 128, kDis = kIds + R * 16, kBounds = kDis + ((R + 1) * 4 + 15) / 16 * 16;
-    {
-        const float *src = blk + (int64_t)p.src0 * p.F;
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int row = rwave + 8 * s + grp;
-            if (row < nn && !(DC_CHAIN_ABL & 8))
-                __builtin_amdgcn_global_load_lds(
-                    (const void __attribute__((address_space(1))) *)(src + (int64_t)row * p.ld),
-                    (void __attribute__((address_space(3))) *)(smem + (rwave + 8 * s) * 128), 16, 0, 0);
-        }
-    }
-    if (threadIdx.x < 8) *reinterpret_cast<float4 *>(smem + R * 128 + 16 * threadIdx.x) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // prologue, by wave role: waves 8-15 issue ALL the LDS-DMA of the slice (one instruction = 8 rows x 128 B, contiguous
+    // in LDS), waves 0-7 build the tables.  hipcc makes a wave with LDS-DMA in flight wait for vmcnt(0) before each of
+    // its own LDS accesses: with both jobs in every wave the tables' loads were only issued once the slice had landed.
     const __amdgpu_buffer_rsrc_t ro =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.other), 0, p.cap * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.cap * 4, 0x00020000);
-    for (int r = threadIdx.x; r <= R; r += 1024) {              // one row per thread: bounds, dis, padded local ids
-        const bool live = r < nn;
-        const int b = live ? p.ptr[n0 + r] : 0, d = (live ? p.ptr[n0 + r + 1] : 0) - b;
-        const int din = live ? p.deg_ptr[n0 + r + 1] - p.deg_ptr[n0 + r] : 0;
-        *reinterpret_cast<float *>(smem + kDis + 4 * r) = inv_sqrt_count(din);
-        if (r == R) break;
-        *reinterpret_cast<int2 *>(smem + kBounds + 8 * r) = make_int2(b, d);
-        const u32x4 i0 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * b, 0, 0);
-        const u32x4 i1 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * b + 16, 0, 0);
-        const unsigned g[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-        unsigned l[8];
+    if (wid >= 8) {
+        const float *src = blk + (int64_t)p.src0 * p.F;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                            // a neighbour outside the graph (flagged by the build)
-            const unsigned loc = g[j] - (unsigned)n0;           // must not leave the LDS tables: it reads the zeros
-            l[j] = (j < d && loc < (unsigned)R) ? loc : (unsigned)R;
+        for (int s = 0; s < 2 * STEPS; ++s) {
+            const int r0 = (wid - 8) * 16 * STEPS + 8 * s;      // the rows of waves 2 (wid - 8) and 2 (wid - 8) + 1
+            if (r0 + grp < nn && !(DC_CHAIN_ABL & 8))
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1))) *)(src + (int64_t)(r0 + grp) * p.ld),
+                    (void __attribute__((address_space(3))) *)(smem + r0 * 128), 16, 0, 0);
         }
-        *reinterpret_cast<uint4 *>(smem + kIds + 16 * r) =
-            make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
+    } else {
+        if (threadIdx.x < 8)
+            *reinterpret_cast<float4 *>(smem + R * 128 + 16 * threadIdx.x) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = threadIdx.x; r <= R; r += 512) {           // bounds, dis, padded local ids of one row
+            const bool live = r < nn;
+            const int b = live ? p.ptr[n0 + r] : 0, d = (live ? p.ptr[n0 + r + 1] : 0) - b;
+            const int din = live ? p.deg_ptr[n0 + r + 1] - p.deg_ptr[n0 + r] : 0;
+            *reinterpret_cast<float *>(smem + kDis + 4 * r) = inv_sqrt_count(din);
+            if (r == R) break;
+            *reinterpret_cast<int2 *>(smem + kBounds + 8 * r) = make_int2(b, d);
+            const u32x4 i0 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * b, 0, 0);
+            const u32x4 i1 = __builtin_amdgcn_raw_buffer_load_b128(ro, 4 * b + 16, 0, 0);
+            const unsigned g[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+            unsigned l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                        // a neighbour outside the graph (flagged by the build)
+                const unsigned loc = g[j] - (unsigned)n0;       // must not leave the LDS tables: it reads the zeros
+                l[j] = (j < d && loc < (unsigned)R) ? loc : (unsigned)R;
+            }
+            *reinterpret_cast<uint4 *>(smem + kIds + 16 * r) =
+                make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): slice and tables have landed
     lds_barrier();

@@ -195,11 +195,12 @@ class CrossAttention(nn.Module):
         self.attention_heads = nn.ModuleList(
             nn.Linear(feature_dim, feature_dim) for _ in range(num_heads))
 
-    #: blocked attention on the library's dense kernels (``attention.attention_core``): the
-    #: ``[N_s, N_r]`` score / weight matrices of the reference exist only per block of soft rows.
-    #: "auto" (default) uses it once a score matrix would exceed ``fused_min_scores`` elements
-    #: (batch 32: 8e8 -> 49.8 ms / 1.4 GiB per step instead of 51.1 ms / 15.6 GiB; at the shipped
-    #: batch 4 the materialising formula on stock PyTorch has fewer launches and is faster);
+    #: the library's attention (``attention.attention_core``: at d = 256 the flash-style forward ``dc_attn_flash_fwd``,
+    #: scores never leave the compute unit, and the ``dc_attn_flash_ds`` backward; other widths the blocked form) -
+    #: the ``[N_s, N_r]`` score / weight matrices of the reference are not materialised in the forward.
+    #: "auto" (default) uses it once a score matrix would exceed ``fused_min_scores`` elements (batch 32: 8e8 scores,
+    #: whole step 24 - 25 ms against 51 ms / 15.6 GiB with the materialising formula on stock PyTorch, DESIGN.md 4.6;
+    #: below the threshold - the shipped batch 4 - the materialising formula has fewer launches and is faster);
     #: ``DC_FUSED_ATTN=1`` / ``0`` force it on / off.
     fused = os.environ.get("DC_FUSED_ATTN", "auto")
     fused_min_scores = 1 << 26

@@ -34,3 +34,29 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the parity distances the run collected (tests/helpers.PARITY_LOG) next to the other GPU-box outputs:
+    gpurun_out/parity_distances.json (or $DC_PARITY_LOG) - one record per compared tensor, plus a summary."""
+    try:
+        from tests import helpers
+    except Exception:
+        return
+    log = helpers.PARITY_LOG
+    if not log:
+        return
+    import json
+    path = os.environ.get("DC_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_distances.json"))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    ds = [r["hip_vs_fp32_oracle"] for r in log if r["hip_vs_fp32_oracle"] is not None]
+    fired = [r for r in log if r["float64_widening_fired"]]
+    summary = {"comparisons": len(log), "float64_widening_fired": len(fired),
+               "worst_hip_vs_fp32_oracle": max(ds) if ds else None,
+               "worst_hip_vs_fp32_oracle_without_widening": max((r["hip_vs_fp32_oracle"] for r in log
+                                                                  if not r["float64_widening_fired"]
+                                                                  and r["hip_vs_fp32_oracle"] is not None), default=None),
+               "worst_hip_vs_float64_where_widened": max((r["hip_vs_float64"] for r in fired), default=None),
+               "tests": len({r["test"] for r in log})}
+    with open(path, "w") as f:
+        json.dump({"summary": summary, "widened": fired, "all": log}, f, indent=1)
