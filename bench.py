@@ -82,6 +82,8 @@ def parse():
                     help="skip the extra lines with the GCNConv / GATConv encoders on the same batch")
     ap.add_argument("--no-radius100k", action="store_true",
                     help="leave the radius100k extra out of the default line")
+    ap.add_argument("--graph-tail", action="store_true",
+                    help="N > 1: capture the gradient all-reduce + Adam inside the step's hipGraph (default: eager after it)")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="batches rotated through the timed steps (each step sees a new edge_index)")
     return ap.parse_args()
@@ -939,7 +941,10 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
-    tail_in_graph = world == 1
+    # N > 1: the collective stays OUTSIDE the captured graph by default (the 2-rank tests cover exactly this form);
+    # --graph-tail captures all-reduce + Adam with the step (RCCL collectives are capturable; falls back to eager if
+    # the capture fails) - opt-in because it cannot be exercised on the one-GPU test box
+    tail_in_graph = world == 1 or bool(args.graph_tail)
 
     def make_mode(mode: str):
         """-> step(i).  serial: every step loads a new batch into the input buffers and the captured
@@ -1057,7 +1062,28 @@ def main():
     if world > 1:
         torch.cuda.synchronize()
         us = sorted(a.elapsed_time(b) * 1e3 for a, b in ar_events[-max(args.steps, 1):])
+        # which physical devices took part: every rank reports the device it ran on (UUID where the runtime exposes
+        # one, else PCI location), all-gathered - the driver can check that N ranks mean N distinct GPUs
+        props = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(props, "uuid", "") or "")
+        if not ident or set(ident.replace("-", "")) <= {"0"}:
+            ident = "pci:%s:%s:%s" % tuple(getattr(props, k, "?") for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": ident, "name": props.name,
+                "host": os.uname().nodename}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        # host-side cost of the eager tail (all-reduce + Adam launched from Python after every graph replay)
+        th0 = time.perf_counter()
+        for _ in range(20):
+            tail()
+        tail_host_us = (time.perf_counter() - th0) / 20 * 1e6
+        torch.cuda.synchronize()
         out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "ranks_seen": seen,
+                       "distinct_devices": len({(r["host"], r["device"]) for r in seen}),
+                       "tail": "eager after the replayed fwd+bwd graph (all_reduce + dc_adam_flat: 2 launches)"
+                               if not tail_in_graph else "inside the step's hipGraph",
+                       "tail_host_us_per_step": round(tail_host_us, 1),
                        "allreduce_bytes": int(bucket.flat.numel() * bucket.flat.element_size()),
                        "allreduce_us": round(us[len(us) // 2], 1) if us else None,
                        "allreduce_us_max": round(us[-1], 1) if us else None,

@@ -62,6 +62,8 @@ _SIGNATURES = {
                                          POINTER(c_int64), POINTER(c_int64), c_int64, POINTER(_vp),
                                          POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp, _vp, _vp]),
     "dc_generic_dense_launches": (c_int64, [c_int]),
+    "dc_kernel_trace": (None, [c_int]),
+    "dc_kernel_trace_dump": (c_int64, [c_char_p, c_int64]),
     "dc_hash_i64": (c_int, [_vp, c_int64, _vp, _vp]),
     "dc_morton_codes": (c_int, [_vp, c_int64, c_int64, POINTER(c_float), POINTER(c_float), _vp, _vp]),
     "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
@@ -115,6 +117,7 @@ _SIGNATURES = {
     "dc_tag_linear_fwd_h2p_exp": (c_int, [_vp, c_int64, _vp, _vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp, _vp,
                                           c_int64, _vp]),
     "dc_tag_weight_prep": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "dc_tag_weight_prep_zero": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp, _vp, _vp, _vp, c_int64, _vp]),
     "dc_rowabsmax_f32": (c_int, [_vp, c_int64, c_int64, c_int64, _vp, _vp]),
     "dc_tag_weight_rowmax": (c_int, [POINTER(_vp), c_int, c_int64, c_int64, _vp, _vp]),
     "dc_spmm_f32_rowmax": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
@@ -168,6 +171,23 @@ def check(rc: int, what: str) -> None:
         msg = lib().dc_last_error()
         raise DeformContactLibraryError(
             f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def kernel_trace(on: bool) -> None:
+    """Start (clearing the log) / stop the library's launch log (``dc_kernel_trace``)."""
+    lib().dc_kernel_trace(1 if on else 0)
+
+
+def kernel_trace_counts() -> dict:
+    """``{kernel name: launches}`` recorded since ``kernel_trace(True)``."""
+    n = int(lib().dc_kernel_trace_dump(None, 0))
+    buf = ctypes.create_string_buffer(n + 1)
+    lib().dc_kernel_trace_dump(buf, n + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, _, cnt = line.rpartition(" ")
+        out[name] = int(cnt)
+    return out
 
 
 def exported_names():

@@ -218,13 +218,13 @@ extern "C" int dc_attn_softmax_rows(float *s, int64_t ld, int64_t rows, int64_t 
     const dim3 gr((unsigned)rows), bl(256);
     hipStream_t hs = (hipStream_t)stream;
     if (attn_vec_ok(s, nullptr, ld, npad) && npad <= 32 * 1024) {
-        if (npad <= 8 * 1024) hipLaunchKernelGGL((k_attn_softmax_rows_reg<8>), gr, bl, 0, hs, s, ld, n, npad, lse);
-        else if (npad <= 16 * 1024) hipLaunchKernelGGL((k_attn_softmax_rows_reg<16>), gr, bl, 0, hs, s, ld, n, npad, lse);
-        else if (npad <= 24 * 1024) hipLaunchKernelGGL((k_attn_softmax_rows_reg<24>), gr, bl, 0, hs, s, ld, n, npad, lse);
-        else hipLaunchKernelGGL((k_attn_softmax_rows_reg<32>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        if (npad <= 8 * 1024) DC_LAUNCH((k_attn_softmax_rows_reg<8>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        else if (npad <= 16 * 1024) DC_LAUNCH((k_attn_softmax_rows_reg<16>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        else if (npad <= 24 * 1024) DC_LAUNCH((k_attn_softmax_rows_reg<24>), gr, bl, 0, hs, s, ld, n, npad, lse);
+        else DC_LAUNCH((k_attn_softmax_rows_reg<32>), gr, bl, 0, hs, s, ld, n, npad, lse);
         return check_launch("dc_attn_softmax_rows");
     }
-    hipLaunchKernelGGL(k_attn_softmax_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld,
+    DC_LAUNCH(k_attn_softmax_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld,
                        n, npad, lse);
     return check_launch("dc_attn_softmax_rows");
 }
@@ -234,7 +234,7 @@ extern "C" int dc_attn_exp_rows(float *s, int64_t ld, int64_t rows, int64_t n, i
     if (int rc = attn_check("dc_attn_exp_rows", s, ld, rows, n, npad)) return rc;
     if (rows == 0) return DC_OK;
     DC_REQUIRE(lse, "dc_attn_exp_rows: null lse");
-    hipLaunchKernelGGL(k_attn_exp_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld, n,
+    DC_LAUNCH(k_attn_exp_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld, n,
                        npad, lse);
     return check_launch("dc_attn_exp_rows");
 }
@@ -247,12 +247,12 @@ extern "C" int dc_attn_ds_rows(const float *p, float *dp, int64_t ld, int64_t ro
     if (!delta && attn_vec_ok(p, dp, ld, npad) && npad <= 24 * 1024) {
         const dim3 gr((unsigned)rows), bl(256);
         hipStream_t hs = (hipStream_t)stream;
-        if (npad <= 8 * 1024) hipLaunchKernelGGL((k_attn_ds_rows_reg<8>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
-        else if (npad <= 16 * 1024) hipLaunchKernelGGL((k_attn_ds_rows_reg<16>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
-        else hipLaunchKernelGGL((k_attn_ds_rows_reg<24>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
+        if (npad <= 8 * 1024) DC_LAUNCH((k_attn_ds_rows_reg<8>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
+        else if (npad <= 16 * 1024) DC_LAUNCH((k_attn_ds_rows_reg<16>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
+        else DC_LAUNCH((k_attn_ds_rows_reg<24>), gr, bl, 0, hs, p, dp, ld, npad, rowmax);
         return check_launch("dc_attn_ds_rows");
     }
-    hipLaunchKernelGGL(k_attn_ds_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, ld,
+    DC_LAUNCH(k_attn_ds_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, ld,
                        npad, delta, rowmax);
     return check_launch("dc_attn_ds_rows");
 }

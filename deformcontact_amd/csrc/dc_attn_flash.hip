@@ -625,12 +625,12 @@ extern "C" int dc_attn_flash_prep(void *vt_image, int64_t dv, int64_t nr_padded,
     if (nchunks > 0) {
         DC_REQUIRE(vt_image && ((uintptr_t)vt_image & 15) == 0, "dc_attn_flash_prep: null or misaligned image");
         const int64_t nthreads = nchunks / 4;
-        hipLaunchKernelGGL(k_attn_flash_vt_image, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
+        DC_LAUNCH(k_attn_flash_vt_image, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, (fl_u32x2 *)vt_image, nchunks);
     }
     if (nr_padded > 0) {
         DC_REQUIRE(k_rowmax && k_unscale, "dc_attn_flash_prep: null key maxima / output");
-        hipLaunchKernelGGL(k_attn_flash_unscale, dim3((unsigned)((nr_padded + 255) / 256)), dim3(256), 0,
+        DC_LAUNCH(k_attn_flash_unscale, dim3((unsigned)((nr_padded + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, k_rowmax, k_unscale, nr_padded);
     }
     return check_launch("dc_attn_flash_prep");
@@ -652,7 +652,7 @@ extern "C" int dc_attn_flash_fwd(const float *q, int64_t ldq, const float *q_row
     DC_REQUIRE((ns + kFlQ - 1) / kFlQ < (int64_t)INT32_MAX, "dc_attn_flash_fwd: too many query tiles");
     FlashParams p{q, ldq, q_rowmax, (const char *)k_image, k_unscale, (const char *)vt_image, vt_rowmax,
                   ns, nr, nr_padded, o, ldo, lse};
-    hipLaunchKernelGGL(k_attn_flash_fwd, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0,
+    DC_LAUNCH(k_attn_flash_fwd, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0,
                        (hipStream_t)stream, p);
     return check_launch("dc_attn_flash_fwd");
 }
@@ -677,6 +677,6 @@ extern "C" int dc_attn_flash_ds(const float *q, int64_t ldq, const float *q_rowm
     DC_REQUIRE((ns + kFlQ - 1) / kFlQ < (int64_t)INT32_MAX, "dc_attn_flash_ds: too many query tiles");
     FlashDsParams p{q, ldq, q_rowmax, go, ldgo, go_rowmax, (const char *)k_image, k_unscale, (const char *)v_image,
                     v_unscale, lse, ns, nr, nr_padded, p_out, ds_out, ldp, ds_rowmax, delta_in, eps_out};
-    hipLaunchKernelGGL(k_attn_flash_ds, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0, (hipStream_t)stream, p);
+    DC_LAUNCH(k_attn_flash_ds, dim3((unsigned)((ns + kFlQ - 1) / kFlQ)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_attn_flash_ds");
 }

@@ -14,6 +14,13 @@ constexpr int kXcds = 8;       // MI355X: 8 XCDs, each with a private 4 MiB L2
 
 void set_error(const char *fmt, ...);
 
+// launch log (dc_kernel_trace / dc_kernel_trace_dump, dc_core.hip): off unless a test or tool switches it on
+extern int g_trace_on;
+void trace_kernel_slow(const char *name);
+inline void trace_kernel(const char *name) {
+    if (__builtin_expect(g_trace_on, 0)) trace_kernel_slow(name);
+}
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -42,6 +49,14 @@ __device__ __forceinline__ float inv_sqrt_count(int d) {
 }
 
 }  // namespace dc
+
+// every kernel launch of the library: the kernel expression as written (template arguments included) goes to the
+// launch log when it is on
+#define DC_LAUNCH(kernel, ...)                     \
+    do {                                           \
+        dc::trace_kernel(#kernel);                 \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);   \
+    } while (0)
 
 #define DC_REQUIRE(cond, ...)            \
     do {                                 \

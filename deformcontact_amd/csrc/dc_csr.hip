@@ -621,22 +621,22 @@ static int run_build(Build &b, int nsides, hipStream_t stream, const char *what)
     }
     const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
     const int64_t slots = E + (b.self_loops ? N : 0);
-    hipLaunchKernelGGL(k_init, dim3((unsigned)((N + 255) / 256), nsides), dim3(256), 0, stream, b);
+    DC_LAUNCH(k_init, dim3((unsigned)((N + 255) / 256), nsides), dim3(256), 0, stream, b);
     if (E > 0)
-        hipLaunchKernelGGL(k_count, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, b, nsides);
+        DC_LAUNCH(k_count, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, b, nsides);
     bool ptr16 = true;                          // k_scan_small stores ptr with 16-byte accesses
     for (int s = 0; s < nsides; ++s) ptr16 = ptr16 && (((uintptr_t)b.s[s].ptr & 15) == 0);
     if (N <= kScanSmall && ptr16) {
-        hipLaunchKernelGGL(k_scan_small, dim3(nsides), dim3(1024), 0, stream, b);
+        DC_LAUNCH(k_scan_small, dim3(nsides), dim3(1024), 0, stream, b);
     } else {
-        hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ntiles, nsides), dim3(256), 0, stream, b);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(nsides), dim3(256), 0, stream, b, ntiles);
-        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)ntiles, nsides), dim3(256), 0, stream, b, ntiles);
+        DC_LAUNCH(k_scan_reduce, dim3((unsigned)ntiles, nsides), dim3(256), 0, stream, b);
+        DC_LAUNCH(k_scan_tiles, dim3(nsides), dim3(256), 0, stream, b, ntiles);
+        DC_LAUNCH(k_scan_apply, dim3((unsigned)ntiles, nsides), dim3(256), 0, stream, b, ntiles);
     }
     if (slots > 0) {
         const unsigned sb = (unsigned)((slots + 255) / 256);
-        hipLaunchKernelGGL(k_fill, dim3(sb), dim3(256), 0, stream, b, nsides);
-        hipLaunchKernelGGL(k_emit, dim3(sb + kBigBlocks, nsides), dim3(256), 0, stream, b, sb);
+        DC_LAUNCH(k_fill, dim3(sb), dim3(256), 0, stream, b, nsides);
+        DC_LAUNCH(k_emit, dim3(sb + kBigBlocks, nsides), dim3(256), 0, stream, b, sb);
     }
     return check_launch(what);
 }
@@ -799,7 +799,7 @@ extern "C" int dc_graph_build_segmented(const int64_t *edge_index, int64_t E, in
             b.edge_ptr[i] = (int32_t)edge_ptr_host[first + i];
         }
         b.nseg = cnt, b.last = first + cnt == nseg;
-        hipLaunchKernelGGL(k_build_segment, dim3((unsigned)cnt, 2), dim3(1024), 0, stream, b);
+        DC_LAUNCH(k_build_segment, dim3((unsigned)cnt, 2), dim3(1024), 0, stream, b);
     }
     return check_launch("dc_graph_build_segmented");
 }
@@ -809,7 +809,7 @@ extern "C" int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last, int3
     DC_REQUIRE(max_edges >= 0, "dc_invert_perm: negative size");
     if (max_edges == 0) return DC_OK;
     DC_REQUIRE(perm && ptr_last && pos_of, "dc_invert_perm: null pointer");
-    hipLaunchKernelGGL(k_invert_perm, dim3((max_edges + 255) / 256), dim3(256), 0,
+    DC_LAUNCH(k_invert_perm, dim3((max_edges + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, perm, ptr_last, pos_of, max_edges);
     return check_launch("dc_invert_perm");
 }
@@ -821,7 +821,7 @@ extern "C" int dc_hash_i64(const int64_t *v, int64_t n, uint64_t *out, dc_stream
     if (n == 0) return check_launch("dc_hash_i64");
     DC_REQUIRE(v, "dc_hash_i64: null input");
     const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(k_hash_i64, dim3(grid), dim3(256), 0, stream, v, n,
+    DC_LAUNCH(k_hash_i64, dim3(grid), dim3(256), 0, stream, v, n,
                        (unsigned long long *)out);
     return check_launch("dc_hash_i64");
 }
@@ -832,7 +832,7 @@ extern "C" int dc_morton_codes(const float *pos, int64_t ld, int64_t n, const fl
     DC_REQUIRE(n >= 0, "dc_morton_codes: negative size");
     if (n == 0) return DC_OK;
     DC_REQUIRE(pos && lo_host && inv_extent_host && codes && ld >= 3, "dc_morton_codes: bad arguments");
-    hipLaunchKernelGGL(k_morton, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pos, ld, n,
+    DC_LAUNCH(k_morton, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pos, ld, n,
                        lo_host[0], lo_host[1], lo_host[2], inv_extent_host[0], inv_extent_host[1],
                        inv_extent_host[2], codes);
     return check_launch("dc_morton_codes");

@@ -540,7 +540,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
                 r.partial = p.kpartial, r.gw[0] = out, r.Fi = Fo, r.Fo = N, r.cols = Fo;
                 r.nseg = 1, r.nchunks = p.ksplit, r.ngw = 1, r.bps = 1, r.accumulate = 0;
                 const int64_t total = N * Fo;
-                hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, r);
+                DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, r);
             }
             return check_launch("dc_tag_linear_fwd_h2");
         }
@@ -558,13 +558,13 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
         fprintf(stderr, "[dc] generic fwd dense kernel: N=%lld Fi=%lld Fo=%lld nseg=%d vec=%d ldx=%lld ldo=%lld products=%d\n",
                 (long long)N, (long long)Fi, (long long)Fo, nseg, (int)vec, (long long)ldxs[0], (long long)ldo, products);
     if (mb == 2 && vec)
-        hipLaunchKernelGGL((k_tag_linear_fwd<2, true>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_tag_linear_fwd<2, true>), gd, bd, 0, hs, p);
     else if (mb == 2)
-        hipLaunchKernelGGL((k_tag_linear_fwd<2, false>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_tag_linear_fwd<2, false>), gd, bd, 0, hs, p);
     else if (vec)
-        hipLaunchKernelGGL((k_tag_linear_fwd<1, true>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_tag_linear_fwd<1, true>), gd, bd, 0, hs, p);
     else
-        hipLaunchKernelGGL((k_tag_linear_fwd<1, false>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_tag_linear_fwd<1, false>), gd, bd, 0, hs, p);
     return check_launch("dc_tag_linear_fwd");
 }
 
@@ -603,7 +603,7 @@ static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
                               "aligned operands (Fi=%lld Fo=%lld)", (long long)Fi, (long long)Fo);
     if (use_fast() && vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
     ++g_generic_dense_launches;
-#define DC_DX(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
+#define DC_DX(MB_, V_, M_) DC_LAUNCH((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) {
         if (vec && p.has_mask) DC_DX(2, true, true);
         else if (vec) DC_DX(2, true, false);
@@ -746,7 +746,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
         r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = nslots;
         r.cols = gw_cols, r.ngw = ngw, r.bps = ngw / nseg, r.accumulate = accumulate;
         const int64_t total_c = (int64_t)ngw * Fo * gw_cols + (gbias ? Fo : 0);
-        hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total_c + 255) / 256)), dim3(256), 0, hs, r);
+        DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total_c + 255) / 256)), dim3(256), 0, hs, r);
         return check_launch("dc_tag_linear_bwd_dw_h2_corr");
     }
     if (ragged) {
@@ -761,11 +761,11 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
         t.h2 = H2Scales{};
         const dim3 gt((unsigned)(tiles * nseg));
         if (mb == 2) {
-            if (p.has_mask) hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, true>), gt, bd, 0, hs, t);
-            else hipLaunchKernelGGL((k_tag_linear_bwd_dw<2, true, false>), gt, bd, 0, hs, t);
+            if (p.has_mask) DC_LAUNCH((k_tag_linear_bwd_dw<2, true, true>), gt, bd, 0, hs, t);
+            else DC_LAUNCH((k_tag_linear_bwd_dw<2, true, false>), gt, bd, 0, hs, t);
         } else {
-            if (p.has_mask) hipLaunchKernelGGL((k_tag_linear_bwd_dw<1, true, true>), gt, bd, 0, hs, t);
-            else hipLaunchKernelGGL((k_tag_linear_bwd_dw<1, true, false>), gt, bd, 0, hs, t);
+            if (p.has_mask) DC_LAUNCH((k_tag_linear_bwd_dw<1, true, true>), gt, bd, 0, hs, t);
+            else DC_LAUNCH((k_tag_linear_bwd_dw<1, true, false>), gt, bd, 0, hs, t);
         }
         p.N = n0;                                        // chunks past n0 become empty (zero partials)
     }
@@ -773,7 +773,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     DC_REQUIRE(fast_done || products != 2, "dc_tag_linear_bwd_dw_h2: needs N %% 16 == 0, Fi %% 4 == 0, "
                "Fo %% 4 == 0 and 16-byte aligned operands (N=%lld)", (long long)N);
     fast_done = fast_done || (use_fast() && vec && dw_fast_launch(p, mb, hs));
-#define DC_DW(MB_, V_, M_) hipLaunchKernelGGL((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
+#define DC_DW(MB_, V_, M_) DC_LAUNCH((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (!fast_done) ++g_generic_dense_launches;
     if (fast_done) {
     } else
@@ -793,7 +793,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = nslots;
     r.cols = gw_cols, r.ngw = ngw, r.bps = ngw / nseg, r.accumulate = accumulate;
     const int64_t total = (int64_t)ngw * Fo * gw_cols + (gbias ? Fo : 0);
-    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, r);
     return check_launch("dc_tag_linear_bwd_dw");
 }
@@ -1035,7 +1035,7 @@ extern "C" int dc_tag_mask_grad(const float *g, int64_t ldg, const float *out_fo
     const bool vec4 = (F % 4 == 0) && (ldg % 4 == 0) && (ldgm % 4 == 0) && (((uintptr_t)g) & 15) == 0 &&
                       (((uintptr_t)gm) & 15) == 0 &&
                       (!out_for_mask || ((ldo % 4 == 0) && (((uintptr_t)out_for_mask) & 15) == 0));
-    hipLaunchKernelGGL(k_mask_grad, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g,
+    DC_LAUNCH(k_mask_grad, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g,
                        ldg, out_for_mask, ldo, gm, ldgm, N, (int)F, rowmax_a, rowmax_b, vec4);
     return check_launch("dc_tag_mask_grad");
 }
@@ -1057,6 +1057,8 @@ struct WPrepParams {
     int64_t Fo, Fi;
     float *w_rowmax, *wt_rowmax;
     _Float16 *wimg, *wtimg;
+    float *zero;                         // optional: a float buffer this launch also clears (dc_tag_weight_prep_zero)
+    int64_t zero_n;
 };
 __device__ __forceinline__ void wprep_put(_Float16 *img_row, int64_t k, float v, float scale) {
     const float x = v * scale;
@@ -1067,6 +1069,8 @@ __device__ __forceinline__ void wprep_put(_Float16 *img_row, int64_t k, float v,
 }
 __device__ __forceinline__ void weight_prep_body(const WPrepParams &p) {
     const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.zero_n; i += (int64_t)gridDim.x * blockDim.x)
+        p.zero[i] = 0.f;
     const int64_t rb = (p.Fo + 3) / 4;
     float m = 0.f;
     if ((int64_t)blockIdx.x < rb) {
@@ -1108,9 +1112,19 @@ __device__ __forceinline__ void weight_prep_body(const WPrepParams &p) {
 __global__ void __launch_bounds__(256) k_weight_prep(WPrepParams p) { weight_prep_body(p); }
 }  // namespace dc
 
+extern "C" int dc_tag_weight_prep_zero(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
+                                       void *w_image, void *wt_image, float *wt_rowmax, float *zero, int64_t zero_n,
+                                       dc_stream_t stream);
 extern "C" int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi,
                                   float *w_rowmax, void *w_image, void *wt_image, float *wt_rowmax,
                                   dc_stream_t stream) {
+    return dc_tag_weight_prep_zero(ws, nseg, Fo, Fi, w_rowmax, w_image, wt_image, wt_rowmax, nullptr, 0, stream);
+}
+
+extern "C" int dc_tag_weight_prep_zero(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
+                                       void *w_image, void *wt_image, float *wt_rowmax, float *zero, int64_t zero_n,
+                                       dc_stream_t stream) {
+    DC_REQUIRE(zero_n >= 0 && (zero_n == 0 || zero), "dc_tag_weight_prep_zero: bad zero buffer");
     DC_REQUIRE(nseg >= 1 && nseg <= kMaxSeg && Fo >= 1 && Fi >= 1 && ws && w_rowmax,
                "dc_tag_weight_prep: bad arguments");
     DC_REQUIRE((wt_image == nullptr) == (wt_rowmax == nullptr),
@@ -1126,8 +1140,9 @@ extern "C" int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, 
     }
     p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax, p.wt_rowmax = wt_rowmax;
     p.wimg = (_Float16 *)w_image, p.wtimg = (_Float16 *)wt_image;
+    p.zero = zero, p.zero_n = zero_n;
     const int64_t blocks = (Fo + 3) / 4 + (wt_image ? (Fi + 3) / 4 : 0);
-    hipLaunchKernelGGL(k_weight_prep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    DC_LAUNCH(k_weight_prep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_tag_weight_prep");
 }
 
@@ -1137,7 +1152,7 @@ extern "C" int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F
     if (N == 0) return DC_OK;
     DC_REQUIRE(x && rowmax, "dc_rowabsmax_f32: null pointer");
     const bool vec4 = (F % 4 == 0) && (ld % 4 == 0) && (((uintptr_t)x) & 15) == 0;
-    hipLaunchKernelGGL(k_rowabsmax, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    DC_LAUNCH(k_rowabsmax, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, ld, N, (int)F, rowmax, vec4);
     return check_launch("dc_rowabsmax_f32");
 }
@@ -1161,7 +1176,7 @@ extern "C" int dc_tag_weight_rowmax(const float *const *ws, int nseg, int64_t Fo
         p.w[s] = ws[s];
     }
     p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.out = w_rowmax;
-    hipLaunchKernelGGL(k_w_rowmax, dim3((unsigned)((Fo + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    DC_LAUNCH(k_w_rowmax, dim3((unsigned)((Fo + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_tag_weight_rowmax");
 }
 
@@ -1261,7 +1276,7 @@ extern "C" int dc_tag_grouped_weight_prep(const float *const *ws, int ngroups, i
         p.wimg = (_Float16 *)w_image[g], p.wtimg = wt_image ? (_Float16 *)wt_image[g] : nullptr;
     }
     const int64_t blocks = (Fo + 3) / 4 + (wt_image ? (Fi + 3) / 4 : 0);
-    hipLaunchKernelGGL(k_weight_prep_grouped, dim3((unsigned)blocks, (unsigned)ngroups), dim3(256), 0,
+    DC_LAUNCH(k_weight_prep_grouped, dim3((unsigned)blocks, (unsigned)ngroups), dim3(256), 0,
                        (hipStream_t)stream, q);
     return check_launch("dc_tag_grouped_weight_prep");
 }
@@ -1314,7 +1329,7 @@ extern "C" int dc_tag_grouped_mask_grad(const float *const *g, const int64_t *ld
                    "dc_tag_grouped_mask_grad: null / misaligned gradient of group %d", k);
         q.g[k] = g[k], q.ldg[k] = ldg[k], q.row_beg[k] = row_beg[k], q.rows[k] = rows[k];
     }
-    hipLaunchKernelGGL(k_mask_grad_grouped, dim3((unsigned)((N_total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    DC_LAUNCH(k_mask_grad_grouped, dim3((unsigned)((N_total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        q, out_for_mask, ldo, gm, ldgm, N_total, (int)F, rowmax_a, rowmax_b);
     return check_launch("dc_tag_grouped_mask_grad");
 }
@@ -1398,7 +1413,7 @@ extern "C" int dc_tag_grouped_bwd_dw_h2(const float *g, int64_t ldg, const float
         r.ngw = nseg, r.bps = 1, r.accumulate = accumulate;
     }
     const int64_t total = (int64_t)nseg * Fo * Fi + (any_bias ? Fo : 0);
-    hipLaunchKernelGGL(k_dw_reduce_grouped, dim3((unsigned)((total + 255) / 256), (unsigned)ngroups), dim3(256), 0,
+    DC_LAUNCH(k_dw_reduce_grouped, dim3((unsigned)((total + 255) / 256), (unsigned)ngroups), dim3(256), 0,
                        hs, rg);
     return check_launch("dc_tag_grouped_bwd_dw_h2");
 }
@@ -1459,6 +1474,6 @@ extern "C" int dc_tag_linear_bwd_dw_bf16(const uint16_t *g, int64_t ldg, const u
     r.Fi = Fi, r.Fo = Fo, r.cols = Fi, r.nseg = nseg, r.nchunks = N > 0 ? p.nchunks : 0;
     r.ngw = nseg, r.bps = 1, r.accumulate = accumulate;
     const int64_t total = (int64_t)nseg * Fo * Fi + (gbias ? Fo : 0);
-    hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, r);
+    DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, r);
     return check_launch("dc_tag_linear_bwd_dw_bf16");
 }

@@ -522,7 +522,7 @@ bool dw_bf16_launch(const DwBf16Params &p, hipStream_t hs) {
     if (p.ldg % 8 != 0 || p.ldx % 8 != 0 || ((uintptr_t)p.g & 15) || ((uintptr_t)p.x & 15)) return false;
     const int64_t grid = (p.Fo / 128) * (p.Fi / 256) * p.nseg * p.nchunks;
     if (grid >= (int64_t)INT32_MAX) return false;
-    hipLaunchKernelGGL(k_dw_bf16, dim3((unsigned)grid), dim3(512), 0, hs, p);
+    DC_LAUNCH(k_dw_bf16, dim3((unsigned)grid), dim3(512), 0, hs, p);
     return true;
 }
 
@@ -552,12 +552,12 @@ extern "C" int dc_tag_linear_fwd_bf16(const uint16_t *a, int64_t lda, const uint
     const int64_t xtiles = ((N + kGxBM - 1) / kGxBM) * ((Fo + kGxBN - 1) / kGxBN);
     const bool xok = K % kGxBK == 0 && lda * kGxBM < ((int64_t)1 << 31) && K * kGxBN < ((int64_t)1 << 31);
     if (xok && (force == 1 || (force != 0 && xtiles >= 160))) {
-        if (out_is_bf16) hipLaunchKernelGGL(k_fwd_bf16x<true>, dim3((unsigned)xtiles), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL(k_fwd_bf16x<false>, dim3((unsigned)xtiles), dim3(512), 0, stream, p);
+        if (out_is_bf16) DC_LAUNCH(k_fwd_bf16x<true>, dim3((unsigned)xtiles), dim3(512), 0, stream, p);
+        else DC_LAUNCH(k_fwd_bf16x<false>, dim3((unsigned)xtiles), dim3(512), 0, stream, p);
         return check_launch("dc_tag_linear_fwd_bf16");
     }
     const int64_t grid = ((N + 127) / 128) * ((Fo + BN - 1) / BN);
-    hipLaunchKernelGGL(k_fwd_bf16, dim3((unsigned)grid), dim3(512), 0, stream, p);
+    DC_LAUNCH(k_fwd_bf16, dim3((unsigned)grid), dim3(512), 0, stream, p);
     return check_launch("dc_tag_linear_fwd_bf16");
 }
 
@@ -574,7 +574,7 @@ extern "C" int dc_to_bf16(const float *const *srcs, int nseg, int64_t rows, int6
         pk.p[s] = srcs[s];
     }
     const int64_t total = rows * cols * nseg;
-    hipLaunchKernelGGL(k_to_bf16_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pk,
+    DC_LAUNCH(k_to_bf16_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pk,
                        nseg, rows, cols, ld_src, dst, ld_dst);
     return check_launch("dc_to_bf16");
 }
@@ -588,6 +588,6 @@ extern "C" int dc_tag_mask_grad_bf16(const void *g, int64_t ldg, int g_is_bf16, 
     DC_REQUIRE(g && gm, "dc_tag_mask_grad_bf16: null pointer");
     MaskBf16Params p{g, out_for_mask, gm, ldg, ldo, ldgm, N, (int)F, g_is_bf16, mask_is_bf16};
     const int64_t total = N * F;
-    hipLaunchKernelGGL(k_mask_grad_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    DC_LAUNCH(k_mask_grad_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_tag_mask_grad_bf16");
 }

@@ -279,9 +279,9 @@ bool fwd_fast_launch(const FwdParams &p, int mb, hipStream_t hs) {
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
     const dim3 gd((unsigned)grid), bd(256);
     if (mb == 2)
-        hipLaunchKernelGGL((k_fwd_fast<2>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_fwd_fast<2>), gd, bd, 0, hs, p);
     else
-        hipLaunchKernelGGL((k_fwd_fast<1>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_fwd_fast<1>), gd, bd, 0, hs, p);
     return true;
 }
 
@@ -292,7 +292,7 @@ bool dx_fast_launch(const DxParams &p, int mb, hipStream_t hs) {
         if (!al16(p.w[s].p)) return false;
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN) * p.nseg;
     const dim3 gd((unsigned)grid), bd(256);
-#define DC_L(MB_, M_) hipLaunchKernelGGL((k_dx_fast<MB_, M_>), gd, bd, 0, hs, p)
+#define DC_L(MB_, M_) DC_LAUNCH((k_dx_fast<MB_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
     else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
 #undef DC_L
@@ -308,7 +308,7 @@ bool dw_fast_launch(const DwParams &p, int mb, hipStream_t hs) {
         if (!al16(p.x[s].p) || p.x[s].ld % 4 != 0) return false;
     const int64_t tiles = ((p.Fo + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN);
     const dim3 gd((unsigned)(tiles * p.nseg * p.nchunks)), bd(256);
-#define DC_L(MB_, M_) hipLaunchKernelGGL((k_dw_fast<MB_, M_>), gd, bd, 0, hs, p)
+#define DC_L(MB_, M_) DC_LAUNCH((k_dw_fast<MB_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
     else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
 #undef DC_L

@@ -259,11 +259,11 @@ bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs) {
                          (p.ksplit > 1 ? p.ksplit : 1);
     const dim3 gd((unsigned)grid), bd(256);
     if (p.h2.b_presplit) {
-        if (mb == 2) hipLaunchKernelGGL((k_fwd_h2<2, true>), gd, bd, 0, hs, p);
-        else hipLaunchKernelGGL((k_fwd_h2<1, true>), gd, bd, 0, hs, p);
+        if (mb == 2) DC_LAUNCH((k_fwd_h2<2, true>), gd, bd, 0, hs, p);
+        else DC_LAUNCH((k_fwd_h2<1, true>), gd, bd, 0, hs, p);
     } else {
-        if (mb == 2) hipLaunchKernelGGL((k_fwd_h2<2, false>), gd, bd, 0, hs, p);
-        else hipLaunchKernelGGL((k_fwd_h2<1, false>), gd, bd, 0, hs, p);
+        if (mb == 2) DC_LAUNCH((k_fwd_h2<2, false>), gd, bd, 0, hs, p);
+        else DC_LAUNCH((k_fwd_h2<1, false>), gd, bd, 0, hs, p);
     }
     return true;
 }

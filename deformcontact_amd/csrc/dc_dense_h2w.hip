@@ -320,15 +320,15 @@ bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     if (p.x2) {
         if (!p.x2_coef || ks > 1 || !hw_al16(p.x2)) return false;
         if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
-            hipLaunchKernelGGL((k_fwd_h2w<true, true>), gd, bd, 0, hs, p);
+            DC_LAUNCH((k_fwd_h2w<true, true>), gd, bd, 0, hs, p);
         else
-            hipLaunchKernelGGL((k_fwd_h2w<false, true>), gd, bd, 0, hs, p);
+            DC_LAUNCH((k_fwd_h2w<false, true>), gd, bd, 0, hs, p);
         return true;
     }
     if (p.N % kWBM == 0 && p.Fo % kWBN == 0)
-        hipLaunchKernelGGL((k_fwd_h2w<true>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_fwd_h2w<true>), gd, bd, 0, hs, p);
     else
-        hipLaunchKernelGGL((k_fwd_h2w<false>), gd, bd, 0, hs, p);
+        DC_LAUNCH((k_fwd_h2w<false>), gd, bd, 0, hs, p);
     return true;
 }
 

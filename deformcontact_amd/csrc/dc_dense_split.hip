@@ -766,8 +766,8 @@ bool dw_h2w_launch(const DwParams &p, hipStream_t hs) {
     const int64_t grid = (p.Fo / 128) * p.nseg * p.nchunks;
     if (grid >= (int64_t)INT32_MAX) return false;
     const dim3 gd((unsigned)grid), bd(512);
-    if (p.g2) hipLaunchKernelGGL((k_dw_h2w<true>), gd, bd, 0, hs, p);
-    else hipLaunchKernelGGL((k_dw_h2w<false>), gd, bd, 0, hs, p);
+    if (p.g2) DC_LAUNCH((k_dw_h2w<true>), gd, bd, 0, hs, p);
+    else DC_LAUNCH((k_dw_h2w<false>), gd, bd, 0, hs, p);
     return true;
 }
 
@@ -805,7 +805,7 @@ void transpose_weights_launch(const float *const *ws, int nseg, int64_t Fo, int6
     for (int s = 0; s < nseg; ++s) t.w[s] = ws[s];
     t.wt = wt, t.Fi = Fi, t.Fo = Fo, t.nseg = nseg;
     const int64_t tiles = ((Fi + 31) / 32) * ((Fo + 31) / 32) * nseg;
-    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)tiles), dim3(256), 0, hs, t);
+    DC_LAUNCH(k_transpose_w, dim3((unsigned)tiles), dim3(256), 0, hs, t);
 }
 
 static inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
@@ -819,7 +819,7 @@ bool fwd_split_launch(const FwdParams &p, int mb, int np, hipStream_t hs) {
             return false;
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fo + BN - 1) / BN);
     const dim3 gd((unsigned)grid), bd(256);
-#define DC_L(MB_, NP_) hipLaunchKernelGGL((k_fwd_split<MB_, NP_>), gd, bd, 0, hs, p)
+#define DC_L(MB_, NP_) DC_LAUNCH((k_fwd_split<MB_, NP_>), gd, bd, 0, hs, p)
     if (mb == 2) { if (np == 6) DC_L(2, 6); else if (np == 3) DC_L(2, 3); else if (np == 2) DC_L(2, 2); else DC_L(2, 1); }
     else { if (np == 6) DC_L(1, 6); else if (np == 3) DC_L(1, 3); else if (np == 2) DC_L(1, 2); else DC_L(1, 1); }
 #undef DC_L
@@ -840,16 +840,16 @@ bool dx_split_launch(DxParams p, float *wt, int mb, int np, hipStream_t hs) {
     for (int s = 0; s < p.nseg; ++s) t.w[s] = p.w[s].p;
     t.wt = wt, t.Fi = p.Fi, t.Fo = p.Fo, t.nseg = p.nseg;
     const int64_t tiles = ((p.Fi + 31) / 32) * ((p.Fo + 31) / 32) * p.nseg;
-    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)tiles), dim3(256), 0, hs, t);
+    DC_LAUNCH(k_transpose_w, dim3((unsigned)tiles), dim3(256), 0, hs, t);
     for (int s = 0; s < p.nseg; ++s) p.w[s] = Mat{wt + (int64_t)s * p.Fi * p.Fo, p.Fo};
     const int64_t grid = ((p.N + 64 * mb - 1) / (64 * mb)) * ((p.Fi + BN - 1) / BN) * p.nseg;
     const dim3 gd((unsigned)grid), bd(256);
 #define DC_L(MB_, M_)                                                                 \
     do {                                                                              \
-        if (np == 6) hipLaunchKernelGGL((k_dx_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
-        else if (np == 3) hipLaunchKernelGGL((k_dx_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
-        else if (np == 2) hipLaunchKernelGGL((k_dx_split<MB_, M_, 2>), gd, bd, 0, hs, p);  \
-        else hipLaunchKernelGGL((k_dx_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
+        if (np == 6) DC_LAUNCH((k_dx_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
+        else if (np == 3) DC_LAUNCH((k_dx_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
+        else if (np == 2) DC_LAUNCH((k_dx_split<MB_, M_, 2>), gd, bd, 0, hs, p);  \
+        else DC_LAUNCH((k_dx_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
     } while (0)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
     else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }
@@ -871,10 +871,10 @@ bool dw_split_launch(const DwParams &p, int mb, int np, hipStream_t hs) {
     const dim3 gd((unsigned)(tiles * p.nseg * p.nchunks)), bd(256);
 #define DC_L(MB_, M_)                                                                 \
     do {                                                                              \
-        if (np == 6) hipLaunchKernelGGL((k_dw_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
-        else if (np == 3) hipLaunchKernelGGL((k_dw_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
-        else if (np == 2) hipLaunchKernelGGL((k_dw_split<MB_, M_, 2>), gd, bd, 0, hs, p);  \
-        else hipLaunchKernelGGL((k_dw_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
+        if (np == 6) DC_LAUNCH((k_dw_split<MB_, M_, 6>), gd, bd, 0, hs, p);       \
+        else if (np == 3) DC_LAUNCH((k_dw_split<MB_, M_, 3>), gd, bd, 0, hs, p);  \
+        else if (np == 2) DC_LAUNCH((k_dw_split<MB_, M_, 2>), gd, bd, 0, hs, p);  \
+        else DC_LAUNCH((k_dw_split<MB_, M_, 1>), gd, bd, 0, hs, p);               \
     } while (0)
     if (mb == 2) { if (p.has_mask) DC_L(2, true); else DC_L(2, false); }
     else { if (p.has_mask) DC_L(1, true); else DC_L(1, false); }

@@ -156,7 +156,7 @@ extern "C" int dc_gat_edge_softmax_fwd(const int32_t *ptr, const int32_t *other,
     DC_REQUIRE(N >= 0, "dc_gat_edge_softmax_fwd: negative N");
     if (N == 0) return DC_OK;
     DC_REQUIRE(ptr && other && a_src && a_dst && alpha, "dc_gat_edge_softmax_fwd: null pointer");
-    hipLaunchKernelGGL(k_gat_softmax_fwd, dim3((unsigned)((N * kSub + 255) / 256)), dim3(256), 0,
+    DC_LAUNCH(k_gat_softmax_fwd, dim3((unsigned)((N * kSub + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, ptr, other, a_src, a_dst, slope, alpha, N);
     return check_launch("dc_gat_edge_softmax_fwd");
 }
@@ -169,7 +169,7 @@ extern "C" int dc_gat_edge_softmax_bwd(const int32_t *ptr, const int32_t *other,
     if (N == 0) return DC_OK;
     DC_REQUIRE(ptr && other && a_src && a_dst && alpha && galpha && ge && g_a_dst,
                "dc_gat_edge_softmax_bwd: null pointer");
-    hipLaunchKernelGGL(k_gat_softmax_bwd, dim3((unsigned)((N * kSub + 255) / 256)), dim3(256), 0,
+    DC_LAUNCH(k_gat_softmax_bwd, dim3((unsigned)((N * kSub + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, ptr, other, a_src, a_dst, slope, alpha, galpha, ge, g_a_dst, N);
     return check_launch("dc_gat_edge_softmax_bwd");
 }
@@ -183,10 +183,10 @@ extern "C" int dc_sddmm_f32(const int32_t *ptr, const int32_t *other, const floa
     DC_REQUIRE(ldg >= F && ldh >= F, "dc_sddmm_f32: leading dimension smaller than F");
     const bool vec4 = F % 4 == 0 && ldg % 4 == 0 && ldh % 4 == 0 && (((uintptr_t)g | (uintptr_t)h) & 15) == 0;
     if (vec4)
-        hipLaunchKernelGGL((k_sddmm<4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+        DC_LAUNCH((k_sddmm<4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                            ptr, other, g, ldg, h, ldh, d, N, (int)F);
     else
-        hipLaunchKernelGGL((k_sddmm<1>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+        DC_LAUNCH((k_sddmm<1>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                            ptr, other, g, ldg, h, ldh, d, N, (int)F);
     return check_launch("dc_sddmm_f32");
 }
@@ -196,7 +196,7 @@ extern "C" int dc_segment_sum_f32(const int32_t *ptr, const int32_t *map, const 
     DC_REQUIRE(N >= 0, "dc_segment_sum_f32: negative N");
     if (N == 0) return DC_OK;
     DC_REQUIRE(ptr && v && out, "dc_segment_sum_f32: null pointer");
-    hipLaunchKernelGGL(k_segment_sum, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, ptr,
+    DC_LAUNCH(k_segment_sum, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, ptr,
                        map, v, out, N);
     return check_launch("dc_segment_sum_f32");
 }
@@ -206,7 +206,7 @@ extern "C" int dc_gather_f32(const float *v, const int32_t *idx, float *out,
     DC_REQUIRE(cap >= 0, "dc_gather_f32: negative size");
     if (cap == 0) return DC_OK;
     DC_REQUIRE(v && idx && out && count_ptr, "dc_gather_f32: null pointer");
-    hipLaunchKernelGGL(k_gather, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, idx,
+    DC_LAUNCH(k_gather, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, idx,
                        out, count_ptr, cap);
     return check_launch("dc_gather_f32");
 }
@@ -216,7 +216,7 @@ extern "C" int dc_compose_perm(const int32_t *a, const int32_t *b, int32_t *out,
     DC_REQUIRE(cap >= 0, "dc_compose_perm: negative size");
     if (cap == 0) return DC_OK;
     DC_REQUIRE(a && b && out && count_ptr, "dc_compose_perm: null pointer");
-    hipLaunchKernelGGL(k_compose, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b,
+    DC_LAUNCH(k_compose, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b,
                        out, count_ptr, cap);
     return check_launch("dc_compose_perm");
 }

@@ -16,6 +16,8 @@
 // zeros with weight 0: the running sum started at +0 and can never be -0, so adding +0 leaves it unchanged.
 #include <stdlib.h>
 
+#include <string>
+
 #include "dc_common.h"
 
 #pragma clang fp contract(off)
@@ -437,6 +439,8 @@ static bool launch_chain_gcn_steps(unsigned grid, hipStream_t stream, const Chai
             return false;
         attr_set = true;
     }
+    static const std::string name = "k_hop_chain_gcn<" + std::to_string(STEPS) + ">";
+    trace_kernel(name.c_str());
     hipLaunchKernelGGL((k_hop_chain_gcn<STEPS>), dim3(grid), dim3(1024), lds, stream, p);
     return true;
 }
@@ -465,6 +469,8 @@ static bool launch_chain_steps(unsigned grid, hipStream_t stream, const ChainPar
             return false;
         attr_set = true;
     }
+    static const std::string name = std::string("k_hop_chain<") + (W ? "true, " : "false, ") + std::to_string(STEPS) + ">";
+    trace_kernel(name.c_str());
     hipLaunchKernelGGL((k_hop_chain<W, STEPS>), dim3(grid), dim3(1024), lds, stream, p);
     return true;
 }

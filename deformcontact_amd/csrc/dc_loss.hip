@@ -129,10 +129,10 @@ extern "C" int dc_contact_loss(const int32_t *ptr_f, const int32_t *other_f, con
     const float inv_3n = 1.0f / (3.0f * (float)N);
     // mean over edges as the reference divides: sum / E (E = 0: the reference divides by zero -> nan/inf)
     const float inv_e = 1.0f / (float)E;
-    hipLaunchKernelGGL(k_loss_nodes, dim3((unsigned)nblk), dim3(256), 0, stream, ptr_f, other_f, ptr_b,
+    DC_LAUNCH(k_loss_nodes, dim3((unsigned)nblk), dim3(256), 0, stream, ptr_f, other_f, ptr_b,
                        other_b, pred, ld_pred, target, ld_target, N, inv_3n, inv_e, grad_l1, grad_gcl,
                        (float *)workspace);
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, stream, (const float *)workspace, nblk, inv_3n,
+    DC_LAUNCH(k_loss_final, dim3(1), dim3(256), 0, stream, (const float *)workspace, nblk, inv_3n,
                        inv_e, losses);
     return check_launch("dc_contact_loss");
 }

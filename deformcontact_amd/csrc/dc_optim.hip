@@ -78,7 +78,7 @@ extern "C" int dc_adam_flat(float *p, float *g, float *m, float *v, int64_t n, f
     DC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                "dc_adam_flat: buffers must be 16-byte aligned");
     const int64_t threads = (n + 3) / 4;
-    hipLaunchKernelGGL(dc::k_adam_flat, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+    DC_LAUNCH(dc::k_adam_flat, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, p, g, m, v, n, step, lr, beta1, beta2, eps, zero_grad);
     return dc::check_launch("dc_adam_flat");
 }
@@ -128,7 +128,7 @@ extern "C" int dc_tag_pack_input(const float *x, int64_t ldx, float *slab, int64
     if (N == 0) return DC_OK;
     DC_REQUIRE(x && slab, "dc_tag_pack_input: null pointer");
     const int64_t total = N * (F + (wpad - width));
-    hipLaunchKernelGGL(dc::k_pack_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    DC_LAUNCH(dc::k_pack_input, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, x, ldx, slab, ld_slab, N, (int)F, (int)width, (int)wpad);
     return dc::check_launch("dc_tag_pack_input");
 }
@@ -145,7 +145,7 @@ extern "C" int dc_tag_pack_weights(const float *const *ws, int nw, float *wcat, 
     }
     p.wcat = wcat, p.Fo = Fo, p.nw = nw, p.fi = (int)fi, p.wpad = (int)wpad;
     const int64_t total = Fo * wpad;
-    hipLaunchKernelGGL(dc::k_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    DC_LAUNCH(dc::k_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, p);
     return dc::check_launch("dc_tag_pack_weights");
 }

@@ -239,7 +239,7 @@ static void launch_sub(const int32_t *ptr, const int32_t *other, const float *w,
                        int pad_beg = 0, int pad_end = 0) {
     constexpr int kRows = 256 / L;
     const unsigned grid = (unsigned)((N + kRows - 1) / kRows);
-    hipLaunchKernelGGL((k_spmm_sub<VEC, L, U>), dim3(grid), dim3(256), 0, stream, ptr, other, w, x,
+    DC_LAUNCH((k_spmm_sub<VEC, L, U>), dim3(grid), dim3(256), 0, stream, ptr, other, w, x,
                        ldx, addend, ldadd, y, ldy, N, F, src_off, self_dst, pad_beg, pad_end);
 }
 
@@ -485,10 +485,10 @@ static void launch_bf16(const int32_t *ptr, const int32_t *other, const float *w
     constexpr int kRows = 256 / L;
     const unsigned grid = (unsigned)((N + kRows - 1) / kRows);
     if (X8)
-        hipLaunchKernelGGL((k_spmm_bf16x8<L, 8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
+        DC_LAUNCH((k_spmm_bf16x8<L, 8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
                            other, w, x, ldx, addend, ldadd, y, ldy, N, F);
     else
-        hipLaunchKernelGGL((k_spmm_bf16x1<L, 8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
+        DC_LAUNCH((k_spmm_bf16x1<L, 8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
                            other, w, x, ldx, addend, ldadd, y, ldy, N, F);
 }
 
@@ -507,7 +507,7 @@ static void dispatch_bf16(const int32_t *ptr, const int32_t *other, const float 
     const bool pair = forced ? forced == 1 : N * ldx * 2 > (int64_t)128 << 20;
     if (x8 && F >= 256 && pair) {
         const unsigned grid = (unsigned)((N + 7) / 8);
-        hipLaunchKernelGGL((k_spmm_bf16_pair<8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
+        DC_LAUNCH((k_spmm_bf16_pair<8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
                            other, w, x, ldx, addend, ldadd, y, ldy, N, F);
     } else if (x8) {
         const int v = F / 8;
@@ -546,7 +546,7 @@ static int spmm_f32_impl(const int32_t *ptr, const int32_t *other, const float *
         const int64_t v = F / 4;
         if (v > 32) {
             const unsigned grid = (unsigned)((N + 3) / 4);
-            hipLaunchKernelGGL((k_spmm_wave<4, 8>), dim3(grid), dim3(256), 0, stream, ptr, other,
+            DC_LAUNCH((k_spmm_wave<4, 8>), dim3(grid), dim3(256), 0, stream, ptr, other,
                                w, x, ldx, addend, ldadd, y, ldy, N, Fi, nullptr, 0, src_off);
         } else if (v > 16)
             launch_sub<4, 32, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
@@ -559,7 +559,7 @@ static int spmm_f32_impl(const int32_t *ptr, const int32_t *other, const float *
     } else {
         if (F > 32) {
             const unsigned grid = (unsigned)((N + 3) / 4);
-            hipLaunchKernelGGL((k_spmm_wave<1, 8>), dim3(grid), dim3(256), 0, stream, ptr, other,
+            DC_LAUNCH((k_spmm_wave<1, 8>), dim3(grid), dim3(256), 0, stream, ptr, other,
                                w, x, ldx, addend, ldadd, y, ldy, N, Fi, nullptr, 0, src_off);
         } else if (F > 16)
             launch_sub<1, 32, 8>(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, Fi, src_off, stream);
@@ -648,10 +648,10 @@ static int spmm_f32_rowmax_impl(const int32_t *ptr, const int32_t *other, const 
                       aligned16(y) && (!addend || ((ldadd % 4 == 0) && aligned16(addend)));
     const unsigned grid = (unsigned)((N + 3) / 4);
     if (vec4)
-        hipLaunchKernelGGL((k_spmm_wave<4, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
+        DC_LAUNCH((k_spmm_wave<4, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
                            x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode, src_off);
     else
-        hipLaunchKernelGGL((k_spmm_wave<1, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
+        DC_LAUNCH((k_spmm_wave<1, 8, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w,
                            x, ldx, addend, ldadd, y, ldy, N, (int)F, rowmax, mode, src_off);
     return check_launch("dc_spmm_f32_rowmax");
 }

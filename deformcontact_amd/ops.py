@@ -249,7 +249,7 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
 
 def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool,
                  rowmax: Optional[torch.Tensor] = None, transposed: bool = False,
-                 rowmax_has_block0: bool = False) -> None:
+                 rowmax_has_block0: bool = False, rowmax_zeroed: bool = False) -> None:
     """In place on ``slab`` ([N, ld], K+1 column blocks of width ``f``).  Forward: block j+1 =
     A block j (j = 0..k-1).  Backward: block j-1 += A^T block j (j = k..1).  Forward with
     ``rowmax`` ([N]): also ``rowmax[i] = max_j max |block j [i, :]|`` (needs k >= 1;
@@ -263,8 +263,10 @@ def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bo
         for j in range(k, 0, -1):
             hop(adj, blocks[j], out=blocks[j - 1], addend=blocks[j - 1], weighted=g.normalize)
     elif hop_chain_eligible(g, adj, slab, f, k):
+        # mode: 1 = fresh maxima over blocks 0..K (the entry clears the buffer first), 2 = joined with block 0's, which
+        # the buffer already holds, 3 = over blocks 0..K joined with a buffer the caller has cleared (``rowmax_zeroed``)
         hop_chain(g, adj, slab, f, k, weighted=g.normalize, rowmax=rowmax,
-                  rowmax_mode=2 if rowmax_has_block0 else 1)
+                  rowmax_mode=2 if rowmax_has_block0 else (3 if rowmax_zeroed else 1))
     else:
         for j in range(k):
             hop(adj, blocks[j], out=blocks[j + 1], weighted=g.normalize, rowmax=rowmax,
@@ -426,6 +428,25 @@ def _as_slab_block0(x: torch.Tensor, n: int, fi: int, wpad: int):
     return None
 
 
+def _h2_weight_prep(L, ws, k: int, fo: int, fi: int, want_t: bool, dev, st, zero: Optional[torch.Tensor] = None):
+    """``dc_tag_weight_prep(_zero)``: row maxima and scaled fp16x2 image of the layer's weights over the concatenated
+    reduction, the same for the transposed weights (``want_t``: the forward-shaped dX block), and - on the side -
+    ``zero`` cleared.  -> (wmax, wimg, wt, wt_rowmax)."""
+    width = (k + 1) * fi
+    wmax = torch.empty(fo, dtype=torch.float32, device=dev)
+    wimg = torch.empty((fo, width), dtype=torch.float32, device=dev)     # 4 B / element
+    wt = wt_rowmax = None
+    if want_t:
+        wt = torch.empty((fi, (k + 1) * fo), dtype=torch.float32, device=dev)
+        wt_rowmax = torch.empty(fi, dtype=torch.float32, device=dev)
+    _lib.check(L.dc_tag_weight_prep_zero(_ptr_array(ws), k + 1, fo, fi, wmax.data_ptr(), wimg.data_ptr(),
+                                         wt.data_ptr() if wt is not None else None,
+                                         wt_rowmax.data_ptr() if wt is not None else None,
+                                         zero.data_ptr() if zero is not None else None,
+                                         zero.numel() if zero is not None else 0, st), "dc_tag_weight_prep")
+    return wmax, wimg, wt, wt_rowmax
+
+
 class _TagConvFn(torch.autograd.Function):
     """Whole TAGConv layer (+ optional fused ReLU): K hops into one ``[N, (K+1)*Fi]`` slab, then
     ONE fp32-MFMA kernel for ``act(x W_0^T + sum_k (A^k x) W_k^T + b)`` - PyG ``tag_conv.py``
@@ -455,6 +476,7 @@ class _TagConvFn(torch.autograd.Function):
         st = current_stream_ptr(dev)
         h2 = _tag_uses_h2(fi, k)
         rowmax = None
+        prepped = None
         if slab is None:
             # the layer's own input: pack + K hops, or the cached slab when x needs no gradient
             key = None
@@ -469,7 +491,14 @@ class _TagConvFn(torch.autograd.Function):
                     _hop_cache_put(g, key, x, slab, rowmax, dev)
         else:
             rowmax = torch.empty(n, dtype=torch.float32, device=dev) if h2 else None
-            chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax)
+            zeroed = False
+            if h2 and g is not None and hop_chain_eligible(g, g.fwd, slab, fi, k):
+                # the chain launch joins its row maxima into `rowmax` with atomics: the weight preparation - one launch
+                # anyway, independent of the slab - clears it on the side (a memset node of its own: ~5 us per chain)
+                prepped = _h2_weight_prep(L, [w.contiguous() for w in weights], k, fo, fi,
+                                          ctx.needs_input_grad[1] and fo % 16 == 0, dev, st, zero=rowmax)
+                zeroed = True
+            chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax, rowmax_zeroed=zeroed)
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
         if concat:
             wc = [w.contiguous() for w in weights]
@@ -506,15 +535,9 @@ class _TagConvFn(torch.autograd.Function):
             # reduction (the dense block runs as ONE segment over the whole slab and pulls them into
             # LDS by DMA), their row maxima and, when the input needs a gradient, the same for the
             # transposed weights (forward-shaped dX block)
-            wmax = torch.empty(fo, dtype=torch.float32, device=dev)
-            wimg = torch.empty((fo, width), dtype=torch.float32, device=dev)     # 4 B / element
-            if ctx.needs_input_grad[1] and fo % 16 == 0:
-                wt = torch.empty((fi, (k + 1) * fo), dtype=torch.float32, device=dev)
-                wt_rowmax = torch.empty(fi, dtype=torch.float32, device=dev)
-            _lib.check(L.dc_tag_weight_prep(_ptr_array(ws), k + 1, fo, fi, wmax.data_ptr(), wimg.data_ptr(),
-                                            wt.data_ptr() if wt is not None else None,
-                                            wt_rowmax.data_ptr() if wt is not None else None, st),
-                       "dc_tag_weight_prep")
+            if prepped is None:
+                prepped = _h2_weight_prep(L, ws, k, fo, fi, ctx.needs_input_grad[1] and fo % 16 == 0, dev, st)
+            wmax, wimg, wt, wt_rowmax = prepped
             rc = L.dc_tag_linear_fwd_h2p(slab.data_ptr(), slab.stride(0), wimg.data_ptr(),
                                          b.data_ptr() if b is not None else None, int(relu),
                                          out.data_ptr(), ldo, n, width, fo,

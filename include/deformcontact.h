@@ -405,6 +405,12 @@ int dc_tag_transpose_weights(const float *const *ws, int nseg, int64_t Fo, int64
  *                          backward block. */
 int dc_tag_weight_prep(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
                        void *w_image, void *wt_image, float *wt_rowmax, dc_stream_t stream);
+/* dc_tag_weight_prep that ALSO clears zero[0:zero_n] (fp32) in the same launch: the row-maxima buffer the layer's
+ * dc_hop_chain_f32 launch joins its maxima into (mode | 2) - a separate memset node costs ~5 us on the critical path
+ * of every forward chain. */
+int dc_tag_weight_prep_zero(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *w_rowmax,
+                            void *w_image, void *wt_image, float *wt_rowmax, float *zero, int64_t zero_n,
+                            dc_stream_t stream);
 /* dc_tag_linear_fwd_h2 for ONE segment x [N, K] (ldx) with pre-split weights (w_image of
  * dc_tag_weight_prep; K = nseg*Fi of that call): out = act(x . W^T + b).  With a workspace of
  * dc_tag_linear_fwd_h2p_workspace_bytes (may be NULL / 0) a long reduction with too few output
@@ -472,6 +478,14 @@ int dc_tag_grouped_bwd_dw_h2(const float *g, int64_t ldg, const float *const *xs
  * default-config step means an operand lost its alignment or a shape fell off the fast paths (round 2 found two
  * such silent fallbacks only through DC_DENSE_TRACE=1) - the test suite pins it at zero. */
 int64_t dc_generic_dense_launches(int reset);
+
+/* Launch log: which kernels does a step actually launch?  dc_kernel_trace(1) clears the log and starts counting every
+ * kernel launch of the library by kernel name as written at its launch site (e.g. "k_fwd_h2w<true, false>"; template
+ * parameters of the launching host function stay symbolic: "k_hop_chain_gcn<STEPS>"), dc_kernel_trace(0) stops.
+ * dc_kernel_trace_dump writes "name count\n" lines into buf (NUL-terminated, truncated to cap bytes) and returns the
+ * size the whole text needs.  Process-wide, thread-safe, off by default (one predictable branch per launch). */
+void dc_kernel_trace(int on);
+int64_t dc_kernel_trace_dump(char *buf, int64_t cap);
 
 /* rowmax[i] = max |x[i, 0:F]| for a row-major [N, F] view with leading dimension ld. */
 int dc_rowabsmax_f32(const float *x, int64_t ld, int64_t N, int64_t F, float *rowmax,

@@ -46,3 +46,8 @@ def test_direct_two_rank_launch_on_one_device_over_gloo():
     d = out["dist"]                       # what the driver reads at N > 1 (world size as torch.distributed sees it)
     assert d["world_size"] == 2 and d["backend"] == "gloo" and d["allreduce_bytes"] >= 572416 * 4
     assert d["allreduce_us"] is not None and d["allreduce_us"] > 0
+    # the devices the ranks ran on, all-gathered (here: two ranks, ONE physical device), and what
+    # the eager all-reduce + Adam tail costs the host per step
+    assert [r["rank"] for r in d["ranks_seen"]] == [0, 1] and all(r["device"] for r in d["ranks_seen"])
+    assert d["distinct_devices"] == 1 and d["ranks_seen"][0]["device"] == d["ranks_seen"][1]["device"]
+    assert d["tail"].startswith("eager") and d["tail_host_us_per_step"] > 0

@@ -400,6 +400,53 @@ def test_default_b32_step_launches_no_generic_dense_kernel(everyday_b32, merged)
     assert n <= 3, f"{n} generic dense launches in the shipped-config step (expected the 256 -> 3 output layer only)"
 
 
+def test_default_b32_step_launches_exactly_the_tuned_kernels(everyday_b32):
+    """WHICH kernels a default-config B=32 encoder step (new batch: adjacency build + forward +
+    backward, direct-gradient bucket) launches, by name (`dc_kernel_trace`): the one-launch segmented adjacency build, the
+    fused pack + narrow hops of the first layers, the 3-hop chain launches (`k_hop_chain_gcn`, not 12 `k_spmm_wave`
+    launches), the 128 x 256-tile fp16x2 blocks (`k_fwd_h2w`, `k_dw_h2w`), the six-product narrow blocks - and none
+    of the generic / fallback kernels."""
+    from deformcontact_amd import dp
+    rest, rig = everyday_b32
+    rest, rig = rest.clone().to(DEV), rig.clone().to(DEV)
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256).to(DEV)
+    bucket = dp.GradBucket(enc.parameters(), direct=True)
+    bucket.zero()
+    ga = torch.randn(rest.x.shape[0], 256, device=DEV)
+    gb = torch.randn(rig.x.shape[0], 256, device=DEV)
+    clear_cache()
+    torch.cuda.synchronize()
+    _lib.kernel_trace(True)
+    a, b = enc(rest, rig)
+    torch.autograd.backward([a, b], [ga, gb])
+    torch.cuda.synchronize()
+    _lib.kernel_trace(False)
+    got = _lib.kernel_trace_counts()
+    names = {k.split("<")[0] for k in got}
+    want = {
+        "k_build_segment": 2,                # both sorted adjacencies + gcn_norm of a graph: ONE launch per graph
+        "k_hop_chain_gcn<8>": 2,             # soft: forward chain + transposed chain of layer 2
+        "k_hop_chain_gcn<6>": 2,             # rigid
+        "k_weight_prep": 2,                  # layer-2 weights (+ clears the chain's row maxima)
+        "k_fwd_h2w<true>": 2,                # soft (whole 128-row tiles): layer-2 forward block (bias + ReLU epilogue)
+        "k_fwd_h2w<false>": 2,               # and dX as a forward-shaped block over the gradient slab; rigid (ragged)
+        "k_dw_h2w<false>": 2,                # layer-2 dW
+        "k_mask_grad": 2,
+    }
+    for k, v in want.items():
+        assert got.get(k) == v, (k, got)
+    # first layers: fused pack + first hop, two more narrow hops, six-product split blocks
+    narrow_hops = sum(v for k, v in got.items() if k.startswith("k_spmm_sub"))
+    assert narrow_hops == 6, got
+    assert sum(v for k, v in got.items() if k.startswith("k_fwd_split")) == 2
+    assert sum(v for k, v in got.items() if k.startswith("k_dw_split")) == 2
+    assert "k_dw_reduce" in names
+    banned = {"k_spmm_wave", "k_tag_linear_fwd", "k_tag_linear_bwd_dx", "k_tag_linear_bwd_dw", "k_fwd_h2", "k_fwd_fast",
+              "k_init", "k_count", "k_fill", "k_emit", "k_hop_chain"}
+    assert not (names & banned), (names & banned, got)
+
+
 @pytest.mark.parametrize("npad,n", [(8192 + 4, 8192 + 1), (16384 + 128, 16384 + 77), (24448, 24384), (32768, 32000)])
 def test_attention_row_kernels_register_rows_vs_strided_and_float64(npad, n):
     """the batch-32 step launches the register-row variants of the attention row kernels
