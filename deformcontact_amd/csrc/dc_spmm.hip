@@ -46,6 +46,11 @@ __device__ __forceinline__ void vaxpy(float4 &acc, float w, const float4 &v) {
     acc.w = acc.w + mw;
 }
 
+__device__ __forceinline__ void vadd(float &a, float b) { a = a + b; }
+__device__ __forceinline__ void vadd(float4 &a, const float4 &b) { a.x = a.x + b.x, a.y = a.y + b.y, a.z = a.z + b.z, a.w = a.w + b.w; }
+__device__ __forceinline__ void vrelu(float &a) { a = fmaxf(a, 0.f); }
+__device__ __forceinline__ void vrelu(float4 &a) { a.x = fmaxf(a.x, 0.f), a.y = fmaxf(a.y, 0.f), a.z = fmaxf(a.z, 0.f), a.w = fmaxf(a.w, 0.f); }
+
 // ---- one wave per destination row (F >= 64*VEC/2 ... up to any F) ----------
 __device__ __forceinline__ float vabsmax(float v) { return fabsf(v); }
 __device__ __forceinline__ float vabsmax(const float4 &v) {
@@ -76,12 +81,16 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
-template <int VEC, int U, bool RM = false>
+// EPI: y = act(sum + bias) - the "+ bias" and the ReLU that follow the aggregation of a GCNConv / GATConv layer
+// (PyG gcn_conv.py / gat_conv.py: out = propagate(...); out = out + bias; models/model.py:71,77: relu) in the row's
+// epilogue instead of two elementwise passes; same values (the sum is complete before the bias is added)
+template <int VEC, int U, bool RM = false, bool EPI = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
             const float *__restrict__ w, const float *__restrict__ x, int64_t ldx,
             const float *addend, int64_t ldadd, float *y, int64_t ldy,
-            int64_t N, int F, float *rowmax = nullptr, int rm_mode = 0, int src_off = 0) {
+            int64_t N, int F, float *rowmax = nullptr, int rm_mode = 0, int src_off = 0,
+            const float *__restrict__ bias = nullptr, int relu = 0) {
     // src_off: the adjacency is a ROW WINDOW of a larger (merged, block-diagonal) one - `ptr` points at the
     // window's first row, neighbour ids are ids of the larger node space and x / y / addend / rowmax hold only
     // the window's rows: neighbour row = other[p] - src_off
@@ -120,6 +129,10 @@ k_spmm_wave(const int32_t *__restrict__ ptr, const int32_t *__restrict__ other,
 #pragma unroll
             for (int j = 0; j < U; ++j)
                 if (j < n) vaxpy(acc, ww[j], v[j]);
+        }
+        if (EPI) {
+            if (bias) vadd(acc, *reinterpret_cast<const V *>(bias + c));
+            if (relu) vrelu(acc);
         }
         *reinterpret_cast<V *>(y + row * ldy + c) = acc;
         if (RM) rmax = fmaxf(rmax, fmaxf(vabsmax(acc), vabsmax(self)));
@@ -576,6 +589,29 @@ extern "C" int dc_spmm_f32(const int32_t *ptr, const int32_t *other, const float
                            const float *x, int64_t ldx, const float *addend, int64_t ldadd,
                            float *y, int64_t ldy, int64_t N, int64_t F, dc_stream_t stream) {
     return spmm_f32_impl(ptr, other, w, x, ldx, addend, ldadd, y, ldy, N, F, 0, stream);
+}
+
+// y = act(A x + bias) in one launch (GCNConv / GATConv aggregation + bias + the encoder's ReLU); one wave per row for
+// every width (these layers aggregate the hidden width, 256)
+extern "C" int dc_spmm_f32_bias_act(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
+                                    int64_t ldx, const float *bias, int relu, float *y, int64_t ldy, int64_t N,
+                                    int64_t F, dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(N >= 0 && F >= 0, "dc_spmm_f32_bias_act: negative size");
+    if (N == 0 || F == 0) return DC_OK;
+    DC_REQUIRE(ptr && x && y, "dc_spmm_f32_bias_act: null ptr/x/y");
+    DC_REQUIRE(N < (int64_t)INT32_MAX / 4 && F < (1 << 24) && ldx >= F && ldy >= F && x != y,
+               "dc_spmm_f32_bias_act: bad sizes / aliasing");
+    const bool vec4 = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
+                      (!bias || aligned16(bias));
+    const unsigned grid = (unsigned)((N + 3) / 4);
+    if (vec4)
+        DC_LAUNCH((k_spmm_wave<4, 8, false, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w, x, ldx, nullptr,
+                  (int64_t)0, y, ldy, N, (int)F, nullptr, 0, 0, bias, relu);
+    else
+        DC_LAUNCH((k_spmm_wave<1, 8, false, true>), dim3(grid), dim3(256), 0, stream, ptr, other, w, x, ldx, nullptr,
+                  (int64_t)0, y, ldy, N, (int)F, nullptr, 0, 0, bias, relu);
+    return check_launch("dc_spmm_f32_bias_act");
 }
 
 extern "C" int dc_spmm_f32_pack(const int32_t *ptr, const int32_t *other, const float *w, const float *x,

@@ -145,13 +145,20 @@ class GCNConv(nn.Module):
     def graph(self, edge_index: Tensor, num_nodes: int, segments=None) -> GraphIndex:
         return graph_index(edge_index, num_nodes, segments=segments, **self.graph_flags())
 
-    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+    supports_fused_relu = True
+
+    def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False, next_conv=None) -> Tensor:
+        """``conv(x, edge_index)`` as PyG; ``relu=True`` fuses the ReLU the reference applies right after
+        (``models/model.py:71,77``) - with the bias - into the aggregation launch (``ops.gcn_aggregate``)."""
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
-        out = ops.propagate(g, self.lin(x), weighted=True)
+        h = self.lin(x)
+        if ops.fused_gnn_ok(h):
+            return ops.gcn_aggregate(g, h, self.bias, relu)
+        out = ops.propagate(g, h, weighted=True)
         if self.bias is not None:
             out = out + self.bias
-        return out
+        return torch.relu(out) if relu else out
 
 
 class GATConv(nn.Module):
@@ -186,16 +193,22 @@ class GATConv(nn.Module):
     def graph(self, edge_index: Tensor, num_nodes: int, segments=None) -> GraphIndex:
         return graph_index(edge_index, num_nodes, segments=segments, **self.graph_flags())
 
-    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+    supports_fused_relu = True
+
+    def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False, next_conv=None) -> Tensor:
+        """``conv(x, edge_index)`` as PyG; everything behind ``lin`` is one autograd node on fused kernels
+        (``ops.gat_conv``); ``relu=True`` also fuses the encoder's ReLU (``models/model.py:71,77``)."""
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
         h = self.lin(x)
+        if ops.fused_gnn_ok(h):
+            return ops.gat_conv(g, h, self.att_src, self.att_dst, self.bias, self.negative_slope, relu)
         a_src = (h * self.att_src.view(1, -1)).sum(-1)
         a_dst = (h * self.att_dst.view(1, -1)).sum(-1)
         out = ops.gat_aggregate(g, h, a_src, a_dst, self.negative_slope)
         if self.bias is not None:
             out = out + self.bias
-        return out
+        return torch.relu(out) if relu else out
 
 
 def knn(*args, **kwargs):

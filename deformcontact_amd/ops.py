@@ -1111,6 +1111,166 @@ def gat_aggregate(g: GraphIndex, h, a_src, a_dst, slope: float) -> torch.Tensor:
     return _GatAggregateFn.apply(g, h, a_src, a_dst, float(slope))
 
 
+
+# --------------------------------------------------------------------------- #
+# GCNConv / GATConv: aggregation + bias + ReLU as one node, row-wise passes fused (dc_gnn_epi.hip)
+# --------------------------------------------------------------------------- #
+FUSED_GNN_EPILOGUE = os.environ.get("DC_FUSED_GNN", "1") != "0"
+
+
+def fused_gnn_ok(h: torch.Tensor) -> bool:
+    """Widths / layouts the fused GCN / GAT layer kernels take (F % 4 == 0, F / 4 divides 256, aligned rows)."""
+    f = h.size(1)
+    return (FUSED_GNN_EPILOGUE and h.is_cuda and h.dtype == torch.float32 and f % 4 == 0 and 4 <= f <= 1024
+            and 256 % (f // 4) == 0)
+
+
+def _agg_bias_act(adj: SortedAdjacency, w: torch.Tensor, h: torch.Tensor, bias, relu: bool) -> torch.Tensor:
+    n, f = h.shape
+    y = torch.empty((n, f), dtype=torch.float32, device=h.device)
+    _lib.check(_lib.lib().dc_spmm_f32_bias_act(adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr(), h.data_ptr(),
+                                               _rowmajor(h, "h"), bias.data_ptr() if bias is not None else None,
+                                               int(relu), y.data_ptr(), f, n, f, current_stream_ptr(h.device)),
+               "dc_spmm_f32_bias_act")
+    return y
+
+
+def _mask_and_bias_grad(gy: torch.Tensor, y: Optional[torch.Tensor], bias_param, need_bias: bool):
+    """gm = gy * (y > 0) (y None: gm is gy) and the bias gradient sum_i gm[i, :] in one pass.  The bias gradient
+    goes straight into the bucket's view in direct mode (-> None), else it is returned."""
+    n, f = gy.shape
+    dev = gy.device
+    if y is None and not need_bias:
+        return gy, None
+    L = _lib.lib()
+    gm = torch.empty((n, f), dtype=torch.float32, device=dev) if y is not None else None
+    sink = _grad_sink(bias_param) if (need_bias and bias_param is not None) else None
+    direct = DIRECT_PARAM_GRAD and not torch.is_grad_enabled() and sink is not None
+    if need_bias:
+        gb = bias_param.grad if direct else torch.empty(f, dtype=torch.float32, device=dev)
+    else:
+        gb = torch.empty(f, dtype=torch.float32, device=dev)         # (the kernel always forms it: one pass either way)
+    nb = L.dc_colsum_workspace_bytes(n, f, 1)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    _lib.check(L.dc_mask_colsum_f32(gy.data_ptr(), gy.stride(0), y.data_ptr() if y is not None else None,
+                                    y.stride(0) if y is not None else 0, gm.data_ptr() if gm is not None else None,
+                                    gm.stride(0) if gm is not None else 0, n, f, ws.data_ptr(), ws.numel(),
+                                    gb.data_ptr(), int(direct), current_stream_ptr(dev)), "dc_mask_colsum_f32")
+    if direct:
+        sink.note_direct_write(torch.cuda.current_stream(dev))
+    return (gm if gm is not None else gy), (None if (direct or not need_bias) else gb)
+
+
+class _GcnAggFn(torch.autograd.Function):
+    """``act(A_hat h + bias)`` of a GCNConv layer (PyG gcn_conv.py: ``propagate`` + ``out + bias``, then the encoder's
+    ReLU, models/model.py:71,77) as ONE aggregation launch; backward: mask + bias gradient in one pass, then the
+    transposed aggregation."""
+
+    @staticmethod
+    def forward(ctx, g: GraphIndex, h, bias, relu: bool):
+        h = h.contiguous()
+        y = _agg_bias_act(g.fwd, g.fwd.w, h, bias, relu)
+        ctx.g, ctx.relu, ctx.bias_param = g, relu, bias
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        need_b = ctx.bias_param is not None and ctx.needs_input_grad[2]
+        gm, gb = _mask_and_bias_grad(gy, y, ctx.bias_param, need_b)
+        gh = hop(ctx.g.bwd, gm, weighted=True) if ctx.needs_input_grad[1] else None
+        return None, gh, gb, None
+
+
+def gcn_aggregate(g: GraphIndex, h: torch.Tensor, bias, relu: bool = False) -> torch.Tensor:
+    return _GcnAggFn.apply(g, h, bias, bool(relu))
+
+
+class _GatConvFn(torch.autograd.Function):
+    """Everything of a GATConv layer (heads = 1) behind its ``lin``: both attention dot products in one pass over h,
+    edge softmax, ``act(sum_j a_ij h_j + bias)`` as one aggregation launch; backward: mask + bias gradient in one
+    pass, transposed aggregation, SDDMM + softmax backward, and the dot products' backward (rank-one updates of dh
+    and the two attention-vector gradients) in one pass (PyG gat_conv.py, utils/_softmax.py)."""
+
+    @staticmethod
+    def forward(ctx, g: GraphIndex, h, att_src, att_dst, bias, slope: float, relu: bool):
+        L = _lib.lib()
+        h = h.contiguous()
+        n, f = h.shape
+        dev = h.device
+        st = current_stream_ptr(dev)
+        a_s, a_d = att_src.reshape(-1).contiguous(), att_dst.reshape(-1).contiguous()
+        a_src = torch.empty(n, dtype=torch.float32, device=dev)
+        a_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_gat_alpha_fwd(h.data_ptr(), f, a_s.data_ptr(), a_d.data_ptr(), a_src.data_ptr(),
+                                      a_dst.data_ptr(), n, f, st), "dc_gat_alpha_fwd")
+        alpha = torch.zeros(max(g.capacity, 1), dtype=torch.float32, device=dev)
+        _lib.check(L.dc_gat_edge_softmax_fwd(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), a_src.data_ptr(),
+                                             a_dst.data_ptr(), slope, alpha.data_ptr(), n, st),
+                   "dc_gat_edge_softmax_fwd")
+        y = _agg_bias_act(g.fwd, alpha, h, bias, relu)
+        ctx.g, ctx.slope, ctx.relu = g, slope, relu
+        ctx.params = (att_src, att_dst, bias)
+        ctx.save_for_backward(h, a_src, a_dst, alpha, a_s, a_d, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        h, a_src, a_dst, alpha, a_s, a_d, y = ctx.saved_tensors
+        g, slope = ctx.g, ctx.slope
+        att_src, att_dst, bias = ctx.params
+        gy = gy.contiguous()
+        n, f = h.shape
+        dev = h.device
+        st = current_stream_ptr(dev)
+        need_b = bias is not None and ctx.needs_input_grad[4]
+        gm, gb = _mask_and_bias_grad(gy, y, bias, need_b)
+        cap = max(g.capacity, 1)
+        b2f = g.bwd_to_fwd()
+        cnt = g.fwd.ptr[-1:]
+        alpha_b = torch.zeros(cap, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_gather_f32(alpha.data_ptr(), b2f.data_ptr(), alpha_b.data_ptr(), cnt.data_ptr(), g.capacity, st),
+                   "dc_gather_f32")
+        gh = _spmm_w(g.bwd, alpha_b, gm)
+        galpha = torch.zeros(cap, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_sddmm_f32(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), gm.data_ptr(), f, h.data_ptr(), f,
+                                  galpha.data_ptr(), n, f, st), "dc_sddmm_f32")
+        ge = torch.zeros(cap, dtype=torch.float32, device=dev)
+        g_a_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_gat_edge_softmax_bwd(g.fwd.ptr.data_ptr(), g.fwd.other.data_ptr(), a_src.data_ptr(),
+                                             a_dst.data_ptr(), slope, alpha.data_ptr(), galpha.data_ptr(),
+                                             ge.data_ptr(), g_a_dst.data_ptr(), n, st), "dc_gat_edge_softmax_bwd")
+        g_a_src = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(L.dc_segment_sum_f32(g.bwd.ptr.data_ptr(), b2f.data_ptr(), ge.data_ptr(), g_a_src.data_ptr(), n, st),
+                   "dc_segment_sum_f32")
+        # the attention dot products' backward: gh += ga_src att_src + ga_dst att_dst, the two vector gradients
+        sinks = [_grad_sink(att_src), _grad_sink(att_dst)]
+        direct = (DIRECT_PARAM_GRAD and not torch.is_grad_enabled() and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+                  and sinks[0] is not None and sinks[1] is sinks[0])
+        if direct:
+            gs, gd = att_src.grad.view(-1), att_dst.grad.view(-1)
+        else:
+            gs = torch.empty(f, dtype=torch.float32, device=dev)
+            gd = torch.empty(f, dtype=torch.float32, device=dev)
+        nb = L.dc_colsum_workspace_bytes(n, f, 2)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        _lib.check(L.dc_gat_alpha_bwd(h.data_ptr(), f, g_a_src.data_ptr(), g_a_dst.data_ptr(), a_s.data_ptr(),
+                                      a_d.data_ptr(), gh.data_ptr(), f, n, f, ws.data_ptr(), ws.numel(), gs.data_ptr(),
+                                      gd.data_ptr(), int(direct), st), "dc_gat_alpha_bwd")
+        if direct:
+            sinks[0].note_direct_write(torch.cuda.current_stream(dev))
+            gs = gd = None
+        else:
+            gs, gd = gs.view_as(att_src), gd.view_as(att_dst)
+        return None, gh, gs, gd, gb, None, None
+
+
+def gat_conv(g: GraphIndex, h, att_src, att_dst, bias, slope: float, relu: bool = False) -> torch.Tensor:
+    return _GatConvFn.apply(g, h, att_src, att_dst, bias, float(slope), bool(relu))
+
 # --------------------------------------------------------------------------- #
 # the two training losses in one pass (train.py:51-53, models/losses.py:7-19)
 # --------------------------------------------------------------------------- #

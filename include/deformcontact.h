@@ -502,6 +502,34 @@ int dc_invert_perm(const int32_t *perm, const int32_t *ptr_last /* &ptr[N] */, i
 int dc_compose_perm(const int32_t *a, const int32_t *b, int32_t *out, const int32_t *count_ptr,
                     int64_t cap, dc_stream_t stream);
 
+/* ---- GCNConv / GATConv: the row-wise passes around the aggregation, fused (dc_gnn_epi.hip) ----
+ * PyG gcn_conv.py / gat_conv.py: out = propagate(...) + bias; the encoder loop then applies relu
+ * (models/model.py:71,77); GAT: alpha_src = (h * att_src).sum(-1), alpha_dst likewise.
+ *   dc_spmm_f32_bias_act : y[i,:] = act(sum_p w[p] x[other[p],:] + bias)  (bias may be NULL, relu 0/1);
+ *                          the sum as dc_spmm_f32, bias added to the finished sum: same values as the
+ *                          three separate passes
+ *   dc_mask_colsum_f32   : gm = g * (y_mask > 0) (y_mask NULL: gm = g; gm NULL: not written) and
+ *                          colsum[c] (+)= sum_i gm[i,c] (the bias gradient), per-block partials combined
+ *                          in block order - deterministic; workspace of dc_colsum_workspace_bytes(N,F,1)
+ *   dc_gat_alpha_fwd     : a_src[i] = h[i,:] . att_src, a_dst[i] = h[i,:] . att_dst, one pass over h
+ *   dc_gat_alpha_bwd     : gh[i,:] += ga_src[i] att_src + ga_dst[i] att_dst (gh holds the aggregation's
+ *                          gradient), g_att_src (+)= sum_i ga_src[i] h[i,:], g_att_dst likewise; workspace
+ *                          of dc_colsum_workspace_bytes(N,F,2)
+ * F % 4 == 0 and 16-byte aligned rows; the column-sum passes need F/4 to divide 256. */
+int dc_spmm_f32_bias_act(const int32_t *ptr, const int32_t *other, const float *w, const float *x,
+                         int64_t ldx, const float *bias, int relu, float *y, int64_t ldy, int64_t N,
+                         int64_t F, dc_stream_t stream);
+int64_t dc_colsum_workspace_bytes(int64_t N, int64_t F, int nvec);
+int dc_mask_colsum_f32(const float *g, int64_t ldg, const float *y_mask, int64_t ldy, float *gm,
+                       int64_t ldgm, int64_t N, int64_t F, void *workspace, int64_t workspace_bytes,
+                       float *colsum, int accumulate, dc_stream_t stream);
+int dc_gat_alpha_fwd(const float *h, int64_t ldh, const float *att_src, const float *att_dst, float *a_src,
+                     float *a_dst, int64_t N, int64_t F, dc_stream_t stream);
+int dc_gat_alpha_bwd(const float *h, int64_t ldh, const float *ga_src, const float *ga_dst,
+                     const float *att_src, const float *att_dst, float *gh, int64_t ldgh, int64_t N,
+                     int64_t F, void *workspace, int64_t workspace_bytes, float *g_att_src,
+                     float *g_att_dst, int accumulate, dc_stream_t stream);
+
 /* ---- GATConv edge terms (nn/conv/gat_conv.py edge_update + utils/_softmax.py) -
  * Only reached when the reference is configured with backbone "GATConv"
  * (models/model.py:39).  Arrays are in key_row=1 order of a self_loops=1 set;
