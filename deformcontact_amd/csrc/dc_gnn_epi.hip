@@ -15,7 +15,7 @@
 
 namespace dc {
 
-constexpr int kEpiRows = 128;                       // rows per block of the column-sum passes
+constexpr int kEpiRows = 32;                        // rows per block of the column-sum passes (1,024 blocks at N = 32,768)
 
 // block = kEpiRows rows; thread t owns 4 columns (c = 4 (t % (F/4))) of the row group t / (F/4): for F = 256, 64 threads
 // span a row and 4 rows are walked side by side
@@ -50,14 +50,18 @@ k_mask_colsum(const float *__restrict__ g, int64_t ldg, const float *__restrict_
     }
 }
 
-// out[c] (+)= sum over blocks of partial[b * stride + c], in block order
+// out[c] (+)= sum over blocks of partial[b * stride + c]: one wave per column, lane l sums the blocks l, l + 64, ...
+// in order, the 64 lane sums meet in a fixed butterfly - the same association every run (deterministic), and 64 loads
+// in flight per column instead of one thread walking hundreds of partials one after the other
 __global__ void __launch_bounds__(256)
 k_colsum_final(const float *__restrict__ partial, int64_t nblocks, int64_t stride, int F, float *out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= F) return;
     float s = 0.f;
-    for (int64_t b = 0; b < nblocks; ++b) s = s + partial[b * stride + c];
-    out[c] = accumulate ? out[c] + s : s;
+    for (int64_t b = lane; b < nblocks; b += 64) s = s + partial[b * stride + c];
+#pragma unroll
+    for (int q = 32; q >= 1; q >>= 1) s = s + __shfl_xor(s, q);
+    if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 // one wave per row: a_src[i] = sum_c h[i, c] att_src[c], a_dst likewise
@@ -150,7 +154,7 @@ extern "C" int dc_mask_colsum_f32(const float *g, int64_t ldg, const float *y_ma
     if (nb > 0)
         DC_LAUNCH(k_mask_colsum, dim3((unsigned)nb), dim3(256), 0, stream, g, ldg, y_mask, ldy, gm, ldgm, N, (int)F,
                   (float *)workspace);
-    DC_LAUNCH(k_colsum_final, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, stream, (const float *)workspace, nb, F,
+    DC_LAUNCH(k_colsum_final, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, (const float *)workspace, nb, F,
               (int)F, colsum, accumulate);
     return check_launch("dc_mask_colsum_f32");
 }
@@ -185,9 +189,9 @@ extern "C" int dc_gat_alpha_bwd(const float *h, int64_t ldh, const float *ga_src
                   gh, ldgh, N, (int)F, (float *)workspace);
     // every block's partial row holds the two column vectors [src | dst]
     const float *ws = (const float *)workspace;
-    DC_LAUNCH(k_colsum_final, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, stream, ws, nb, 2 * F, (int)F, g_att_src,
+    DC_LAUNCH(k_colsum_final, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, ws, nb, 2 * F, (int)F, g_att_src,
               accumulate);
-    DC_LAUNCH(k_colsum_final, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, stream, ws + F, nb, 2 * F, (int)F,
+    DC_LAUNCH(k_colsum_final, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, ws + F, nb, 2 * F, (int)F,
               g_att_dst, accumulate);
     return check_launch("dc_gat_alpha_bwd");
 }
