@@ -73,6 +73,10 @@ _SIGNATURES = {
     "dc_kernel_trace_dump": (c_int64, [c_char_p, c_int64]),
     "dc_hash_i64": (c_int, [_vp, c_int64, _vp, _vp]),
     "dc_morton_codes": (c_int, [_vp, c_int64, c_int64, POINTER(c_float), POINTER(c_float), _vp, _vp]),
+    "dc_morton_order_workspace_bytes": (c_int64, [c_int64]),
+    "dc_morton_order": (c_int, [_vp, c_int64, c_int64, _vp, _vp, _vp, c_int64, _vp]),
+    "dc_relabel_edges": (c_int, [_vp, c_int64, _vp, c_int64, _vp, _vp]),
+    "dc_gather_rows": (c_int, [_vp, c_int64, _vp, _vp, c_int64, c_int64, c_int64, _vp]),
     "dc_invert_perm": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
     "dc_spmm_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int64, c_int64,
                             c_int64, _vp]),

@@ -1,0 +1,168 @@
+// dc_order.hip -- node reordering of ONE big graph on the device (BASELINE.json configs[4]: the 100k-point radius
+// graph of /root/reference/utils/pointcloud_utils.py:7-13): Z-order permutation of a point cloud, edge relabelling and
+// the row gathers that apply / undo it - one C entry each, no host synchronisation (hipGraph-capturable), replacing
+// the stock-PyTorch sequence (amin / amax + .cpu(), torch.sort, two index_select, an indexed assignment) that was
+// 44 % on top of the forward + backward it prepared.
+// The key sort itself is rocPRIM's device radix sort (/opt/rocm/include/rocprim): preprocessing, not a hot-path kernel.
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "dc_common.h"
+
+namespace dc {
+
+__device__ __forceinline__ unsigned ord_of(float f) {           // order-preserving map float -> unsigned
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_inv(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ unsigned spread10b(unsigned v) {      // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ void k_bbox_init(unsigned *bbox) {
+    if (threadIdx.x < 3) bbox[threadIdx.x] = 0xFFFFFFFFu;         // minima
+    else if (threadIdx.x < 6) bbox[threadIdx.x] = 0u;             // maxima
+}
+
+__global__ void __launch_bounds__(256)
+k_bbox(const float *__restrict__ pos, int64_t ld, int64_t n, unsigned *bbox) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pos[i * ld + a];
+            lo[a] = fminf(lo[a], v), hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int q = 32; q >= 1; q >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], q));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], q));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&bbox[a], ord_of(lo[a]));
+            atomicMax(&bbox[3 + a], ord_of(hi[a]));
+        }
+    }
+}
+
+// 30-bit Z-order code of every point (each axis mapped from its extent to 10 bits), value = the point's index
+__global__ void __launch_bounds__(256)
+k_codes(const float *__restrict__ pos, int64_t ld, int64_t n, const unsigned *__restrict__ bbox, unsigned *codes,
+        int32_t *vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned c = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = ord_inv(bbox[a]), hi = ord_inv(bbox[3 + a]);
+        const float sc = 1.0f / fmaxf(hi - lo, 1e-30f);
+        const float t = (pos[i * ld + a] - lo) * sc * 1024.0f;
+        const unsigned q = (unsigned)(t < 0.f ? 0.f : (t > 1023.f ? 1023.f : t));
+        c |= spread10b(q) << a;
+    }
+    codes[i] = c;
+    vals[i] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(256)
+k_invert_order(const int32_t *__restrict__ perm, int32_t *inv, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[perm[i]] = (int32_t)i;
+}
+
+__global__ void __launch_bounds__(256)
+k_relabel(const int64_t *__restrict__ ei, int64_t count, const int32_t *__restrict__ inv, int64_t n, int64_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t v = ei[i];
+    out[i] = ((uint64_t)v < (uint64_t)n) ? (int64_t)inv[v] : v;      // out-of-range ids stay what they are (flagged later)
+}
+
+// out row i = x row idx[i]; 16 bytes per lane, a row's lanes side by side
+__global__ void __launch_bounds__(256)
+k_gather_rows(const char *__restrict__ x, int64_t ldx, const int32_t *__restrict__ idx, char *out, int64_t ldo,
+              int64_t n, int vec_per_row) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = t / vec_per_row;
+    if (row >= n) return;
+    const int v = (int)(t - row * vec_per_row);
+    *reinterpret_cast<uint4 *>(out + row * ldo + 16 * v) =
+        *reinterpret_cast<const uint4 *>(x + (int64_t)idx[row] * ldx + 16 * v);
+}
+
+static inline int64_t al256(int64_t b) { return (b + 255) & ~int64_t(255); }
+static size_t sort_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr,
+                                    (int32_t *)nullptr, (size_t)n, 0, 30, (hipStream_t)0);
+    return bytes;
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+extern "C" int64_t dc_morton_order_workspace_bytes(int64_t n) {
+    if (n < 0 || n >= (int64_t)INT32_MAX) return -1;
+    return 256 + 3 * al256(4 * n) + al256((int64_t)sort_temp_bytes(n > 0 ? n : 1));
+}
+
+extern "C" int dc_morton_order(const float *pos, int64_t ld, int64_t n, int32_t *perm, int32_t *inv, void *workspace,
+                               int64_t workspace_bytes, dc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DC_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX && ld >= 3, "dc_morton_order: bad sizes");
+    if (n == 0) return DC_OK;
+    DC_REQUIRE(pos && perm && inv && workspace && workspace_bytes >= dc_morton_order_workspace_bytes(n),
+               "dc_morton_order: null pointer or workspace too small");
+    char *ws = (char *)workspace;
+    unsigned *bbox = (unsigned *)ws;
+    unsigned *codes_in = (unsigned *)(ws + 256), *codes_out = (unsigned *)(ws + 256 + al256(4 * n));
+    int32_t *vals_in = (int32_t *)(ws + 256 + 2 * al256(4 * n));
+    void *temp = ws + 256 + 3 * al256(4 * n);
+    size_t temp_bytes = sort_temp_bytes(n);
+    DC_LAUNCH(k_bbox_init, dim3(1), dim3(64), 0, stream, bbox);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    DC_LAUNCH(k_bbox, dim3(nb < 512 ? nb : 512), dim3(256), 0, stream, pos, ld, n, bbox);
+    DC_LAUNCH(k_codes, dim3(nb), dim3(256), 0, stream, pos, ld, n, (const unsigned *)bbox, codes_in, vals_in);
+    trace_kernel("rocprim::radix_sort_pairs");
+    // stable: points with equal codes keep their original order (what torch.sort(stable=True) gave)
+    if (rocprim::radix_sort_pairs(temp, temp_bytes, codes_in, codes_out, vals_in, perm, (size_t)n, 0, 30, stream) !=
+        hipSuccess)
+        return check_launch("dc_morton_order (sort)");
+    DC_LAUNCH(k_invert_order, dim3(nb), dim3(256), 0, stream, (const int32_t *)perm, inv, n);
+    return check_launch("dc_morton_order");
+}
+
+extern "C" int dc_relabel_edges(const int64_t *ei, int64_t count, const int32_t *inv, int64_t n, int64_t *out,
+                                dc_stream_t stream) {
+    DC_REQUIRE(count >= 0 && n >= 0, "dc_relabel_edges: negative size");
+    if (count == 0) return DC_OK;
+    DC_REQUIRE(ei && inv && out, "dc_relabel_edges: null pointer");
+    DC_LAUNCH(k_relabel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ei, count, inv, n, out);
+    return check_launch("dc_relabel_edges");
+}
+
+extern "C" int dc_gather_rows(const void *x, int64_t ldx_bytes, const int32_t *idx, void *out, int64_t ldo_bytes,
+                              int64_t n, int64_t row_bytes, dc_stream_t stream) {
+    DC_REQUIRE(n >= 0 && row_bytes >= 0, "dc_gather_rows: negative size");
+    if (n == 0 || row_bytes == 0) return DC_OK;
+    DC_REQUIRE(x && idx && out && x != out, "dc_gather_rows: null pointer / in place");
+    DC_REQUIRE(row_bytes % 16 == 0 && ldx_bytes % 16 == 0 && ldo_bytes % 16 == 0 && ((uintptr_t)x & 15) == 0 &&
+                   ((uintptr_t)out & 15) == 0 && ldx_bytes >= row_bytes && ldo_bytes >= row_bytes,
+               "dc_gather_rows: rows must be whole 16-byte vectors (row_bytes=%lld)", (long long)row_bytes);
+    const int64_t vpr = row_bytes / 16, total = n * vpr;
+    DC_REQUIRE(total < ((int64_t)1 << 40) && vpr < (1 << 20), "dc_gather_rows: too large");
+    DC_LAUNCH(k_gather_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const char *)x,
+              ldx_bytes, idx, (char *)out, ldo_bytes, n, (int)vpr);
+    return check_launch("dc_gather_rows");
+}

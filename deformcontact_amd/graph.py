@@ -443,7 +443,7 @@ def content_hash(t: torch.Tensor) -> int:
 
 
 class NodeOrder:
-    """A relabelling of the nodes of one graph: ``perm[new] = old``.
+    """A relabelling of the nodes of one graph: ``perm[new] = old``, ``inv[old] = new`` (int32, on the device).
 
     Message passing commutes with it: run the convs on ``apply(x)`` / ``relabel(edge_index)`` and
     ``undo`` the result.  The sorted adjacency orders every node's neighbours by EDGE id, which the
@@ -451,40 +451,59 @@ class NodeOrder:
     to the unordered computation; only where rows live in memory changes.  ``morton(pos)`` sorts
     by Z-order code: for a radius graph over an unordered point cloud
     (``/root/reference/utils/pointcloud_utils.py:7-13``) that turns the hop's neighbour gathers from
-    random reads of the whole feature matrix into reads of nearby rows (one XCD's L2)."""
+    random reads of the whole feature matrix into reads of nearby rows (one XCD's L2).
+    Everything runs on the library's kernels (``dc_morton_order`` / ``dc_relabel_edges`` / ``dc_gather_rows``),
+    without a host synchronisation: ordering a new cloud can sit inside a captured hipGraph."""
 
-    def __init__(self, perm: torch.Tensor):
-        self.perm = perm.to(torch.int64).contiguous()
-        self.inv = torch.empty_like(self.perm)
-        self.inv[self.perm] = torch.arange(self.perm.numel(), device=self.perm.device)
+    def __init__(self, perm: torch.Tensor, inv: Optional[torch.Tensor] = None):
+        self.perm = perm.to(torch.int32).contiguous()
+        if inv is None:
+            inv = torch.empty_like(self.perm)
+            inv[self.perm.long()] = torch.arange(self.perm.numel(), device=self.perm.device, dtype=torch.int32)
+        self.inv = inv.to(torch.int32).contiguous()
 
     @classmethod
     def morton(cls, pos: torch.Tensor) -> "NodeOrder":
         _require_cuda(pos, "pos")
         if pos.dim() != 2 or pos.size(1) < 3 or pos.dtype != torch.float32:
             raise ValueError("NodeOrder.morton: pos must be float32 [N, >=3]")
-        import ctypes
         n = pos.size(0)
         pos = pos if pos.stride(1) == 1 else pos.contiguous()
-        lo = pos[:, :3].amin(0).cpu() if n else torch.zeros(3)
-        hi = pos[:, :3].amax(0).cpu() if n else torch.ones(3)
-        inv = [1.0 / max(float(hi[a] - lo[a]), 1e-30) for a in range(3)]
-        codes = torch.empty(n, dtype=torch.int64, device=pos.device)
-        rc = _lib.lib().dc_morton_codes(pos.data_ptr(), pos.stride(0), n,
-                                        (ctypes.c_float * 3)(*[float(v) for v in lo]),
-                                        (ctypes.c_float * 3)(*inv), codes.data_ptr(),
-                                        current_stream_ptr(pos.device))
-        _lib.check(rc, "dc_morton_codes")
-        return cls(torch.sort(codes, stable=True).indices)
+        L = _lib.lib()
+        perm = torch.empty(n, dtype=torch.int32, device=pos.device)
+        inv = torch.empty(n, dtype=torch.int32, device=pos.device)
+        ws = torch.empty(max(int(L.dc_morton_order_workspace_bytes(n)), 16), dtype=torch.uint8, device=pos.device)
+        _lib.check(L.dc_morton_order(pos.data_ptr(), pos.stride(0), n, perm.data_ptr(), inv.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), current_stream_ptr(pos.device)), "dc_morton_order")
+        return cls(perm, inv)
 
     def relabel(self, edge_index: torch.Tensor) -> torch.Tensor:
-        return self.inv[edge_index]
+        _require_cuda(edge_index, "edge_index")
+        ei = edge_index.contiguous()
+        out = torch.empty_like(ei)
+        _lib.check(_lib.lib().dc_relabel_edges(ei.data_ptr(), ei.numel(), self.inv.data_ptr(), self.inv.numel(),
+                                               out.data_ptr(), current_stream_ptr(ei.device)), "dc_relabel_edges")
+        return out
+
+    def _gather(self, x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        _require_cuda(x, "x")
+        if x.dim() != 2 or x.size(0) != idx.numel():
+            raise ValueError("NodeOrder: x must be [N, F] with N = number of nodes")
+        x = x if x.stride(1) == 1 else x.contiguous()
+        esz = x.element_size()
+        row_bytes, ld_bytes = x.size(1) * esz, x.stride(0) * esz
+        if row_bytes % 16 or ld_bytes % 16 or x.data_ptr() % 16:
+            return x.index_select(0, idx.long())              # odd widths: stock gather
+        out = torch.empty((x.size(0), x.size(1)), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().dc_gather_rows(x.data_ptr(), ld_bytes, idx.data_ptr(), out.data_ptr(), row_bytes,
+                                             x.size(0), row_bytes, current_stream_ptr(x.device)), "dc_gather_rows")
+        return out
 
     def apply(self, x: torch.Tensor) -> torch.Tensor:
-        return x.index_select(0, self.perm)
+        return self._gather(x, self.perm)
 
     def undo(self, y: torch.Tensor) -> torch.Tensor:
-        return y.index_select(0, self.inv)
+        return self._gather(y, self.inv)
 
 
 def register(edge_index: torch.Tensor, g: GraphIndex) -> None:

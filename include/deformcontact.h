@@ -143,6 +143,23 @@ int dc_graph_build_segmented(const int64_t *edge_index, int64_t E, int64_t N,
 int dc_morton_codes(const float *pos, int64_t ld, int64_t n, const float *lo_host,
                     const float *inv_extent_host, int64_t *codes, dc_stream_t stream);
 
+/* ---- node reordering of one big graph, on the device (dc_order.hip; BASELINE.json configs[4]) ----
+ * dc_morton_order: Z-order permutation of a point cloud pos [n, >= 3] (fp32, leading dimension ld): the bounding
+ *   box, the 30-bit codes (10 bits per axis over its extent), a STABLE key sort (rocPRIM device radix sort) and the
+ *   inverse - perm[new] = old, inv[old] = new (int32) - without a host synchronisation (hipGraph-capturable).
+ *   Running a conv stack on gather_rows(x, perm) / relabel(edge_index) and putting the result back with
+ *   gather_rows(y, inv) turns the hops' neighbour gathers of a radius graph (utils/pointcloud_utils.py:10) into reads
+ *   of nearby rows; outputs are bit-identical to the unordered run (a row's neighbours stay in edge order).
+ * dc_relabel_edges: out[i] = inv[ei[i]] over `count` int64 ids (both rows of edge_index at once).
+ * dc_gather_rows  : out row i = x row idx[i], rows of row_bytes bytes (a multiple of 16; any element type). */
+int64_t dc_morton_order_workspace_bytes(int64_t n);
+int dc_morton_order(const float *pos, int64_t ld, int64_t n, int32_t *perm, int32_t *inv, void *workspace,
+                    int64_t workspace_bytes, dc_stream_t stream);
+int dc_relabel_edges(const int64_t *ei, int64_t count, const int32_t *inv, int64_t n, int64_t *out,
+                     dc_stream_t stream);
+int dc_gather_rows(const void *x, int64_t ldx_bytes, const int32_t *idx, void *out, int64_t ldo_bytes, int64_t n,
+                   int64_t row_bytes, dc_stream_t stream);
+
 /* Order-dependent 64-bit content hash of an int64 device array (e.g. edge_index) into
  * out[1] (device): the key of the host's per-topology cache (loaders.TopologyCache), so a batch
  * whose edge_index has been seen before reuses its sorted adjacency. */
