@@ -158,7 +158,7 @@ def test_fused_contact_losses_match_reference_formulation_and_golden():
     model = load_model(SMALL).to(dev)
     collated = _batches(2, 2)[0]
     rest, deff, rig = loaders.to_batches(collated, dev)
-    assert deff._dc_edges_equal == (True,)
+    assert deff._dc_edges_equal[0] is True
     calls = []
     real = ops.contact_losses
     ops.contact_losses = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
@@ -179,7 +179,7 @@ def test_fused_contact_losses_match_reference_formulation_and_golden():
         d2.edge_index = torch.flip(d.edge_index, dims=[1])
         defs2.append(d2)
     rest2, deff2, rig2 = loaders.to_batches((names, rests, tuple(defs2), meta, rigids), dev)
-    assert deff2._dc_edges_equal == (False,)
+    assert deff2._dc_edges_equal[0] is False
     out2 = dc_train.losses(model, rest2, deff2, rig2)
     assert len(calls) == 1                                               # stock formulation, no fused kernel
     from tests.helpers import G as _G
@@ -192,7 +192,8 @@ def test_fused_contact_losses_match_reference_formulation_and_golden():
     # debug assert: a batch MARKED equal whose device content differs poisons the losses
     old_dbg, dc_train.LOSS_DEBUG = dc_train.LOSS_DEBUG, True
     try:
-        deff.edge_index = deff.edge_index.clone()
+        # (edited IN PLACE on the device copy, which the host-side mark cannot see; ASSIGNING a new edge_index would
+        # drop the mark - tests/test_host_cpu.py - and take the stock formulation)
         deff.edge_index[0, 0] = (deff.edge_index[0, 0] + 1) % 5
         assert torch.isnan(dc_train.losses(model, rest, deff, rig)["loss"])
     finally:

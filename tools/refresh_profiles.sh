@@ -31,7 +31,11 @@ for M in 0 1; do
     DC_MERGE_BRANCHES=$M timeout -s KILL 400 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$R/$O/pmc_hop_l2_$M" -- python3 "$R/tools/pmc_hop.py" > "$R/$O/pmc_hop_l2_$M.log" 2>&1
     (cd "$R" && python tools/pmc_hop.py --parse-l2 "$O/pmc_hop_l2_$M" > "$O/hop_l2_requests_merged$M.json" 2>> "$O/dense_pmc.err")
 done
-(cd "$R" && timeout -s KILL 300 python tools/exp/hop_win.py > "$O/hop_window_experiment.txt" 2>&1)
+# r04: the 3-hop chain launches (dc_hop_chain_f32): timing against 12 single hops, SQ / L2 / HBM counters, ablations
+(cd "$R" && timeout -s KILL 300 python tools/exp/hop_chain.py > "$O/hop_chain_timing.txt" 2>&1)
+(cd "$R" && timeout -s KILL 900 bash tools/exp/pmc_chain.sh "$O/pmc_chain" > "$O/pmc_chain.log" 2>&1)
+(cd "$R" && timeout -s KILL 600 python tools/exp/hop_chain_abl.py 0 1 2 3 > "$O/hop_chain_ablation.txt" 2>&1)
+(cd "$R" && cp gpurun_out/parity_distances.json "$O/parity_distances.json" 2>/dev/null)
 (cd "$R" && timeout -s KILL 300 python tools/exp/build_time.py > "$O/graph_build_time.txt" 2>&1)
 (cd "$R" && DC_BF16_X=0 timeout -s KILL 300 python tools/exp/bf16_dense.py > "$O/bf16_dense_128tiles.txt" 2>&1; DC_BF16_X=1 timeout -s KILL 300 python tools/exp/bf16_dense.py > "$O/bf16_dense_256tiles.txt" 2>&1)
 (cd "$R" && timeout -s KILL 300 python tools/exp/gap_parts.py > "$O/new_batch_gap_parts.txt" 2>&1)
