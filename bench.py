@@ -282,7 +282,7 @@ def dense_roofline(dev, n_s: int, n_r: int, reps: int, graphs=None):
     prod = (3 if h2 else ops.DENSE_PRODUCTS) if ops.DENSE_SPLIT_BF16 else 1
     peak = 2500.0 if ops.DENSE_SPLIT_BF16 else 157.3
     achieved = prod * flops / ms / 1e9
-    res = {"bound": "mfma", "kernel": ("dc::k_fwd_h2w x2 (forward, dX in forward shape) / k_dw_h2w "
+    res = {"bound": "mfma", "kernel": ("dc::k_fwd_h2d x2 (forward, dX in forward shape; both operands by LDS-DMA, MFMA waves + loading waves) / k_dw_h2w "
                                        "(layer-2 dense block, fp16x2, 128 x 256 tiles)" if h2 else
                                        "dc::k_fwd_split / k_dx_split / k_dw_split (layer-2 dense block)")
            if ops.DENSE_SPLIT_BF16 else "dc::k_fwd_fast / k_dx_fast / k_dw_fast",
@@ -400,7 +400,7 @@ def dense_roofline_grouped(dev, parts, reps: int):
     ms = sum(sum(v) for v in t.values()) / len(evs)
     flops = 3 * 2.0 * n_real * fi * nseg * fo
     achieved = 3 * flops / ms / 1e9
-    return {"bound": "mfma", "kernel": "dc::k_fwd_h2w x2 (grouped forward, grouped dX in forward shape) / k_dw_h2w "
+    return {"bound": "mfma", "kernel": "dc::k_fwd_h2d x2 (grouped forward, grouped dX in forward shape) / k_dw_h2w "
                                        "(grouped layer-2 dense blocks of BOTH branches, fp16x2, 128 x 256 tiles)",
             "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
             "executed": "3 fp16 MFMA products per fp32 product tile",
@@ -1186,6 +1186,7 @@ def main():
                         "), replayed from a hipGraph as the step is (no host launch cost), HIP events on the launch "
                         "stream, launch gaps included",
             "cases_isolated": per_case,
+            "cases_isolated_kernel": "dc::k_spmm_wave<4,8,true>, ONE hop per launch (ops.hop), the same launch back to back",
         }
         if chained:
             # the fused launch against what IT must move (1 block in + 3 out per chain): the honest HBM fraction of the

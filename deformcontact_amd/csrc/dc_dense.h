@@ -230,6 +230,8 @@ bool dw_h2w_launch(const DwParams &p, hipStream_t hs);
 bool fwd_h2_launch(const FwdParams &p, int mb, hipStream_t hs);
 // 128 x 256 tiles, BK = 32, for the wide layers (dc_dense_h2w.hip); tried first by fwd_h2_launch
 bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs);
+// the same tiles with both operands by LDS-DMA and the waves split by role (dc_dense_h2d.hip); tried first by fwd_h2w_launch
+bool fwd_h2d_launch(const FwdParams &p, hipStream_t hs);
 // wt[s][f][o] = ws[s][o][f]
 void transpose_weights_launch(const float *const *ws, int nseg, int64_t Fo, int64_t Fi, float *wt,
                               hipStream_t hs);

@@ -316,6 +316,7 @@ bool fwd_h2w_launch(const FwdParams &p, hipStream_t hs) {
     const int64_t tiles = ((p.N + kWBM - 1) / kWBM) * ((p.Fo + kWBN - 1) / kWBN);
     static const int min_tiles = hw_env_int("DC_H2_WIDE_MIN_TILES", 128);
     if ((tiles * ks < min_tiles && p.grp.n < 1 && !p.x2) || tiles * ks >= (int64_t)INT32_MAX) return false;
+    if (fwd_h2d_launch(p, hs)) return true;            // both operands by LDS-DMA, waves split by role (dc_dense_h2d.hip)
     const dim3 gd((unsigned)(tiles * ks)), bd(512);
     if (p.x2) {
         if (!p.x2_coef || ks > 1 || !hw_al16(p.x2)) return false;

@@ -49,6 +49,8 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     path = os.environ.get("DC_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_distances.json"))
     os.makedirs(os.path.dirname(path), exist_ok=True)
+    special = [r for r in log if r.get("special")]
+    log = [r for r in log if not r.get("special")]
     ds = [r["hip_vs_fp32_oracle"] for r in log if r["hip_vs_fp32_oracle"] is not None]
     fired = [r for r in log if r["float64_widening_fired"]]
     summary = {"comparisons": len(log), "float64_widening_fired": len(fired),
@@ -57,6 +59,9 @@ def pytest_sessionfinish(session, exitstatus):
                                                                   if not r["float64_widening_fired"]
                                                                   and r["hip_vs_fp32_oracle"] is not None), default=None),
                "worst_hip_vs_float64_where_widened": max((r["hip_vs_float64"] for r in fired), default=None),
-               "tests": len({r["test"] for r in log})}
+               "worst_ratio_hip_to_oracle_distance_from_float64_where_widened": max(
+                   (r["hip_vs_float64"] / max(r["fp32_oracle_vs_float64"], 1e-30) for r in fired
+                    if r["hip_vs_float64"] is not None and r["hip_vs_float64"] > r["tol"]), default=None),
+               "tests": len({r["test"] for r in log}), "special_comparisons": len(special)}
     with open(path, "w") as f:
-        json.dump({"summary": summary, "widened": fired, "all": log}, f, indent=1)
+        json.dump({"summary": summary, "widened": fired, "special": special, "all": log}, f, indent=1)

@@ -42,9 +42,12 @@ def row_rel_err(a, b):
 PARITY_LOG = []
 
 
-def record_parity(name, d, widened=False, e_h=None, e_o=None, tol=1e-5, metric="rel_err"):
+def record_parity(name, d, widened=False, e_h=None, e_o=None, tol=1e-5, metric="rel_err", special=None):
+    """``special``: why this comparison is not on north_star's 1e-5 scale (e.g. a gradient that is mathematically zero,
+    parameters after several Adam steps) - listed apart and kept out of the summary's worst-case figures."""
     test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
-    PARITY_LOG.append({"test": test, "tensor": name, "hip_vs_fp32_oracle": None if d is None else float(d),
+    PARITY_LOG.append({"test": test, "tensor": name, "special": special,
+                       "hip_vs_fp32_oracle": None if d is None else float(d),
                        "tol": tol, "metric": metric, "float64_widening_fired": bool(widened),
                        "hip_vs_float64": None if e_h is None else float(e_h),
                        "fp32_oracle_vs_float64": None if e_o is None else float(e_o)})

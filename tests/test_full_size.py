@@ -128,7 +128,9 @@ def test_b32_default_init_step_with_relu_masks_vs_oracle(everyday_b32, backbone,
         # size (the softmax weights of a segment sum to one), so it sits 1e-5 from float64 in the fp32 oracle
         # already; the HIP path's dense blocks carry 22 rather than 24 bits - 3 x the oracle's distance there
         fac = 3 if ".att_" in name else 2
-        record_parity(name + " (vs float64 over the HIP masks)", rel_err(_np(p.grad), _np(rp[name].grad)), True, e_h, e_o)
+        record_parity(name + " (vs float64 over the HIP masks)", rel_err(_np(p.grad), _np(rp[name].grad)), True, e_h, e_o,
+                      special="a gradient that is mathematically zero: rounding noise of the softmax backward"
+                      if name.endswith("att_dst") else None)
         assert e_h <= max(fac * e_o, TOL), (f"{name}: {e_h:.2e} from the float64 backward over the HIP path's own "
                                             f"masks (fp32 oracle vs float64: {e_o:.2e})")
         # and the north-star bar against the fp32 oracle wherever the two fp32 evaluations took the same masks
@@ -183,7 +185,8 @@ def test_loss_curve_of_the_shipped_configuration_vs_oracle():
         # (Adam moves every element by ~lr per step whatever its gradient's size: an element whose gradient is
         # within rounding of zero walks differently in every evaluation - the fp32 oracle itself ends 5e-4 from
         # the float64 run; the bound says the HIP path's walk is of the same kind, not that it is the same walk)
-        record_parity(name + " after 8 Adam steps", rel_err(_np(pg), _np(pr)), True, e_h, e_o, tol=1e-4)
+        record_parity(name + " after 8 Adam steps", rel_err(_np(pg), _np(pr)), True, e_h, e_o, tol=1e-4,
+                      special="parameters after 8 Adam steps: every element moves ~lr per step whatever its gradient's size")
         assert e_h <= max(4 * e_o, 1e-4), f"{name}: HIP {e_h:.2e} vs oracle {e_o:.2e} from float64 after 8 steps"
 
 
@@ -404,7 +407,7 @@ def test_default_b32_step_launches_exactly_the_tuned_kernels(everyday_b32):
     """WHICH kernels a default-config B=32 encoder step (new batch: adjacency build + forward +
     backward, direct-gradient bucket) launches, by name (`dc_kernel_trace`): the one-launch segmented adjacency build, the
     fused pack + narrow hops of the first layers, the 3-hop chain launches (`k_hop_chain_gcn`, not 12 `k_spmm_wave`
-    launches), the 128 x 256-tile fp16x2 blocks (`k_fwd_h2w`, `k_dw_h2w`), the six-product narrow blocks - and none
+    launches), the 128 x 256-tile fp16x2 blocks (`k_fwd_h2d`, `k_dw_h2w`), the six-product narrow blocks - and none
     of the generic / fallback kernels."""
     from deformcontact_amd import dp
     rest, rig = everyday_b32
@@ -429,8 +432,8 @@ def test_default_b32_step_launches_exactly_the_tuned_kernels(everyday_b32):
         "k_hop_chain_gcn<8>": 2,             # soft: forward chain + transposed chain of layer 2
         "k_hop_chain_gcn<6>": 2,             # rigid
         "k_weight_prep": 2,                  # layer-2 weights (+ clears the chain's row maxima)
-        "k_fwd_h2w<true>": 2,                # soft (whole 128-row tiles): layer-2 forward block (bias + ReLU epilogue)
-        "k_fwd_h2w<false>": 2,               # and dX as a forward-shaped block over the gradient slab; rigid (ragged)
+        "k_fwd_h2d<true>": 2,                # soft (whole 128-row tiles): layer-2 forward block (bias + ReLU epilogue)
+        "k_fwd_h2d<false>": 2,               # and dX as a forward-shaped block over the gradient slab; rigid (ragged)
         "k_dw_h2w<false>": 2,                # layer-2 dW
         "k_mask_grad": 2,
     }

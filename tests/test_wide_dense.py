@@ -1,6 +1,8 @@
-"""The 128 x 256 form (`k_fwd_h2w`, default for the wide layers) of the forward-shaped fp16x2 dense block, here
-forced onto small shapes (DC_H2_WIDE_MIN_TILES=1): bit-identical to the 64/128 x 128 kernel (`k_fwd_h2`) and within
-2e-6 per row of float64, on ragged shapes (rows / columns that do not fill a tile, odd stage counts).
+"""The 128 x 256 forms of the forward-shaped fp16x2 dense block - `k_fwd_h2d` (both operands by LDS-DMA, waves split by
+role: the default for the wide layers) and `k_fwd_h2w` (every wave stages through registers: split reductions, the exp
+epilogue, the correction operand, outputs without 16-byte rows; DC_H2_DMA=0 sends everything there) - here forced onto
+small shapes (DC_H2_WIDE_MIN_TILES=1): bit-identical to the 64/128 x 128 kernel (`k_fwd_h2`) and within 2e-6 per row of
+float64, on ragged shapes (rows / columns that do not fill a tile, odd stage counts, a single stage).
 
 The tile shape is chosen from environment variables read once per process, so every variant runs in a child
 process (which also keeps the selection of THIS process - the default - untouched)."""
@@ -21,13 +23,16 @@ from deformcontact_amd import _lib, ops
 from deformcontact_amd.graph import current_stream_ptr
 from deformcontact_amd.ops import _i64_array, _ptr_array
 
+import os
 dev = torch.device("cuda:0")
 L = _lib.lib()
 gen = torch.Generator().manual_seed(1234)
 worst = 0.0
+_lib.kernel_trace(True)
 for n, k, fo, relu, bias_on, ldpad in ((1000, 96, 256, True, True, 0), (4112, 1024, 256, True, True, 64),
                                        (515, 64, 320, False, True, 4), (256, 32, 256, False, False, 0),
-                                       (2048, 160, 200, True, False, 8), (33, 1024, 17, True, True, 0)):
+                                       (2048, 160, 200, True, False, 8), (33, 1024, 17, True, True, 0),
+                                       (128, 2048, 512, True, True, 0), (1, 32, 4, False, True, 0)):
     st = current_stream_ptr(dev)
     slab_base = (torch.rand(n, k + ldpad, generator=gen) * 4 - 2).to(dev)
     slab_base *= torch.logspace(-4, 0, n).unsqueeze(1).to(dev)            # rows on very different scales
@@ -58,6 +63,12 @@ for n, k, fo, relu, bias_on, ldpad in ((1000, 96, 256, True, True, 0), (4112, 10
     err = float(((out.double().cpu() - ref).abs() / den).max())
     assert err < 2e-6, (err, n, k, fo)
     worst = max(worst, err)
+counts = _lib.kernel_trace_counts()
+_lib.kernel_trace(False)
+want = os.environ.get("DC_EXPECT_KERNEL")
+assert any(want in name for name in counts), (want, counts)
+if want == "k_fwd_h2w":
+    assert not any("k_fwd_h2d" in name for name in counts), counts
 # split reduction on the wide tiles: a long K with few output tiles (attention weights x values)
 for n, k, fo in ((256, 4096, 256), (200, 2080, 192)):
     st = current_stream_ptr(dev)
@@ -82,8 +93,9 @@ print("OK", worst)
 
 
 @pytest.mark.gpu
-def test_wide_dense_tiles_bit_identical_and_fp32_accurate():
-    env = dict(os.environ, DC_H2_WIDE="1", DC_H2_WIDE_MIN_TILES="1")
+@pytest.mark.parametrize("dma", ["1", "0"])
+def test_wide_dense_tiles_bit_identical_and_fp32_accurate(dma):
+    env = dict(os.environ, DC_H2_WIDE="1", DC_H2_WIDE_MIN_TILES="1", DC_H2_DMA=dma, DC_EXPECT_KERNEL="k_fwd_h2d" if dma == "1" else "k_fwd_h2w")
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
