@@ -481,7 +481,10 @@ static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_
     }
     int64_t rows = (N + want - 1) / want;
     if (rows < 256) rows = 256;
-    rows = (rows + BK - 1) / BK * BK;
+    // whole 32-node stages: k_dw_h2w (the only kernel that forms the corrected gradient operand of the attention
+    // backward) walks a chunk 32 nodes at a time; 16 was enough for the other kernels and sent e.g. N = 8,192 in 5
+    // chunks (1,648 rows) to the fallback - an error for dc_tag_linear_bwd_dw_h2_corr
+    rows = (rows + 2 * BK - 1) / (2 * BK) * (2 * BK);
     *chunk_rows = rows;
     *nchunks = (int)((N + rows - 1) / rows);
     if (*nchunks < 1) *nchunks = 1;
