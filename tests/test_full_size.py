@@ -129,8 +129,10 @@ def test_b32_default_init_step_with_relu_masks_vs_oracle(everyday_b32, backbone,
         # already; the HIP path's dense blocks carry 22 rather than 24 bits - 3 x the oracle's distance there
         fac = 3 if ".att_" in name else 2
         record_parity(name + " (vs float64 over the HIP masks)", rel_err(_np(p.grad), _np(rp[name].grad)), True, e_h, e_o,
-                      special="a gradient that is mathematically zero: rounding noise of the softmax backward"
-                      if name.endswith("att_dst") else None)
+                      special=("a gradient that is mathematically zero: rounding noise of the softmax backward"
+                               if name.endswith("att_dst") else
+                               "GAT attention vector: a sum of terms that cancel to ~1 % of their size; bar 3 x the fp32 "
+                               "oracle's distance from float64" if ".att_" in name else None))
         assert e_h <= max(fac * e_o, TOL), (f"{name}: {e_h:.2e} from the float64 backward over the HIP path's own "
                                             f"masks (fp32 oracle vs float64: {e_o:.2e})")
         # and the north-star bar against the fp32 oracle wherever the two fp32 evaluations took the same masks
@@ -172,7 +174,8 @@ def test_loss_curve_of_the_shipped_configuration_vs_oracle():
     assert len(curves["gpu"]) == 8 and step.replays == 6
     for i, (g, r, t) in enumerate(zip(curves["gpu"], curves["f32"], curves["f64"])):
         d = abs(g - r) / abs(r)
-        record_parity(f"loss of step {i}", d, d >= TOL, abs(g - t) / abs(t), abs(r - t) / abs(t))
+        record_parity(f"loss of step {i}", d, d >= TOL, abs(g - t) / abs(t), abs(r - t) / abs(t),
+                      special=None if i == 0 else f"loss after {i} Adam steps (every parameter has moved ~lr per step)")
         if d >= TOL:
             e_h, e_o = abs(g - t) / abs(t), abs(r - t) / abs(t)
             assert e_h <= max(2 * e_o, TOL), (f"step {i}: HIP {g:.9g} vs fp32 oracle {r:.9g} ({d:.2e}); vs float64 "
@@ -429,13 +432,14 @@ def test_default_b32_step_launches_exactly_the_tuned_kernels(everyday_b32):
     names = {k.split("<")[0] for k in got}
     want = {
         "k_build_segment": 2,                # both sorted adjacencies + gcn_norm of a graph: ONE launch per graph
-        "k_hop_chain_gcn<8>": 2,             # soft: forward chain + transposed chain of layer 2
-        "k_hop_chain_gcn<6>": 2,             # rigid
+        "k_hop_chain_gcn<8>": 1,             # soft: forward chain of layer 2
+        "k_hop_chain_gcn<8, true>": 1,       #   and the transposed chain, the masked gradient formed in its staging
+        "k_hop_chain_gcn<6>": 1,             # rigid
+        "k_hop_chain_gcn<6, true>": 1,
         "k_weight_prep": 2,                  # layer-2 weights (+ clears the chain's row maxima)
         "k_fwd_h2d<true>": 2,                # soft (whole 128-row tiles): layer-2 forward block (bias + ReLU epilogue)
         "k_fwd_h2d<false>": 2,               # and dX as a forward-shaped block over the gradient slab; rigid (ragged)
         "k_dw_h2w<false>": 2,                # layer-2 dW
-        "k_mask_grad": 2,
     }
     for k, v in want.items():
         assert got.get(k) == v, (k, got)
@@ -446,7 +450,7 @@ def test_default_b32_step_launches_exactly_the_tuned_kernels(everyday_b32):
     assert sum(v for k, v in got.items() if k.startswith("k_dw_split")) == 2
     assert "k_dw_reduce" in names
     banned = {"k_spmm_wave", "k_tag_linear_fwd", "k_tag_linear_bwd_dx", "k_tag_linear_bwd_dw", "k_fwd_h2", "k_fwd_fast",
-              "k_init", "k_count", "k_fill", "k_emit", "k_hop_chain"}
+              "k_init", "k_count", "k_fill", "k_emit", "k_hop_chain", "k_mask_grad", "k_fwd_h2w"}
     assert not (names & banned), (names & banned, got)
 
 
