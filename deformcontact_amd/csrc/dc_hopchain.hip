@@ -62,7 +62,11 @@ __device__ __forceinline__ float chain_absmax(const float4 &v) {
 // this wave's LDS operations have completed (reads returned, writes landed), then the workgroup meets: no vmcnt wait -
 // the block stores of a hop keep draining while the next hop computes (__syncthreads() would wait for them)
 __device__ __forceinline__ void lds_barrier() {
+#ifdef DC_CHAIN_SYNCTHREADS                                      // diagnostic build (profiles/r04/e_chain_rerun_difference.txt)
+    __syncthreads();
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // LDS through plain 32-bit byte addresses (base + offsets folded by hand: one v_lshl_add_u32 per neighbour piece)

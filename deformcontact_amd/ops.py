@@ -247,9 +247,17 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
     _lib.check(rc, "dc_hop_chain_f32")
 
 
-#: the backward's masked gradient formed INSIDE the transposed chain's staging (``dc_hop_chain_masked_f32``) instead of by
-#: ``dc_tag_mask_grad`` in front of it; ``DC_HOP_CHAIN_MASK=0``: the two launches.
-HOP_CHAIN_MASK = os.environ.get("DC_HOP_CHAIN_MASK", "1") != "0"
+#: diagnostic tap (tools/exp/dp_flake2.py): ``DEBUG_TAP(name, tensor)`` is called with intermediate tensors of
+#: ``_TagConvFn.backward`` when set; None in production
+DEBUG_TAP = None
+_HUNT_KEEP = [] if os.environ.get("HUNT_KEEP_GSLAB") == "1" else None
+
+
+#: ``DC_HOP_CHAIN_MASK=1``: the backward's masked gradient formed INSIDE the transposed chain's staging
+#: (``dc_hop_chain_masked_f32``) instead of by ``dc_tag_mask_grad`` in front of it.  One launch and a 100 MB pass less per
+#: layer and branch, bit-identical - and NOT faster: the mask pass runs in the shadow of the other branch's dense blocks,
+#: the chain launch is on the step's critical path (same-box A/B: 0 to -1.8 %, profiles/r04).  Off by default.
+HOP_CHAIN_MASK = os.environ.get("DC_HOP_CHAIN_MASK", "0") == "1"
 
 
 def hop_chain_masked_ok(g, slab: torch.Tensor, f: int, k: int, gout: torch.Tensor, out: Optional[torch.Tensor]) -> bool:
@@ -628,6 +636,8 @@ class _TagConvFn(torch.autograd.Function):
             # row maxima also feed dW (no mask reads there).
             gwid = (k + 1) * fo
             gslab = _alloc_slab(n, gwid, dev)
+            if _HUNT_KEEP is not None:                       # diagnostic (tools/exp/dp_flake2.py): never reuse this memory
+                _HUNT_KEEP.append(gslab)
             gld = gslab.stride(0)
             fused_mask = need_x and hop_chain_masked_ok(g, gslab, fo, k, gout, out)
             if fused_mask:
@@ -662,6 +672,12 @@ class _TagConvFn(torch.autograd.Function):
                                              fi, n, gwid, fi, hop_rowmax.data_ptr(), wt_rowmax.data_ptr(),
                                              None, 0, st)
                 _lib.check(rc, "dc_tag_linear_fwd_h2 (dX)")
+                if DEBUG_TAP is not None:
+                    DEBUG_TAP(f"bwd{fi}x{fo}.hop_rowmax", hop_rowmax)
+                    DEBUG_TAP(f"bwd{fi}x{fo}.g_rowmax", g_rowmax)
+                    if os.environ.get("HUNT_TAP_BIG") == "1":
+                        DEBUG_TAP(f"bwd{fi}x{fo}.gx", gx)
+                        DEBUG_TAP(f"bwd{fi}x{fo}.gslab", gslab)
                 need_x = False                               # done
 
         if need_w or need_b:

@@ -30,8 +30,10 @@ def main():
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     from deformcontact_amd import dp
-    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, load_model
+    from deformcontact_amd.graphnet import EVERYDAY_NETWORK, ContactEncoder, load_model
     from deformcontact_amd.train import GraphedTrainStep, losses
+    if os.environ.get("DC_TEST_SERIAL_BRANCHES") == "1":
+        ContactEncoder.overlap_branches = False        # both encoder branches on the caller's stream
     dev = torch.device("cuda:0")
     torch.manual_seed(100 + rank)                       # different init per rank ...
     model = load_model(EVERYDAY_NETWORK).to(dev)
@@ -76,7 +78,9 @@ def main():
         want = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
         diff = float((mine - want).abs().max())
         scale = float(want.abs().max())
-        result.update(max_abs_diff=diff, scale=scale, bit_identical=bool(torch.equal(mine, want)))
+        differing = [n for (n, p), q in zip(model.named_parameters(), ref.parameters()) if not torch.equal(p.detach(), q.detach())]
+        result.update(max_abs_diff=diff, scale=scale, bit_identical=bool(torch.equal(mine, want)), differing=differing[:12],
+                      n_differing=len(differing))
     dist.barrier()
     with open(out_path + f".rank{rank}.json", "w") as f:
         json.dump(result, f)
