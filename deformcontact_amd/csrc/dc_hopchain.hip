@@ -382,6 +382,12 @@ k_hop_chain_gcn(ChainParams p) {
 #pragma unroll
         for (int s = 0; s < 2 * STEPS; ++s) {
             const int r0 = (wid - 8) * 16 * STEPS + 8 * s;      // the rows of waves 2 (wid - 8) and 2 (wid - 8) + 1
+#ifdef DC_CHAIN_NODMA                                            // diagnostic build: the slice through registers
+            if (r0 + grp < nn)
+                *reinterpret_cast<float4 *>(smem + (r0 + grp) * 128 + 16 * sub) =
+                    *reinterpret_cast<const float4 *>(src + (int64_t)(r0 + grp) * p.ld);
+            continue;
+#endif
             if (r0 + grp < nn && !(DC_CHAIN_ABL & 8))
                 __builtin_amdgcn_global_load_lds(
                     (const void __attribute__((address_space(1))) *)(src + (int64_t)(r0 + grp) * p.ld),
