@@ -35,7 +35,7 @@ def test_direct_two_rank_launch_on_one_device_over_gloo():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
                         "--warmup", "1", "--kernel-reps", "4", "--no-pmc", "--no-cpu-baseline",
                         "--no-full-step", "--no-strict-fp32", "--no-radius100k", "--no-merged", "--no-backbones"], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=420)
+                       stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]

@@ -193,7 +193,11 @@ def test_masked_chain_equals_mask_grad_then_transposed_chain_bitwise(with_mask):
                                       out.stride(0) if with_mask else f, a.data_ptr(), a.stride(0), n, f,
                                       ga.data_ptr(), ha.data_ptr(), st), "dc_tag_mask_grad")
         ops.chained_hops(g, a, f, k, backward=False, rowmax=ha, transposed=True, rowmax_has_block0=True)
-        assert ops.hop_chain_masked_ok(g, b, f, k, gout, out)
+        keep, ops.HOP_CHAIN_MASK = ops.HOP_CHAIN_MASK, True                     # opt-in switch (DC_HOP_CHAIN_MASK=1)
+        try:
+            assert ops.hop_chain_masked_ok(g, b, f, k, gout, out)
+        finally:
+            ops.HOP_CHAIN_MASK = keep
         rms = torch.zeros(2 * n, device=DEV)
         ops.hop_chain_masked(g, b, f, k, gout, out, rms[:n], rms[n:])
         torch.cuda.synchronize()

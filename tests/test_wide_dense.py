@@ -95,7 +95,7 @@ print("OK", worst)
 @pytest.mark.gpu
 @pytest.mark.parametrize("dma", ["1", "0"])
 def test_wide_dense_tiles_bit_identical_and_fp32_accurate(dma):
-    env = dict(os.environ, DC_H2_WIDE="1", DC_H2_WIDE_MIN_TILES="1", DC_H2_DMA=dma, DC_EXPECT_KERNEL="k_fwd_h2d" if dma == "1" else "k_fwd_h2w")
+    env = dict(os.environ, DC_H2_WIDE="1", DC_H2_WIDE_MIN_TILES="1", DC_H2_DMA=dma, DC_H2_DMA_MIN_K="32", DC_EXPECT_KERNEL="k_fwd_h2d" if dma == "1" else "k_fwd_h2w")
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
