@@ -229,6 +229,7 @@ def hop_chain_eligible(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: i
 #: re-form gcn_norm weights from an LDS-resident degree table inside ``dc_hop_chain_f32`` (no vector-memory loads in its
 #: hop loop) instead of loading ``w``; same bits.  ``DC_HOP_CHAIN_GCN=0``: always load them.
 HOP_CHAIN_GCN = os.environ.get("DC_HOP_CHAIN_GCN", "1") != "0"
+HOP_CHAIN_GCN_MIN_NODES = int(os.environ.get("DC_HOP_CHAIN_GCN_MIN_NODES", "512"))
 
 
 def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weighted: bool = True,
@@ -237,8 +238,24 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
     ``src_block``, one launch (see ``hop_chain_eligible``)."""
     nptr, _, nseg = g._segments
     w = adj.w if weighted else None
-    # the adjacency's weights are gcn_norm's (graph.GraphIndex builds nothing else): tell the kernel so
-    deg = g.fwd.ptr if (HOP_CHAIN_GCN and w is not None and g.normalize and not g.self_loops) else None
+    # the adjacency's weights are gcn_norm's (graph.GraphIndex builds nothing else): tell the kernel so - for graphs above
+    # 512 nodes.  Below that a workgroup of the LDS-table form needs < 80 KB of LDS, several share a CU, and that is the only
+    # configuration in which the rare run-to-run difference of profiles/r04/e_chain_rerun_difference.txt was ever seen
+    # (0 of 2,600 steps with 1,024-node graphs, 0 of 800 repetitions with the id / weight loading form at any size)
+    deg = g.fwd.ptr if (HOP_CHAIN_GCN and w is not None and g.normalize and not g.self_loops
+                        and g._seg_max_nodes > HOP_CHAIN_GCN_MIN_NODES) else None
+    if _CHAIN_SPLIT and k > 1:
+        # diagnostic (profiles/r04/e_chain_rerun_difference.txt): the same kernel, one hop per launch - no LDS hand-over
+        # between hops
+        for j in range(k):
+            rc = _lib.lib().dc_hop_chain_f32(
+                adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+                deg.data_ptr() if deg is not None else None, adj.other.numel(),
+                nptr, nseg, slab.data_ptr(), slab.stride(0), slab.size(0), f, 1, int(src_block) + j * int(direction),
+                int(direction), rowmax.data_ptr() if rowmax is not None else None,
+                int(rowmax_mode) if j == 0 else 2, current_stream_ptr(slab.device))
+            _lib.check(rc, "dc_hop_chain_f32")
+        return
     rc = _lib.lib().dc_hop_chain_f32(
         adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
         deg.data_ptr() if deg is not None else None, adj.other.numel(),
@@ -251,6 +268,7 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
 #: ``_TagConvFn.backward`` when set; None in production
 DEBUG_TAP = None
 _HUNT_KEEP = [] if os.environ.get("HUNT_KEEP_GSLAB") == "1" else None
+_CHAIN_SPLIT = os.environ.get("DC_CHAIN_SPLIT") == "1"
 
 
 #: ``DC_HOP_CHAIN_MASK=1``: the backward's masked gradient formed INSIDE the transposed chain's staging
@@ -263,7 +281,8 @@ HOP_CHAIN_MASK = os.environ.get("DC_HOP_CHAIN_MASK", "0") == "1"
 def hop_chain_masked_ok(g, slab: torch.Tensor, f: int, k: int, gout: torch.Tensor, out: Optional[torch.Tensor]) -> bool:
     """The one-launch form applies: the chain kernel with the adjacency in LDS (gcn_norm weights) is eligible over the
     transposed set and ``gout`` / ``out`` have 16-byte rows."""
-    if not (HOP_CHAIN_MASK and HOP_CHAIN_GCN and k >= 1 and g.normalize and not g.self_loops):
+    if not (HOP_CHAIN_MASK and HOP_CHAIN_GCN and k >= 1 and g.normalize and not g.self_loops
+            and getattr(g, "_seg_max_nodes", 0) > HOP_CHAIN_GCN_MIN_NODES):
         return False
     if not hop_chain_eligible(g, g.bwd, slab, f, k):
         return False

@@ -60,10 +60,11 @@ def run_both(g, adj, n, f, k, mode, weighted=True, src=0, direction=1, with_rowm
     reference_chain(adj, a, f, k, ra, mode, weighted, src, direction)
     assert ops.hop_chain_eligible(g, adj, b, f, k)
     keep, ops.HOP_CHAIN_GCN = ops.HOP_CHAIN_GCN, gcn
+    keep_min, ops.HOP_CHAIN_GCN_MIN_NODES = ops.HOP_CHAIN_GCN_MIN_NODES, 0      # the LDS-table form also on small graphs
     try:
         ops.hop_chain(g, adj, b, f, k, weighted=weighted, rowmax=rb, rowmax_mode=mode, src_block=src, direction=direction)
     finally:
-        ops.HOP_CHAIN_GCN = keep
+        ops.HOP_CHAIN_GCN, ops.HOP_CHAIN_GCN_MIN_NODES = keep, keep_min
     torch.cuda.synchronize()
     assert torch.equal(a, b), f"blocks differ: {(a != b).sum().item()} elements"
     if with_rowmax:

@@ -14,7 +14,9 @@ from deformcontact_amd import dp, synth  # noqa: E402
 from deformcontact_amd.graphnet import EVERYDAY_NETWORK, ContactEncoder, load_model  # noqa: E402
 from deformcontact_amd.train import losses  # noqa: E402
 
-STEPS, B = 4, 2
+STEPS, B = 4, int(os.environ.get("HUNT_B", "2"))
+SV = int(os.environ.get("HUNT_SV", "256"))
+SR = int(os.environ.get("HUNT_SR", "8"))
 if os.environ.get("HUNT_SERIAL") == "1":
     ContactEncoder.overlap_branches = False
 DIRECT = os.environ.get("HUNT_DIRECT", "1") != "0"
@@ -22,7 +24,7 @@ SYNC = os.environ.get("HUNT_SYNC") == "1"
 
 
 def batch(step, dev):
-    return tuple(b.to(dev) for b in synth.make_batch(B, first_idx=step * B, soft_vertices=256, sphere_resolution=8))
+    return tuple(b.to(dev) for b in synth.make_batch(B, first_idx=step * B, soft_vertices=SV, sphere_resolution=SR))
 
 
 def run(init, dev):
