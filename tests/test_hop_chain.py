@@ -231,3 +231,20 @@ def test_encoder_backward_with_and_without_the_fused_mask_is_bit_identical():
         grads.append([p.grad.clone() for p in enc.parameters()] + [xa.grad.clone(), xb.grad.clone()])
     for u, v in zip(*grads):
         assert torch.equal(u, v)
+
+
+def test_small_graphs_take_the_loading_form_of_the_chain_kernel():
+    """`ops.HOP_CHAIN_GCN_MIN_NODES`: batches whose graphs have at most 512 nodes run `k_hop_chain<true, STEPS>` (ids and
+    weights loaded per step), larger ones `k_hop_chain_gcn<STEPS>` (adjacency tables in LDS) - by name, through the launch log
+    (profiles/r04/e_chain_rerun_difference.txt: the only configuration in which the LDS-table form was ever seen to differ
+    between two runs is several small workgroups per CU)."""
+    for sv, want, banned in ((256, "k_hop_chain<true", "k_hop_chain_gcn"), (1024, "k_hop_chain_gcn", "k_hop_chain<")):
+        rest, _, _ = synth.make_batch(4, soft_vertices=sv, sphere_resolution=8)
+        g = GraphIndex(rest.edge_index.to(DEV), rest.x.shape[0], segments=rest.segments())
+        slab = ops._alloc_slab(rest.x.shape[0], 4 * 256, DEV).normal_()
+        rm = torch.zeros(rest.x.shape[0], device=DEV)
+        _lib.kernel_trace(True)
+        ops.chained_hops(g, slab, 256, 3, backward=False, rowmax=rm, rowmax_zeroed=True)
+        counts = _lib.kernel_trace_counts()
+        _lib.kernel_trace(False)
+        assert any(want in k for k in counts) and not any(banned in k for k in counts), (sv, counts)
