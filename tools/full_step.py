@@ -28,7 +28,7 @@ def main():
     if a.graph:
         from deformcontact_amd import dp
         from deformcontact_amd.train import losses
-        bucket = dp.GradBucket(model.parameters())
+        bucket = dp.GradBucket(model.parameters(), direct=True)         # as bench.py and train.train: dW straight into the bucket
         opt = dp.FlatAdam(bucket, lr=4e-4, zero_grad_in_step=True)
         bucket.zero()
         out = {}
