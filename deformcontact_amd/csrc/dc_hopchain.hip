@@ -480,16 +480,24 @@ static bool launch_chain_gcn_steps(unsigned grid, hipStream_t stream, const Chai
     constexpr int R = 128 * STEPS;
     constexpr size_t lds = (size_t)(R + 1) * 128 + (size_t)R * 16 + ((size_t)(R + 1) * 4 + 15) / 16 * 16 + (size_t)R * 8;
     static_assert(lds <= 160 * 1024, "k_hop_chain_gcn: tables do not fit the LDS");
+    // diagnostic (profiles/r04/e_chain_rerun_difference.txt): DC_CHAIN_LDS_MIN_KB asks for at least that much LDS per
+    // workgroup, e.g. 100 = never two workgroups on a CU
+    static const size_t lds_req = [] {
+        const char *v = getenv("DC_CHAIN_LDS_MIN_KB");
+        const size_t want = (v && *v) ? (size_t)atoi(v) * 1024 : 0;
+        const size_t cap = 160 * 1024;
+        return want > lds ? (want < cap ? want : cap) : lds;
+    }();
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain_gcn<STEPS, MASK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) != hipSuccess)
             return false;
         attr_set = true;
     }
     static const std::string name = "k_hop_chain_gcn<" + std::to_string(STEPS) + (MASK ? ", true>" : ">");
     trace_kernel(name.c_str());
-    hipLaunchKernelGGL((k_hop_chain_gcn<STEPS, MASK>), dim3(grid), dim3(1024), lds, stream, p);
+    hipLaunchKernelGGL((k_hop_chain_gcn<STEPS, MASK>), dim3(grid), dim3(1024), lds_req, stream, p);
     return true;
 }
 
