@@ -244,18 +244,6 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
     # (0 of 2,600 steps with 1,024-node graphs, 0 of 800 repetitions with the id / weight loading form at any size)
     deg = g.fwd.ptr if (HOP_CHAIN_GCN and w is not None and g.normalize and not g.self_loops
                         and g._seg_max_nodes > HOP_CHAIN_GCN_MIN_NODES) else None
-    if _CHAIN_SPLIT and k > 1:
-        # diagnostic (profiles/r04/e_chain_rerun_difference.txt): the same kernel, one hop per launch - no LDS hand-over
-        # between hops
-        for j in range(k):
-            rc = _lib.lib().dc_hop_chain_f32(
-                adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
-                deg.data_ptr() if deg is not None else None, adj.other.numel(),
-                nptr, nseg, slab.data_ptr(), slab.stride(0), slab.size(0), f, 1, int(src_block) + j * int(direction),
-                int(direction), rowmax.data_ptr() if rowmax is not None else None,
-                int(rowmax_mode) if j == 0 else 2, current_stream_ptr(slab.device))
-            _lib.check(rc, "dc_hop_chain_f32")
-        return
     rc = _lib.lib().dc_hop_chain_f32(
         adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
         deg.data_ptr() if deg is not None else None, adj.other.numel(),
@@ -267,43 +255,6 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
 #: diagnostic tap (tools/exp/dp_flake2.py): ``DEBUG_TAP(name, tensor)`` is called with intermediate tensors of
 #: ``_TagConvFn.backward`` when set; None in production
 DEBUG_TAP = None
-_HUNT_KEEP = [] if os.environ.get("HUNT_KEEP_GSLAB") == "1" else None
-_CHAIN_SPLIT = os.environ.get("DC_CHAIN_SPLIT") == "1"
-
-
-#: ``DC_HOP_CHAIN_MASK=1``: the backward's masked gradient formed INSIDE the transposed chain's staging
-#: (``dc_hop_chain_masked_f32``) instead of by ``dc_tag_mask_grad`` in front of it.  One launch and a 100 MB pass less per
-#: layer and branch, bit-identical - and NOT faster: the mask pass runs in the shadow of the other branch's dense blocks,
-#: the chain launch is on the step's critical path (same-box A/B: 0 to -1.8 %, profiles/r04).  Off by default.
-HOP_CHAIN_MASK = os.environ.get("DC_HOP_CHAIN_MASK", "0") == "1"
-
-
-def hop_chain_masked_ok(g, slab: torch.Tensor, f: int, k: int, gout: torch.Tensor, out: Optional[torch.Tensor]) -> bool:
-    """The one-launch form applies: the chain kernel with the adjacency in LDS (gcn_norm weights) is eligible over the
-    transposed set and ``gout`` / ``out`` have 16-byte rows."""
-    if not (HOP_CHAIN_MASK and HOP_CHAIN_GCN and k >= 1 and g.normalize and not g.self_loops
-            and getattr(g, "_seg_max_nodes", 0) > HOP_CHAIN_GCN_MIN_NODES):
-        return False
-    if not hop_chain_eligible(g, g.bwd, slab, f, k):
-        return False
-    for t in (gout, out):
-        if t is not None and (t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % 16 != 0):
-            return False
-    return True
-
-
-def hop_chain_masked(g, slab: torch.Tensor, f: int, k: int, gout: torch.Tensor, out: Optional[torch.Tensor],
-                     rowmax_src: torch.Tensor, rowmax_all: torch.Tensor) -> None:
-    """``dc_hop_chain_masked_f32`` over the transposed adjacency: block 0 = gout * (out > 0), blocks 1..k its hops;
-    both row-maxima buffers must hold zeros."""
-    adj = g.bwd
-    nptr, _, nseg = g._segments
-    rc = _lib.lib().dc_hop_chain_masked_f32(
-        adj.ptr.data_ptr(), adj.other.data_ptr(), adj.w.data_ptr(), g.fwd.ptr.data_ptr(), adj.other.numel(), nptr, nseg,
-        gout.data_ptr(), gout.stride(0), out.data_ptr() if out is not None else None,
-        out.stride(0) if out is not None else 0, slab.data_ptr(), slab.stride(0), slab.size(0), f, k, 0, 1,
-        rowmax_src.data_ptr(), rowmax_all.data_ptr(), current_stream_ptr(slab.device))
-    _lib.check(rc, "dc_hop_chain_masked_f32")
 
 
 def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool,
@@ -549,22 +500,14 @@ class _TagConvFn(torch.autograd.Function):
                 if key is not None:
                     _hop_cache_put(g, key, x, slab, rowmax, dev)
         else:
+            rowmax = torch.empty(n, dtype=torch.float32, device=dev) if h2 else None
             zeroed = False
-            ctx.bwd_rowmax = None
             if h2 and g is not None and hop_chain_eligible(g, g.fwd, slab, fi, k):
                 # the chain launch joins its row maxima into `rowmax` with atomics: the weight preparation - one launch
-                # anyway, independent of the slab - clears it on the side (a memset node of its own: ~5 us per chain);
-                # and with it the two buffers the backward's masked chain will join into (hop_chain_masked)
-                want_bwd = ctx.needs_input_grad[1] and HOP_CHAIN_MASK and fo % 16 == 0
-                buf = torch.empty(3 * n if want_bwd else n, dtype=torch.float32, device=dev)
-                rowmax = buf[:n]
-                if want_bwd:
-                    ctx.bwd_rowmax = buf[n:]
+                # anyway, independent of the slab - clears it on the side (a memset node of its own: ~5 us per chain)
                 prepped = _h2_weight_prep(L, [w.contiguous() for w in weights], k, fo, fi,
-                                          ctx.needs_input_grad[1] and fo % 16 == 0, dev, st, zero=buf)
+                                          ctx.needs_input_grad[1] and fo % 16 == 0, dev, st, zero=rowmax)
                 zeroed = True
-            else:
-                rowmax = torch.empty(n, dtype=torch.float32, device=dev) if h2 else None
             chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax, rowmax_zeroed=zeroed)
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
         if concat:
@@ -655,30 +598,20 @@ class _TagConvFn(torch.autograd.Function):
             # row maxima also feed dW (no mask reads there).
             gwid = (k + 1) * fo
             gslab = _alloc_slab(n, gwid, dev)
-            if _HUNT_KEEP is not None:                       # diagnostic (tools/exp/dp_flake2.py): never reuse this memory
-                _HUNT_KEEP.append(gslab)
             gld = gslab.stride(0)
-            fused_mask = need_x and hop_chain_masked_ok(g, gslab, fo, k, gout, out)
-            if fused_mask:
-                # masked gradient formed while the transposed chain stages it: one launch, one pass less over g / out
-                rms = getattr(ctx, "bwd_rowmax", None)       # cleared by the forward's weight-prep launch; good for ONE backward
-                ctx.bwd_rowmax = None
-                if rms is None or rms.numel() != 2 * n:
-                    rms = torch.zeros(2 * n, dtype=torch.float32, device=dev)
-                g_rowmax, hop_rowmax = rms[:n], rms[n:]
-                hop_chain_masked(g, gslab, fo, k, gout, out, g_rowmax, hop_rowmax)
-            else:
-                g_rowmax = torch.empty(n, dtype=torch.float32, device=dev)
-                hop_rowmax = torch.empty(n, dtype=torch.float32, device=dev) if need_x else None
-                _lib.check(L.dc_tag_mask_grad(gout.data_ptr(), ldg, mask_ptr, ldm, gslab.data_ptr(), gld, n,
-                                              fo, g_rowmax.data_ptr(),
-                                              hop_rowmax.data_ptr() if need_x else None, st),
-                           "dc_tag_mask_grad")
+            g_rowmax = torch.empty(n, dtype=torch.float32, device=dev)
+            hop_rowmax = torch.empty(n, dtype=torch.float32, device=dev) if need_x else None
+            # (folding this pass into the transposed chain's staging was built and measured in round 4 - bit-identical, one
+            # launch and 100 MB less, and 0 - 2 % SLOWER on the step: this pass runs in the shadow of the other branch's
+            # dense blocks, the chain launch does not; tools/exp/hopchain_masked.hip keeps the kernel)
+            _lib.check(L.dc_tag_mask_grad(gout.data_ptr(), ldg, mask_ptr, ldm, gslab.data_ptr(), gld, n,
+                                          fo, g_rowmax.data_ptr(),
+                                          hop_rowmax.data_ptr() if need_x else None, st),
+                       "dc_tag_mask_grad")
             g_ptr, g_ld, mask_ptr = gslab.data_ptr(), gld, None
             if need_x:
-                if not fused_mask:
-                    chained_hops(g, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
-                                 rowmax_has_block0=True)
+                chained_hops(g, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
+                             rowmax_has_block0=True)
                 if wt is None:                       # forward ran without needs_input_grad
                     wt = torch.empty((fi, gwid), dtype=torch.float32, device=dev)
                     wt_rowmax = torch.empty(fi, dtype=torch.float32, device=dev)

@@ -247,19 +247,6 @@ int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, c
                      int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
                      int64_t F, int K, int src_block, int dir, float *rowmax, int mode,
                      dc_stream_t stream);
-/* The backward of a ReLU'd TAGConv layer (models/model.py:71-78 under autograd) starts its transposed chain from
- * gm = g * (out > 0): dc_tag_mask_grad followed by dc_hop_chain_f32(mode 2) in ONE launch.  Block src_block of the
- * slab is FORMED while it is staged (g by LDS-DMA, the forward output's pieces alongside, the select of
- * dc_tag_mask_grad; out_for_mask NULL: gm = g) and written to the slab, then the K hops run as in dc_hop_chain_f32.
- * rowmax_src (may be NULL) receives max |gm[i, :]| (what dW scales g by), rowmax_all that maximum joined with the K
- * produced blocks' (what the forward-shaped dX block scales the slab's rows by).  BOTH buffers are joined INTO
- * (integer atomic max over the 32-column slices of a row): the caller hands them over holding zeros.  Same limits
- * as dc_hop_chain_f32, plus: the gcn_norm adjacency (deg_ptr and w non-NULL), K >= 1, 16-byte aligned g / out rows.
- * Results (slab blocks src_block .. src_block + K*dir, both maxima) are bit-identical to the two-call form. */
-int dc_hop_chain_masked_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
-                            int64_t cap, const int64_t *node_ptr_host, int nseg, const float *g, int64_t ldg,
-                            const float *out_for_mask, int64_t ldo, float *slab, int64_t ld, int64_t N, int64_t F,
-                            int K, int src_block, int dir, float *rowmax_src, float *rowmax_all, dc_stream_t stream);
 
 /* ---- the dense block over bf16-STORED features (BASELINE.json configs[4]) ------------------
  * out[N,Fo] = act(A[N,K] . W[Fo,K]^T + bias) with A and W bf16 (uint16 bit patterns, K-contiguous,

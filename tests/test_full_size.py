@@ -438,7 +438,7 @@ def test_default_b32_step_launches_exactly_the_tuned_kernels(everyday_b32):
         "k_fwd_h2d<true>": 2,                # soft (whole 128-row tiles): layer-2 forward block (bias + ReLU epilogue)
         "k_fwd_h2d<false>": 2,               # and dX as a forward-shaped block over the gradient slab; rigid (ragged)
         "k_dw_h2w<false>": 2,                # layer-2 dW
-        "k_mask_grad": 2,                    # (DC_HOP_CHAIN_MASK=1 would fold it into the transposed chain: not faster)
+        "k_mask_grad": 2,
     }
     for k, v in want.items():
         assert got.get(k) == v, (k, got)

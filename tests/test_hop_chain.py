@@ -167,72 +167,6 @@ def test_tagconv_layer_and_encoder_identical_with_and_without_the_chain(monkeypa
         assert np.array_equal(u, v)
 
 
-@pytest.mark.parametrize("with_mask", [True, False])
-def test_masked_chain_equals_mask_grad_then_transposed_chain_bitwise(with_mask):
-    """``dc_hop_chain_masked_f32`` (the backward of a ReLU'd TAGConv layer: /root/reference/models/model.py:71-78 under
-    autograd): block 0 = g * (out > 0) formed while the chain stages it, against ``dc_tag_mask_grad`` followed by the
-    transposed ``dc_hop_chain_f32`` - slab blocks and BOTH row-maxima buffers bit for bit; mesh batch and ragged graphs
-    (empty, one node, the 1,024-node cap, a hub), g / out as column views of wider buffers."""
-    L = _lib.lib()
-    cases = []
-    rest, _, rig = synth.make_batch(6)
-    for b in (rest, rig):
-        cases.append((GraphIndex(b.edge_index.to(DEV), b.x.shape[0], segments=b.segments()), b.x.shape[0]))
-    ei, seg = batch_of_graphs([700, 0, 1, 1024, 333, 129], [6, 0, 1, 5, 7, 3], seed=5, hub=(4, 41))
-    cases.append((GraphIndex(ei.to(DEV), seg[0][-1], segments=seg), seg[0][-1]))
-    f, k = 256, 3
-    for g, n in cases:
-        torch.manual_seed(n)
-        gwide = torch.randn(n, f + 64, device=DEV) * torch.logspace(-2, 2, n, device=DEV)[:, None]
-        gout = gwide[:, 32:32 + f]                                              # 16-byte aligned column view
-        out = torch.relu(torch.randn(n, f, device=DEV)) if with_mask else None
-        st = current_stream_ptr(torch.device(DEV))
-        a = ops._alloc_slab(n, (k + 1) * f, DEV).fill_(float("nan"))
-        b = a.clone()
-        ga, ha = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
-        _lib.check(L.dc_tag_mask_grad(gout.data_ptr(), gout.stride(0), out.data_ptr() if with_mask else None,
-                                      out.stride(0) if with_mask else f, a.data_ptr(), a.stride(0), n, f,
-                                      ga.data_ptr(), ha.data_ptr(), st), "dc_tag_mask_grad")
-        ops.chained_hops(g, a, f, k, backward=False, rowmax=ha, transposed=True, rowmax_has_block0=True)
-        keep, ops.HOP_CHAIN_MASK = ops.HOP_CHAIN_MASK, True                     # opt-in switch (DC_HOP_CHAIN_MASK=1)
-        try:
-            assert ops.hop_chain_masked_ok(g, b, f, k, gout, out)
-        finally:
-            ops.HOP_CHAIN_MASK = keep
-        rms = torch.zeros(2 * n, device=DEV)
-        ops.hop_chain_masked(g, b, f, k, gout, out, rms[:n], rms[n:])
-        torch.cuda.synchronize()
-        assert torch.equal(a, b), f"blocks differ: {(a != b).sum().item()} elements (n={n})"
-        assert torch.equal(ga, rms[:n]) and torch.equal(ha, rms[n:]), "row maxima differ"
-
-
-def test_encoder_backward_with_and_without_the_fused_mask_is_bit_identical():
-    """The whole encoder (both branches, B=4), gradients of every parameter and of the inputs: DC_HOP_CHAIN_MASK on / off."""
-    from deformcontact_amd.graphnet import ContactEncoder
-    rest, _, rig = (b.to(DEV) for b in synth.make_batch(4))
-    torch.manual_seed(3)
-    enc = ContactEncoder([rest.x.shape[1], rig.x.shape[1]], 256).to(DEV)
-    grads = []
-    for fused in (True, False):
-        keep, ops.HOP_CHAIN_MASK = ops.HOP_CHAIN_MASK, fused
-        try:
-            enc.zero_grad(set_to_none=True)
-            xa, xb = rest.x.clone().requires_grad_(True), rig.x.clone().requires_grad_(True)
-            ba, bb = rest.clone(), rig.clone()
-            ba.x, bb.x = xa, xb
-            _lib.kernel_trace(True)
-            a, b = enc(ba, bb)
-            (a.square().sum() + b.square().sum()).backward()
-            counts = _lib.kernel_trace_counts()
-            _lib.kernel_trace(False)
-        finally:
-            ops.HOP_CHAIN_MASK = keep
-        assert any(", true>" in name and "k_hop_chain_gcn" in name for name in counts) == fused, counts
-        grads.append([p.grad.clone() for p in enc.parameters()] + [xa.grad.clone(), xb.grad.clone()])
-    for u, v in zip(*grads):
-        assert torch.equal(u, v)
-
-
 def test_small_graphs_take_the_loading_form_of_the_chain_kernel():
     """`ops.HOP_CHAIN_GCN_MIN_NODES`: batches whose graphs have at most 512 nodes run `k_hop_chain<true, STEPS>` (ids and
     weights loaded per step), larger ones `k_hop_chain_gcn<STEPS>` (adjacency tables in LDS) - by name, through the launch log

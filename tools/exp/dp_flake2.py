@@ -2,7 +2,9 @@
 """Narrowing the rare mismatch of tests/test_a_dp_graphed.py: the eager train step (losses + backward into a direct-gradient
 bucket + FlatAdam) run TWICE from the same state on the same batches, parameters compared after every step.  Environment
 switches select what to rule out:  HUNT_SERIAL=1 (no two-stream branches), HUNT_DIRECT=0 (autograd-accumulated gradients),
-DC_HOP_CACHE=0, DC_FUSED_PACK=0, DC_FUSED_LOSS=0, DC_HOP_CHAIN=0, HUNT_SYNC=1 (device synchronize before Adam).
+DC_HOP_CACHE=0, DC_FUSED_PACK=0, DC_FUSED_LOSS=0, DC_HOP_CHAIN=0, DC_HOP_CHAIN_GCN_MIN_NODES=0 (the LDS-table form of
+the chain kernel also on small graphs: what shows the difference), HUNT_SYNC=1 (device synchronize before Adam), HUNT_TAP=1
+(clones of the backward's row maxima; HUNT_TAP_BIG=1: of the gradient slab and dX too), HUNT_B / HUNT_SV / HUNT_SR (batch and mesh sizes).
 python tools/exp/dp_flake2.py [repeats]"""
 import os
 import sys

@@ -1,3 +1,12 @@
+// tools/exp/hopchain_masked.hip -- EXPERIMENT RECORD (not built, not part of the product library): dc_hopchain.hip as it
+// stood at the end of round 4 WITH the variant that forms the backward's masked gradient inside the transposed chain's
+// staging (k_hop_chain_gcn<STEPS, true>, entry dc_hop_chain_masked_f32) and with the diagnostic builds of the
+// rerun-difference hunt (-DDC_CHAIN_SYNCTHREADS, -DDC_CHAIN_NODMA, DC_CHAIN_LDS_MIN_KB).  The variant was bit-identical to
+// dc_tag_mask_grad + dc_hop_chain_f32 (slab blocks and both row-maxima buffers; the tests lived in tests/test_hop_chain.py,
+// git history) and saved a launch and a 100 MB pass per layer and branch - and the step got 0 to 2.3 % SLOWER
+// (profiles/r04/d_ab_headline*.txt): the mask pass runs in the shadow of the other branch's dense blocks, the chain launch
+// does not.  Removed from the library for that reason.  To build it again: replace deformcontact_amd/csrc/dc_hopchain.hip
+// by this file (the include path below then needs "dc_common.h").
 // dc_hopchain.hip -- K chained hops of a batch of small graphs in ONE launch, each graph's features resident in LDS.
 //
 // TAGConv needs x_k = A_hat x_{k-1}, k = 1..K (/root/reference/models/model.py:71,77 -> PyG tag_conv.py: K = 3
@@ -18,7 +27,7 @@
 
 #include <string>
 
-#include "dc_common.h"
+#include "../../deformcontact_amd/csrc/dc_common.h"
 
 #pragma clang fp contract(off)
 
@@ -47,6 +56,11 @@ struct ChainParams {
     int32_t cap;                      // elements of other / w (range check of the 16-byte id / weight loads)
     int F, nslices, K, src0, dir, rm_mode, nseg;
     int32_t node_ptr[kChainGraphs + 1];
+    // k_hop_chain_gcn<STEPS, true> (dc_hop_chain_masked_f32): the source block is FORMED while it is staged,
+    // block src0 = mg * (mo > 0) (mo null: = mg), and written to the slab; rowmax0 takes its row maxima alone
+    const float *mg, *mo;
+    int64_t ldmg, ldmo;
+    float *rowmax0;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -57,7 +71,11 @@ __device__ __forceinline__ float chain_absmax(const float4 &v) {
 // this wave's LDS operations have completed (reads returned, writes landed), then the workgroup meets: no vmcnt wait -
 // the block stores of a hop keep draining while the next hop computes (__syncthreads() would wait for them)
 __device__ __forceinline__ void lds_barrier() {
+#ifdef DC_CHAIN_SYNCTHREADS                                      // diagnostic build (profiles/r04/e_chain_rerun_difference.txt)
+    __syncthreads();
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // LDS through plain 32-bit byte addresses (base + offsets folded by hand: one v_lshl_add_u32 per neighbour piece)
@@ -312,7 +330,7 @@ __device__ __forceinline__ void gcn_slots(float4 &acc, const uint4 &iv, float di
     }
 }
 
-template <int STEPS>
+template <int STEPS, bool MASK = false>
 __global__ void __launch_bounds__(1024)
 k_hop_chain_gcn(ChainParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -333,11 +351,52 @@ k_hop_chain_gcn(ChainParams p) {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.other), 0, p.cap * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.cap * 4, 0x00020000);
-    if (wid >= 8) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.slab + (int64_t)n0 * p.ld, 0, (int)((unsigned)nn * (unsigned)p.ld * 4u), 0x00020000);
+    const unsigned ldb = (unsigned)p.ld * 4u;
+    if (wid >= 8 && MASK) {
+        // the masked gradient is formed on the way in (dc_tag_mask_grad's gm = g * (out > 0), the same select): g by
+        // LDS-DMA, the forward output's pieces into registers (all in flight together), then every lane finishes the
+        // piece its own DMA lane wrote - no other lane touches it before the barrier - and stores it to block src0
+        const int64_t c0 = (int64_t)slice * kChainCols + 4 * sub;
+        const float *gsrc = p.mg + (int64_t)n0 * p.ldmg + c0;
+        const float *msrc = p.mo ? p.mo + (int64_t)n0 * p.ldmo + c0 : nullptr;
+        float4 mk[2 * STEPS];
+#pragma unroll
+        for (int s = 0; s < 2 * STEPS; ++s) {
+            const int r0 = (wid - 8) * 16 * STEPS + 8 * s;
+            mk[s] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (r0 + grp < nn) {
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1))) *)(gsrc + (int64_t)(r0 + grp) * p.ldmg),
+                    (void __attribute__((address_space(3))) *)(smem + r0 * 128), 16, 0, 0);
+                if (msrc) mk[s] = *reinterpret_cast<const float4 *>(msrc + (int64_t)(r0 + grp) * p.ldmo);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        const unsigned scol = (unsigned)(p.src0 * p.F + slice * kChainCols + 4 * sub) * 4u;
+#pragma unroll
+        for (int s = 0; s < 2 * STEPS; ++s) {
+            const int row = (wid - 8) * 16 * STEPS + 8 * s + grp;
+            if (row < nn) {
+                float4 v = *reinterpret_cast<const float4 *>(smem + row * 128 + 16 * sub);
+                v = make_float4(mk[s].x > 0.f ? v.x : 0.f, mk[s].y > 0.f ? v.y : 0.f, mk[s].z > 0.f ? v.z : 0.f,
+                                mk[s].w > 0.f ? v.w : 0.f);
+                *reinterpret_cast<float4 *>(smem + row * 128 + 16 * sub) = v;
+                store_piece(v, rs, (unsigned)row * ldb + scol);
+            }
+        }
+    } else if (wid >= 8) {
         const float *src = blk + (int64_t)p.src0 * p.F;
 #pragma unroll
         for (int s = 0; s < 2 * STEPS; ++s) {
             const int r0 = (wid - 8) * 16 * STEPS + 8 * s;      // the rows of waves 2 (wid - 8) and 2 (wid - 8) + 1
+#ifdef DC_CHAIN_NODMA                                            // diagnostic build: the slice through registers
+            if (r0 + grp < nn)
+                *reinterpret_cast<float4 *>(smem + (r0 + grp) * 128 + 16 * sub) =
+                    *reinterpret_cast<const float4 *>(src + (int64_t)(r0 + grp) * p.ld);
+            continue;
+#endif
             if (r0 + grp < nn && !(DC_CHAIN_ABL & 8))
                 __builtin_amdgcn_global_load_lds(
                     (const void __attribute__((address_space(1))) *)(src + (int64_t)(r0 + grp) * p.ld),
@@ -380,9 +439,7 @@ k_hop_chain_gcn(ChainParams p) {
     const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned lbase = sbase + 16u * sub, dbase = sbase + kDis;
     const unsigned gbase = lbase - (unsigned)n0 * 128u, zsub = lbase + R * 128u;    // global-id addressing of the tail path
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        p.slab + (int64_t)n0 * p.ld, 0, (int)((unsigned)nn * (unsigned)p.ld * 4u), 0x00020000);
-    const unsigned ldb = (unsigned)p.ld * 4u;
+    if (MASK && p.rowmax0) publish_rowmax(pm, sub, STEPS, rwave + 8 * sub + grp, nn, p.rowmax0 + n0);   // block src0 alone
     for (int h = 0; h < p.K; ++h) {
         const unsigned dcol = (unsigned)((p.src0 + (h + 1) * p.dir) * p.F + slice * kChainCols + 4 * sub) * 4u;
         float4 acc[STEPS];
@@ -427,35 +484,47 @@ k_hop_chain_gcn(ChainParams p) {
     if (want_rm) publish_rowmax(pm, sub, STEPS, rwave + 8 * sub + grp, nn, p.rowmax + n0);
 }
 
-template <int STEPS>
+template <int STEPS, bool MASK>
 static bool launch_chain_gcn_steps(unsigned grid, hipStream_t stream, const ChainParams &p) {
     constexpr int R = 128 * STEPS;
     constexpr size_t lds = (size_t)(R + 1) * 128 + (size_t)R * 16 + ((size_t)(R + 1) * 4 + 15) / 16 * 16 + (size_t)R * 8;
     static_assert(lds <= 160 * 1024, "k_hop_chain_gcn: tables do not fit the LDS");
+    // diagnostic (profiles/r04/e_chain_rerun_difference.txt): DC_CHAIN_LDS_MIN_KB asks for at least that much LDS per
+    // workgroup, e.g. 100 = never two workgroups on a CU
+    static const size_t lds_req = [] {
+        const char *v = getenv("DC_CHAIN_LDS_MIN_KB");
+        const size_t want = (v && *v) ? (size_t)atoi(v) * 1024 : 0;
+        const size_t cap = 160 * 1024;
+        return want > lds ? (want < cap ? want : cap) : lds;
+    }();
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain_gcn<STEPS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain_gcn<STEPS, MASK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) != hipSuccess)
             return false;
         attr_set = true;
     }
-    static const std::string name = "k_hop_chain_gcn<" + std::to_string(STEPS) + ">";
+    static const std::string name = "k_hop_chain_gcn<" + std::to_string(STEPS) + (MASK ? ", true>" : ">");
     trace_kernel(name.c_str());
-    hipLaunchKernelGGL((k_hop_chain_gcn<STEPS>), dim3(grid), dim3(1024), lds, stream, p);
+    hipLaunchKernelGGL((k_hop_chain_gcn<STEPS, MASK>), dim3(grid), dim3(1024), lds_req, stream, p);
     return true;
 }
 
-static bool launch_chain_gcn(int steps, unsigned grid, hipStream_t stream, const ChainParams &p) {
+template <bool MASK>
+static bool launch_chain_gcn_m(int steps, unsigned grid, hipStream_t stream, const ChainParams &p) {
     switch (steps) {
-    case 1: return launch_chain_gcn_steps<1>(grid, stream, p);
-    case 2: return launch_chain_gcn_steps<2>(grid, stream, p);
-    case 3: return launch_chain_gcn_steps<3>(grid, stream, p);
-    case 4: return launch_chain_gcn_steps<4>(grid, stream, p);
-    case 5: return launch_chain_gcn_steps<5>(grid, stream, p);
-    case 6: return launch_chain_gcn_steps<6>(grid, stream, p);
-    case 7: return launch_chain_gcn_steps<7>(grid, stream, p);
-    default: return launch_chain_gcn_steps<8>(grid, stream, p);
+    case 1: return launch_chain_gcn_steps<1, MASK>(grid, stream, p);
+    case 2: return launch_chain_gcn_steps<2, MASK>(grid, stream, p);
+    case 3: return launch_chain_gcn_steps<3, MASK>(grid, stream, p);
+    case 4: return launch_chain_gcn_steps<4, MASK>(grid, stream, p);
+    case 5: return launch_chain_gcn_steps<5, MASK>(grid, stream, p);
+    case 6: return launch_chain_gcn_steps<6, MASK>(grid, stream, p);
+    case 7: return launch_chain_gcn_steps<7, MASK>(grid, stream, p);
+    default: return launch_chain_gcn_steps<8, MASK>(grid, stream, p);
     }
+}
+static bool launch_chain_gcn(int steps, unsigned grid, hipStream_t stream, const ChainParams &p) {
+    return p.mg ? launch_chain_gcn_m<true>(steps, grid, stream, p) : launch_chain_gcn_m<false>(steps, grid, stream, p);
 }
 
 template <bool W, int STEPS>
@@ -495,10 +564,10 @@ using namespace dc;
 
 extern "C" int64_t dc_hop_chain_max_nodes(void) { return 128 * kChainSteps; }
 
-extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
-                                int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
-                                int64_t F, int K, int src_block, int dir, float *rowmax, int mode,
-                                dc_stream_t stream_) {
+static int chain_run(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr, int64_t cap,
+                     const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N, int64_t F, int K,
+                     int src_block, int dir, float *rowmax, int mode, dc_stream_t stream_, const float *mg, int64_t ldmg,
+                     const float *mo, int64_t ldmo, float *rowmax0) {
     hipStream_t stream = (hipStream_t)stream_;
     DC_REQUIRE(N >= 0 && F >= 1 && K >= 0 && nseg >= 0, "dc_hop_chain_f32: negative size");
     if (N == 0 || K == 0 || nseg == 0) return DC_OK;
@@ -529,6 +598,7 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
     DC_REQUIRE(!deg_ptr || w, "dc_hop_chain_f32: deg_ptr describes the weights w - it cannot come without them");
     p.ptr = ptr, p.other = other, p.w = w, p.deg_ptr = deg_ptr, p.slab = slab, p.ld = ld, p.rowmax = rowmax, p.cap = (int32_t)cap;
     p.F = (int)F, p.nslices = (int)(F / kChainCols), p.K = K, p.src0 = src_block, p.dir = dir, p.rm_mode = mode;
+    p.mg = mg, p.ldmg = ldmg, p.mo = mo, p.ldmo = ldmo, p.rowmax0 = rowmax0;
     for (int s0 = 0; s0 < nseg; s0 += kChainGraphs) {
         const int cnt = nseg - s0 < kChainGraphs ? nseg - s0 : kChainGraphs;
         int64_t big = 0;
@@ -547,4 +617,28 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
         DC_REQUIRE(ok, "dc_hop_chain_f32: cannot reserve the kernel's LDS");
     }
     return check_launch("dc_hop_chain_f32");
+}
+
+extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
+                                int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
+                                int64_t F, int K, int src_block, int dir, float *rowmax, int mode,
+                                dc_stream_t stream_) {
+    return chain_run(ptr, other, w, deg_ptr, cap, node_ptr_host, nseg, slab, ld, N, F, K, src_block, dir, rowmax, mode,
+                     stream_, nullptr, 0, nullptr, 0, nullptr);
+}
+
+extern "C" int dc_hop_chain_masked_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
+                                       int64_t cap, const int64_t *node_ptr_host, int nseg, const float *g, int64_t ldg,
+                                       const float *out_for_mask, int64_t ldo, float *slab, int64_t ld, int64_t N,
+                                       int64_t F, int K, int src_block, int dir, float *rowmax_src, float *rowmax_all,
+                                       dc_stream_t stream_) {
+    DC_REQUIRE(g && deg_ptr && w && rowmax_all, "dc_hop_chain_masked_f32: needs g, the gcn_norm adjacency (deg_ptr, w) and "
+                                                "the row-maxima buffer");
+    DC_REQUIRE(K >= 1, "dc_hop_chain_masked_f32: K >= 1 (dc_tag_mask_grad forms the block alone)");
+    DC_REQUIRE(ldg >= F && ldg % 4 == 0 && ((uintptr_t)g & 15) == 0 &&
+                   (!out_for_mask || (ldo >= F && ldo % 4 == 0 && ((uintptr_t)out_for_mask & 15) == 0)),
+               "dc_hop_chain_masked_f32: g / out need 16-byte aligned rows of at least F columns");
+    // mode 3: block src0's maxima join in, both buffers hold zeros (or maxima to join with) on entry
+    return chain_run(ptr, other, w, deg_ptr, cap, node_ptr_host, nseg, slab, ld, N, F, K, src_block, dir, rowmax_all, 3,
+                     stream_, g, ldg, out_for_mask, ldo, rowmax_src);
 }

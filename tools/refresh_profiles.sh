@@ -48,7 +48,7 @@ done
 (cd "$R" && H2S_SRC=dense_h2d.hip timeout -s KILL 400 python tools/exp/dense_h2s.py 0 34 2 32 > "$O/dense_h2d_timing.txt" 2>&1)
 (cd "$R" && timeout -s KILL 300 python tools/exp/dense_h2d_trace.py > "$O/dense_h2d_anatomy.txt" 2>&1)
 (cd "$R" && for f in 0 1; do echo "DC_FUSED_ATTN=$f"; DC_FUSED_ATTN=$f timeout -s KILL 300 python tools/full_step.py --batch 4 --steps 50 --graph 2>&1 | tail -1; done > "$O/attn_b4_stock_vs_library.txt")
-(cd "$R" && timeout -s KILL 600 tools/exp/ab_headline.sh DC_HOP_CHAIN_MASK=0 DC_HOP_CHAIN_MASK=1 > "$O/ab_headline.txt" 2>&1; timeout -s KILL 600 tools/exp/ab_headline.sh DC_H2_DMA=0 DC_H2_DMA=1 >> "$O/ab_headline.txt" 2>&1)
+(cd "$R" && timeout -s KILL 600 tools/exp/ab_headline.sh DC_H2_DMA=0 DC_H2_DMA=1 > "$O/ab_headline.txt" 2>&1; timeout -s KILL 600 tools/exp/ab_headline.sh DC_HOP_CHAIN=0 DC_HOP_CHAIN=1 >> "$O/ab_headline.txt" 2>&1)
 # keep the summaries, drop the bulky per-dispatch traces (gpurun_out/ travels back, 64 MiB cap)
 find "$R/$O" -name "*kernel_trace.csv" -delete
 find "$R/$O" -name "*counter_collection.csv" -delete
