@@ -517,7 +517,10 @@ static void dispatch_bf16(const int32_t *ptr, const int32_t *other, const float 
         const char *e = getenv("DC_SPMM_BF16_KERNEL");
         return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 2 : 0));
     }();
-    const bool pair = forced ? forced == 1 : N * ldx * 2 > (int64_t)128 << 20;
+    // the rule looks at what ONE hop gathers from - N rows of F values - not at the slab the block sits in (round 4: on the
+    // 100k-point radius graph the slab's leading dimension made the rule pick the row-pair kernel for a 51 MB block that the
+    // Infinity Cache holds: 67 vs 45 us per hop, forward 0.64 vs 0.51 ms)
+    const bool pair = forced ? forced == 1 : N * (int64_t)F * 2 > (int64_t)128 << 20;
     if (x8 && F >= 256 && pair) {
         const unsigned grid = (unsigned)((N + 7) / 8);
         DC_LAUNCH((k_spmm_bf16_pair<8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,
