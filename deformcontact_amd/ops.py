@@ -627,6 +627,10 @@ class _TagConvFn(torch.autograd.Function):
                 if DEBUG_TAP is not None:
                     DEBUG_TAP(f"bwd{fi}x{fo}.hop_rowmax", hop_rowmax)
                     DEBUG_TAP(f"bwd{fi}x{fo}.g_rowmax", g_rowmax)
+                    if os.environ.get("HUNT_TAP_ADJ") == "1":
+                        for nm, t in (("bwd.ptr", g.bwd.ptr), ("bwd.other", g.bwd.other), ("bwd.w", g.bwd.w),
+                                      ("fwd.ptr", g.fwd.ptr)):
+                            DEBUG_TAP(f"bwd{fi}x{fo}.adj.{nm}", t)
                     if os.environ.get("HUNT_TAP_BIG") == "1":
                         DEBUG_TAP(f"bwd{fi}x{fo}.gx", gx)
                         DEBUG_TAP(f"bwd{fi}x{fo}.gslab", gslab)
