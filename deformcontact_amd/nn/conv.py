@@ -29,6 +29,9 @@ from ..graph import GraphIndex, _require_cuda, graph_index
 class _Lin(nn.Module):
     """Parameter holder mirroring ``torch_geometric.nn.dense.Linear(bias=False)``."""
 
+    #: set by GATConv on its ``lin``: keep the six-product dense kernels (``ops.dense_linear(six_products=True)``)
+    six_products = False
+
     def __init__(self, in_channels: int, out_channels: int, initializer: Optional[str] = None):
         super().__init__()
         self.in_channels, self.out_channels, self.initializer = in_channels, out_channels, initializer
@@ -45,7 +48,7 @@ class _Lin(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
-            return ops.dense_linear(x, self.weight)          # the library's MFMA dense block
+            return ops.dense_linear(x, self.weight, six_products=self.six_products)      # the library's MFMA dense block
         return torch.nn.functional.linear(x, self.weight)
 
 
@@ -170,6 +173,7 @@ class GATConv(nn.Module):
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
         self.negative_slope = negative_slope
         self.lin = _Lin(in_channels, heads * out_channels, initializer="glorot")
+        self.lin.six_products = True             # the attention vectors' gradient cancels to 1 % of its terms: 24-bit products
         self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
         self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
         if bias:

@@ -353,10 +353,19 @@ def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool,
     return slab, rowmax
 
 
-def _tag_uses_h2(fi: int, k: int) -> bool:
+#: K = 0 layers (``dense_linear``: the ``lin`` of GCNConv / GATConv, the attention heads' Linear, the decoder) on the
+#: fp16x2 kernels too: no hop records their row maxima, so a ``dc_rowabsmax_f32`` pass over the input is added (8 us for
+#: [32768, 256]) and three MFMA products replace six.  From 128 input columns on, outputs a multiple of 16 wide
+#: (the 256 -> 3 output layer stays where it was).  ``DC_DENSE_H2_K0=0``: the six-product kernels.
+DENSE_H2_K0 = os.environ.get("DC_DENSE_H2_K0", "1") != "0"
+
+
+def _tag_uses_h2(fi: int, k: int, fo: Optional[int] = None) -> bool:
     concat, _, wpad = tag_slab_geometry(fi, k)
-    return (DENSE_F16X2 and DENSE_SPLIT_BF16 and DENSE_PRODUCTS == 6 and not concat and k >= 1
-            and fi % 16 == 0 and wpad % 4 == 0)
+    ok = (DENSE_F16X2 and DENSE_SPLIT_BF16 and DENSE_PRODUCTS == 6 and not concat and fi % 16 == 0 and wpad % 4 == 0)
+    if k >= 1:
+        return ok
+    return ok and DENSE_H2_K0 and fo is not None and fi >= 128 and fi % 32 == 0 and fo % 16 == 0 and fo >= 64
 
 
 def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3, refresh: bool = False) -> None:
@@ -484,7 +493,10 @@ class _TagConvFn(torch.autograd.Function):
             slab = x                                 # no hops: the input itself is the (1-block) slab
         L = _lib.lib()
         st = current_stream_ptr(dev)
-        h2 = _tag_uses_h2(fi, k)
+        six = next_geom is SIX_PRODUCTS
+        if six:
+            next_geom = None
+        h2 = _tag_uses_h2(fi, k, None if six else fo)
         rowmax = None
         prepped = None
         if slab is None:
@@ -509,6 +521,10 @@ class _TagConvFn(torch.autograd.Function):
                                           ctx.needs_input_grad[1] and fo % 16 == 0, dev, st, zero=rowmax)
                 zeroed = True
             chained_hops(g, slab, fi, k, backward=False, rowmax=rowmax, rowmax_zeroed=zeroed)
+        if h2 and k == 0:
+            # no hop has recorded the rows' maxima: one pass over the input
+            rowmax = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(L.dc_rowabsmax_f32(slab.data_ptr(), slab.stride(0), n, fi, rowmax.data_ptr(), st), "dc_rowabsmax_f32")
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
         if concat:
             wc = [w.contiguous() for w in weights]
@@ -914,11 +930,21 @@ def tag_conv_grouped(mg: GraphIndex, xs, weights, biases, relu: bool = False, ne
                                    *xs, *flat)
 
 
+class _SixProducts:
+    """``next_geom`` marker of ``dense_linear(..., six_products=True)``."""
+
+
+SIX_PRODUCTS = _SixProducts()
+
+
 def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                 relu: bool = False) -> torch.Tensor:
+                 relu: bool = False, six_products: bool = False) -> torch.Tensor:
     """``act(x @ weight.T + bias)`` on the library's dense block (a TAGConv layer with K = 0: no hops):
-    the ``lin`` of ``GCNConv`` / ``GATConv`` (PyG ``nn/dense/linear.py``), forward and backward."""
-    return _TagConvFn.apply(None, x, bias, bool(relu), None, weight)
+    the ``lin`` of ``GCNConv`` / ``GATConv`` (PyG ``nn/dense/linear.py``), forward and backward.
+    ``six_products``: stay on the exact three-way bf16 split (24 bits) where the three-product fp16 split (22 bits)
+    would apply - GATConv's ``lin``: the gradient of its attention vectors is a sum of terms that cancel to 1 % of
+    their size and sits at the parity bar already."""
+    return _TagConvFn.apply(None, x, bias, bool(relu), SIX_PRODUCTS if six_products else None, weight)
 
 
 def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
