@@ -45,15 +45,21 @@ struct Edges {
 };
 
 // endpoints of edge e in the merged node space; false when either lies outside its part's [0, nodes)
+// (The part's fields are SELECTED, not indexed: `ed.src[p]` with a per-lane p is a vector load from the kernel-argument
+// segment - two dependent memory round trips in front of every edge load; the selects keep every field a scalar load.)
 __device__ __forceinline__ bool load_edge(const Edges &ed, int64_t e, int64_t &s, int64_t &d) {
-    int p = 0;
+    const int64_t *sp = ed.src[0], *dp = ed.dst[0];
+    int64_t beg = ed.e_beg[0], off = ed.node_off[0], nodes = ed.nodes[0];
 #pragma unroll
-    for (int q = 1; q < kMaxParts; ++q)
-        if (q < ed.nparts && e >= ed.e_beg[q]) p = q;
-    const int64_t l = e - ed.e_beg[p];
-    s = ed.src[p][l], d = ed.dst[p][l];
-    const bool ok = s >= 0 && s < ed.nodes[p] && d >= 0 && d < ed.nodes[p];
-    s += ed.node_off[p], d += ed.node_off[p];
+    for (int q = 1; q < kMaxParts; ++q) {
+        const bool in = q < ed.nparts && e >= ed.e_beg[q];
+        sp = in ? ed.src[q] : sp, dp = in ? ed.dst[q] : dp;
+        beg = in ? ed.e_beg[q] : beg, off = in ? ed.node_off[q] : off, nodes = in ? ed.nodes[q] : nodes;
+    }
+    const int64_t l = e - beg;
+    s = sp[l], d = dp[l];
+    const bool ok = s >= 0 && s < nodes && d >= 0 && d < nodes;
+    s += off, d += off;
     return ok;
 }
 
@@ -70,6 +76,11 @@ struct Side {
     float *w;              // [E'] out or null
     const int32_t *deg_ptr;  // offsets whose differences are the in-degrees gcn_norm uses
     int key_is_dst;
+    // bucketed build (workspace): [nb + 1] slots per bucket, after k_bk_scan the first slot of each bucket;
+    // [nb] partition cursors; [E + N] partitioned records: edge id (>= E: the appended self loop of node id - E),
+    // other endpoint, key - first node of its bucket
+    int32_t *bk_start, *bk_cur, *bk_eid, *bk_oth;
+    uint16_t *bk_kl;
 };
 
 struct Build {
@@ -102,29 +113,29 @@ __global__ void __launch_bounds__(256)
 k_count(Build b, int nsides) {
     __shared__ int32_t bins[2][kBins];
     __shared__ int64_t base[2];
-    const int64_t e0 = (int64_t)blockIdx.x * blockDim.x, e = e0 + threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = threadIdx.x; i < 2 * kBins; i += 256) (&bins[0][0])[i] = 0;
-    if (threadIdx.x == 0) {
-        int64_t src = 0, dst = 0;
-        load_edge(b.ed, e0, src, dst);                    // e0 < E: the grid covers E edges (garbage ids only move the window)
-        const int64_t k0 = b.s[0].key_is_dst ? dst : src, o0 = b.s[0].key_is_dst ? src : dst;
-        base[0] = k0 - kBins / 2, base[1] = o0 - kBins / 2;
-    }
-    __syncthreads();
+    // every thread fetches its own edge BEFORE the barrier; thread 0's edge (always < E: the grid covers E edges) places
+    // the windows - garbage ids only move them - so the window costs no memory round trip of its own
+    int64_t k = 0, o = 0;
+    bool ok = true;
     if (e < b.E) {
         int64_t src, dst;
-        if (!load_edge(b.ed, e, src, dst)) {
+        ok = load_edge(b.ed, e, src, dst);
+        k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
+    }
+    if (threadIdx.x == 0) base[0] = k - kBins / 2, base[1] = o - kBins / 2;
+    __syncthreads();
+    if (e < b.E) {
+        if (!ok) {
             atomicOr(b.status, 1);
-        } else {
-            const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
-            if (!(b.self_loops && k == o)) {
-                const int64_t rk = k - base[0], ro = o - base[1];
-                if (rk >= 0 && rk < kBins) atomicAdd(&bins[0][rk], 1);
-                else atomicAdd(&b.s[0].cnt[k], 1);
-                if (nsides == 2) {                        // side 1 groups by side 0's other row
-                    if (ro >= 0 && ro < kBins) atomicAdd(&bins[1][ro], 1);
-                    else atomicAdd(&b.s[1].cnt[o], 1);
-                }
+        } else if (!(b.self_loops && k == o)) {
+            const int64_t rk = k - base[0], ro = o - base[1];
+            if (rk >= 0 && rk < kBins) atomicAdd(&bins[0][rk], 1);
+            else atomicAdd(&b.s[0].cnt[k], 1);
+            if (nsides == 2) {                            // side 1 groups by side 0's other row
+                if (ro >= 0 && ro < kBins) atomicAdd(&bins[1][ro], 1);
+                else atomicAdd(&b.s[1].cnt[o], 1);
             }
         }
     }
@@ -295,28 +306,20 @@ __global__ void __launch_bounds__(256)
 k_fill(Build b, int nsides) {
     __shared__ int32_t bins[2][kBins];
     __shared__ int64_t base[2];
-    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x, t = t0 + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = threadIdx.x; i < 2 * kBins; i += 256) (&bins[0][0])[i] = 0;
-    if (threadIdx.x == 0) {
-        int64_t k0 = t0 - b.E, o0 = t0 - b.E;              // a block of appended self loops: keys = node ids
-        if (t0 < b.E) {
-            int64_t src = 0, dst = 0;
-            load_edge(b.ed, t0, src, dst);
-            k0 = b.s[0].key_is_dst ? dst : src, o0 = b.s[0].key_is_dst ? src : dst;
-        }
-        base[0] = k0 - kBins / 2, base[1] = o0 - kBins / 2;
-    }
-    __syncthreads();
     int64_t key[2] = {-1, -1};                             // -1: this thread places nothing on that side
-    if (t < b.E) {
+    int64_t k0 = t - b.E, o0 = t - b.E;                    // thread 0 of a block of appended self loops: keys = node ids
+    if (t < b.E) {                                         // (own edge fetched before the barrier, as in k_count)
         int64_t src, dst;
-        if (load_edge(b.ed, t, src, dst)) {
-            const int64_t k = b.s[0].key_is_dst ? dst : src, o = b.s[0].key_is_dst ? src : dst;
-            if (!(b.self_loops && k == o)) key[0] = k, key[1] = o;
-        }
+        const bool ok = load_edge(b.ed, t, src, dst);
+        k0 = b.s[0].key_is_dst ? dst : src, o0 = b.s[0].key_is_dst ? src : dst;
+        if (ok && !(b.self_loops && k0 == o0)) key[0] = k0, key[1] = o0;
     } else if (b.self_loops && t < b.E + b.N) {
         key[0] = key[1] = t - b.E;
     }
+    if (threadIdx.x == 0) base[0] = k0 - kBins / 2, base[1] = o0 - kBins / 2;
+    __syncthreads();
     int slot[2] = {-1, -1};                                // local slot inside the block's share (-1: direct global)
 #pragma unroll
     for (int sd = 0; sd < 2; ++sd) {
@@ -363,7 +366,8 @@ __device__ __forceinline__ void emit_one(const Build &b, const Side &sd, int32_t
 
 // Sort a[0..S) ascending with the bitonic network in its all-ascending-comparator form (the
 // first step of every merge compares mirrored positions), so positions >= S can be treated as
-// +infinity without ever being stored.  Ids are distinct: no stability question.
+// +infinity without ever being stored.  Ids are distinct: no stability question.  (The element type is the
+// accessor's: int32 ids, or 64-bit (id, payload) records ordered by the id in the high word.)
 template <typename Get, typename Put>
 __device__ __forceinline__ void bitonic_sort(int S, Get get, Put put) {
     int P = 2;
@@ -374,7 +378,7 @@ __device__ __forceinline__ void bitonic_sort(int S, Get get, Put put) {
             const int blk = t / half, off = t - blk * half;
             const int i = blk * size + off, j = blk * size + size - 1 - off;
             if (j < S) {
-                const int32_t a = get(i), c = get(j);
+                const auto a = get(i), c = get(j);
                 if (a > c) { put(i, c); put(j, a); }
             }
         }
@@ -383,7 +387,7 @@ __device__ __forceinline__ void bitonic_sort(int S, Get get, Put put) {
             for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
                 const int i = 2 * stride * (t / stride) + (t % stride), j = i + stride;
                 if (j < S) {
-                    const int32_t a = get(i), c = get(j);
+                    const auto a = get(i), c = get(j);
                     if (a > c) { put(i, c); put(j, a); }
                 }
             }
@@ -589,12 +593,291 @@ k_morton(const float *pos, int64_t ld, int64_t n, float lx, float ly, float lz, 
     codes[i] = (int64_t)(spread10(a) | (spread10(b) << 1) | (spread10(c) << 2));
 }
 
+// ---- bucketed build (r04): edge lists in ARBITRARY order -----------------------------------------------------------
+// The pipeline above is fast when consecutive edges name nearby nodes (mesh batches: every key inside the block's
+// LDS window).  A radius graph whose nodes were relabelled (Morton order) keeps its edge ORDER: 92 % of the keys of
+// the 100k-point graph fall outside any window (tools/exp/csr_ab.sh), and every one of them costs a device-scope
+// atomic - k_count 78 us, of which 70 us are those atomics (8 us without them), k_fill 112 us, k_emit (dependent
+// gathers through tmp / edge_index / ptr) 62 us for 1.1 M edges: ~10 G scattered atomics per second is what the chip
+// gives, whatever the XCD mapping.  This build does not issue one per edge.  Nodes are cut into buckets of 2^shift
+// consecutive ids; a partition pass (histogram per workgroup in LDS, ONE global atomic per workgroup and non-empty
+// bucket) moves (edge id, other endpoint, key - bucket base) records into per-bucket ranges - which are the bucket's
+// final slot range too, since ptr is monotone in the node id - and ONE workgroup per (bucket, side) does the rest in
+// LDS: degrees, their scan (= ptr), slots by LDS cursors, rank of every id inside its group, perm / other.  Buckets
+// larger than the LDS pass are processed in several passes over runs of consecutive nodes; a single node beyond it is
+// sorted in place in its output range.  The weights need both endpoints' degrees: a last pass over the finished ptr.
+// Same arrays as the pipeline above, bit for bit (the stable sort by key is unique).
+constexpr int kBkEdges = 12288;       // slots of one pass of a bucket held in LDS (8 B record + 2 B local key)
+constexpr int kBkMaxShift = 11;       // <= 2048 nodes per bucket (LDS offsets + cursors)
+constexpr int kBkNodes = 1 << kBkMaxShift;
+constexpr int kBkMaxBuckets = 8192;   // per side (LDS histograms of the partition passes: 2 x 32 KiB)
+constexpr int kBkEpt = 4;             // slots per thread of the partition passes (1024 threads: 4096 per workgroup)
+
+struct Buckets {
+    int shift, nb;         // 2^shift nodes per bucket, nb buckets per side
+};
+
+// slot t of the build - an input edge (t < E) or an appended self loop -> key of side 0 and the other endpoint;
+// false when the slot places nothing (invalid ids: *bad; an input self loop that is being replaced; padding)
+__device__ __forceinline__ bool slot_keys(const Build &b, int64_t t, int32_t &k, int32_t &o, bool &bad) {
+    if (t < b.E) {
+        int64_t src, dst;
+        if (!load_edge(b.ed, t, src, dst)) {
+            bad = true;
+            return false;
+        }
+        k = (int32_t)(b.s[0].key_is_dst ? dst : src), o = (int32_t)(b.s[0].key_is_dst ? src : dst);
+        return !(b.self_loops && k == o);
+    }
+    if (b.self_loops && t < b.E + b.N) {
+        k = o = (int32_t)(t - b.E);
+        return true;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(1024)
+k_bk_count(Build b, Buckets bk, int nsides) {
+    __shared__ int32_t hist[2][kBkMaxBuckets];
+    for (int i = threadIdx.x; i < bk.nb; i += 1024) hist[0][i] = 0, hist[1][i] = 0;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * (1024 * kBkEpt) + threadIdx.x;
+    int32_t k[kBkEpt], o[kBkEpt];
+    bool ok[kBkEpt], bad = false;
+#pragma unroll
+    for (int j = 0; j < kBkEpt; ++j) ok[j] = slot_keys(b, t0 + j * 1024, k[j], o[j], bad);
+#pragma unroll
+    for (int j = 0; j < kBkEpt; ++j) {
+        if (!ok[j]) continue;
+        atomicAdd(&hist[0][k[j] >> bk.shift], 1);
+        if (nsides == 2) atomicAdd(&hist[1][o[j] >> bk.shift], 1);
+    }
+    if (bad) atomicOr(b.status, 1);
+    __syncthreads();
+    for (int sd = 0; sd < nsides; ++sd)
+        for (int i = threadIdx.x; i < bk.nb; i += 1024) {
+            const int c = hist[sd][i];
+            if (c) atomicAdd(&b.s[sd].bk_start[i], c);
+        }
+}
+
+__global__ void __launch_bounds__(1024)
+k_bk_scan(Build b, Buckets bk) {
+    const int sd = blockIdx.x, tid = threadIdx.x;
+    constexpr int kPer = kBkMaxBuckets / 1024;
+    int v[kPer], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = kPer * tid + j;
+        v[j] = i < bk.nb ? b.s[sd].bk_start[i] : 0;
+        sum += v[j];
+    }
+    int total;
+    int run = block_incl_scan<16>(sum, &total) - sum;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = kPer * tid + j;
+        if (i < bk.nb) b.s[sd].bk_start[i] = run, b.s[sd].bk_cur[i] = run;
+        run += v[j];
+    }
+    if (tid == 0) b.s[sd].bk_start[bk.nb] = total, b.s[sd].ptr[b.N] = total;
+}
+
+__global__ void __launch_bounds__(1024)
+k_bk_scatter(Build b, Buckets bk, int nsides) {
+    __shared__ int32_t hist[2][kBkMaxBuckets];
+    for (int i = threadIdx.x; i < bk.nb; i += 1024) hist[0][i] = 0, hist[1][i] = 0;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * (1024 * kBkEpt) + threadIdx.x;
+    int32_t k[kBkEpt], o[kBkEpt], s0[kBkEpt], s1[kBkEpt];
+    bool ok[kBkEpt], bad = false;                          // (invalid ids were flagged by k_bk_count)
+#pragma unroll
+    for (int j = 0; j < kBkEpt; ++j) ok[j] = slot_keys(b, t0 + j * 1024, k[j], o[j], bad);
+#pragma unroll
+    for (int j = 0; j < kBkEpt; ++j) {                     // place inside the workgroup's share of the bucket
+        s0[j] = s1[j] = 0;
+        if (!ok[j]) continue;
+        s0[j] = atomicAdd(&hist[0][k[j] >> bk.shift], 1);
+        if (nsides == 2) s1[j] = atomicAdd(&hist[1][o[j] >> bk.shift], 1);
+    }
+    __syncthreads();
+    for (int sd = 0; sd < nsides; ++sd)                    // share sizes -> reserved first record
+        for (int i = threadIdx.x; i < bk.nb; i += 1024) {
+            const int c = hist[sd][i];
+            if (c) hist[sd][i] = atomicAdd(&b.s[sd].bk_cur[i], c);
+        }
+    __syncthreads();
+    const int32_t mask = (1 << bk.shift) - 1;
+#pragma unroll
+    for (int j = 0; j < kBkEpt; ++j) {
+        if (!ok[j]) continue;
+        const int32_t t = (int32_t)(t0 + j * 1024);
+        int pos = hist[0][k[j] >> bk.shift] + s0[j];
+        b.s[0].bk_eid[pos] = t, b.s[0].bk_oth[pos] = o[j], b.s[0].bk_kl[pos] = (uint16_t)(k[j] & mask);
+        if (nsides == 2) {
+            pos = hist[1][o[j] >> bk.shift] + s1[j];
+            b.s[1].bk_eid[pos] = t, b.s[1].bk_oth[pos] = k[j], b.s[1].bk_kl[pos] = (uint16_t)(o[j] & mask);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_bk_build(Build b, Buckets bk) {
+    __shared__ unsigned long long rec[kBkEdges];            // (edge id << 32) | other endpoint, by slot of the pass
+    __shared__ uint16_t skl[kBkEdges];                      // local key of the slot
+    __shared__ int32_t excl[kBkNodes + 4], cur[kBkNodes], biglist[kBkNodes];
+    __shared__ int nbig;
+    const int sd = blockIdx.y, bkt = blockIdx.x, tid = threadIdx.x;
+    const Side &S = b.s[sd];
+    const int32_t n0 = bkt << bk.shift;
+    const int nn = (int)(b.N - n0 < (1 << bk.shift) ? b.N - n0 : (1 << bk.shift));
+    const int32_t r0 = b.s[sd].bk_start[bkt], n = b.s[sd].bk_start[bkt + 1] - r0;
+    const int32_t *__restrict__ ge = b.s[sd].bk_eid + r0, *__restrict__ go = b.s[sd].bk_oth + r0;
+    const uint16_t *__restrict__ gk = b.s[sd].bk_kl + r0;
+    // degrees of the bucket's nodes, their scan = this bucket's slice of ptr
+    for (int i = tid; i < nn; i += 1024) cur[i] = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 8 * 1024) {             // (a chunk's loads in flight before the first use: one
+        uint16_t kv[8];                                    // workgroup per CU - what hides the latency is the
+#pragma unroll                                             // number of loads a wave has outstanding)
+        for (int j = 0; j < 8; ++j) {
+            const int i = c0 + j * 1024 + tid;
+            kv[j] = i < n ? gk[i] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j * 1024 + tid < n) atomicAdd(&cur[kv[j]], 1);
+    }
+    __syncthreads();
+    constexpr int kPer = kBkNodes / 1024;
+    int v[kPer], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = kPer * tid + j;
+        v[j] = i < nn ? cur[i] : 0;
+        sum += v[j];
+    }
+    int total;
+    int run = block_incl_scan<16>(sum, &total) - sum;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = kPer * tid + j;
+        if (i < nn) excl[i] = run, S.ptr[n0 + i] = r0 + run;
+        run += v[j];
+    }
+    if (tid == 0) excl[nn] = total;
+    __syncthreads();
+    auto emit = [&](unsigned long long r, int kl, int32_t out) {
+        S.perm[out] = (int32_t)(r >> 32);
+        S.other[out] = (int32_t)(uint32_t)r;
+        if (S.w) S.w[out] = __int_as_float(n0 + kl);       // the slot's key, for k_bk_weights
+    };
+    for (int lo = 0; lo < nn;) {
+        // the longest run of nodes [lo, hi) whose slots fit one LDS pass (uniform binary search in the offsets)
+        const int base = excl[lo];
+        int hi = lo, z = nn;
+        while (hi < z) {
+            const int m = (hi + z + 1) >> 1;
+            if (excl[m] - base <= kBkEdges) hi = m;
+            else z = m - 1;
+        }
+        if (hi == lo) {
+            // one node with more slots than a pass holds: its ids go to its perm range in arrival order, the
+            // workgroup sorts them there (in place in global memory, as k_emit does for its longest groups) and
+            // looks the other endpoints up again
+            const int deg = excl[lo + 1] - base;
+            volatile int32_t *vs = S.perm + r0 + base;
+            if (tid == 0) nbig = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024)
+                if (gk[i] == lo) vs[atomicAdd(&nbig, 1)] = ge[i];
+            __syncthreads();
+            bitonic_sort(deg, [&](int i) { return (int32_t)vs[i]; }, [&](int i, int32_t x) { vs[i] = x; });
+            for (int q = tid; q < deg; q += 1024) {
+                const int32_t eid = vs[q];
+                int64_t o = n0 + lo;
+                if (eid < b.E) {
+                    int64_t src, dst;
+                    load_edge(b.ed, eid, src, dst);
+                    o = S.key_is_dst ? src : dst;
+                }
+                S.other[r0 + base + q] = (int32_t)o;
+                if (S.w) S.w[r0 + base + q] = __int_as_float(n0 + lo);
+            }
+            __syncthreads();
+            lo += 1;
+            continue;
+        }
+        const int m = excl[hi] - base;
+        if (m > 0) {
+            for (int i = lo + tid; i < hi; i += 1024) cur[i] = excl[i] - base;
+            if (tid == 0) nbig = 0;
+            __syncthreads();
+            for (int c0 = 0; c0 < n; c0 += 4 * 1024) {
+                int kv[4];
+                int32_t ev[4], ov[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = c0 + j * 1024 + tid;
+                    kv[j] = -1, ev[j] = ov[j] = 0;
+                    if (i < n) kv[j] = gk[i], ev[j] = ge[i], ov[j] = go[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (kv[j] < lo || kv[j] >= hi) continue;
+                    const int pos = atomicAdd(&cur[kv[j]], 1);
+                    rec[pos] = ((unsigned long long)(uint32_t)ev[j] << 32) | (uint32_t)ov[j];
+                    skl[pos] = (uint16_t)kv[j];
+                }
+            }
+            __syncthreads();
+            for (int p = tid; p < m; p += 1024) {
+                const int kl = skl[p];
+                const unsigned long long r = rec[p];
+                const int gb = excl[kl] - base, gend = excl[kl + 1] - base;
+                if (gend - gb > kRankLoop) {                // a long group: sorted by the workgroup below
+                    if (p == gb) biglist[atomicAdd(&nbig, 1)] = kl;
+                    continue;
+                }
+                int rank = 0;
+                int q = gb;
+                for (; q + 4 <= gend; q += 4) {             // four independent LDS reads per trip
+                    const unsigned long long a0 = rec[q], a1 = rec[q + 1], a2 = rec[q + 2], a3 = rec[q + 3];
+                    rank += (a0 < r) + (a1 < r) + (a2 < r) + (a3 < r);
+                }
+                for (; q < gend; ++q) rank += rec[q] < r;
+                emit(r, kl, r0 + base + gb + rank);
+            }
+            __syncthreads();
+            for (int g = 0; g < nbig; ++g) {
+                const int kl = biglist[g], gb = excl[kl] - base, len = excl[kl + 1] - excl[kl];
+                bitonic_sort(len, [&](int i) { return rec[gb + i]; }, [&](int i, unsigned long long x) { rec[gb + i] = x; });
+                for (int q = tid; q < len; q += 1024) emit(rec[gb + q], kl, r0 + base + gb + q);
+                __syncthreads();
+            }
+        }
+        lo = hi;
+    }
+}
+
+// gcn_norm weights of a finished side: dis[source] * 1 * dis[destination] with the degrees deg_ptr names (the
+// expression of emit_one).  One thread per slot; k_bk_build left the slot's key in w[slot].
+__global__ void __launch_bounds__(256)
+k_bk_weights(Build b) {
+    const Side &sd = b.s[blockIdx.y];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!sd.w || p >= sd.ptr[b.N]) return;
+    const float dk = inv_sqrt_deg(sd.deg_ptr, __float_as_int(sd.w[p])), dother = inv_sqrt_deg(sd.deg_ptr, sd.other[p]);
+    sd.w[p] = sd.key_is_dst ? dother * 1.0f * dk : dk * 1.0f * dother;
+}
+
 static inline int64_t align16(int64_t b) { return (b + 15) & ~int64_t(15); }
 
 static inline int64_t side_bytes(int64_t E, int64_t N) {
     const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
     return 2 * align16(4 * (N + 4)) + align16(4 * (E + N + 1)) + align16(4 * (ntiles + 2)) +
-           align16(4 * (N + 2));
+           align16(4 * (N + 2)) +
+           2 * align16(4 * (kBkMaxBuckets + 1)) + 2 * align16(4 * (E + N)) + align16(2 * (E + N));   // bucketed build
 }
 
 static char *carve_side(Side &sd, char *ws, int64_t E, int64_t N) {
@@ -609,7 +892,38 @@ static char *carve_side(Side &sd, char *ws, int64_t E, int64_t N) {
     ws += align16(4 * (ntiles + 2));
     sd.big = (int32_t *)ws;
     ws += align16(4 * (N + 2));
+    sd.bk_start = (int32_t *)ws;
+    ws += align16(4 * (kBkMaxBuckets + 1));
+    sd.bk_cur = (int32_t *)ws;
+    ws += align16(4 * (kBkMaxBuckets + 1));
+    sd.bk_eid = (int32_t *)ws;
+    ws += align16(4 * (E + N));
+    sd.bk_oth = (int32_t *)ws;
+    ws += align16(4 * (E + N));
+    sd.bk_kl = (uint16_t *)ws;
+    ws += align16(2 * (E + N));
     return ws;
+}
+
+// The bucketed build is for edge lists the windowed pipeline cannot serve: large ones (DC_CSR_BUCKETS_MIN slots,
+// default 2^19 - above the mesh batches of the reference's configurations, merged branches and self loops included,
+// which keep their order and are served by the windowed pipeline in ~30 us; the host cannot see the order).  Nodes per bucket: a
+// power of two such that an average bucket fills at most a quarter of one LDS pass (the dense regions of a point
+// cloud hold several times the average; 100k-point graph: 256 nodes, 154 us against 169 us with 512).  DC_CSR_BUCKETS = 0 / 1 forces the
+// choice, DC_CSR_BUCKET_SHIFT the bucket size (tests: multi-pass buckets and single-node passes at small sizes).
+static bool bucket_plan(int64_t slots, int64_t N, Buckets &bk) {
+    const char *mode = getenv("DC_CSR_BUCKETS"), *min_s = getenv("DC_CSR_BUCKETS_MIN"), *sh = getenv("DC_CSR_BUCKET_SHIFT");
+    if (mode && atoi(mode) == 0) return false;
+    const int64_t min_slots = min_s ? atoll(min_s) : (int64_t)1 << 19;
+    if (!(mode && atoi(mode) == 1) && slots < min_slots) return false;
+    int s = 4;
+    while (s < kBkMaxShift && ((int64_t)2 << s) * slots <= (int64_t)(kBkEdges / 4) * N) ++s;
+    if (sh) s = atoi(sh) < 1 ? 1 : (atoi(sh) > kBkMaxShift ? kBkMaxShift : atoi(sh));
+    while (s < kBkMaxShift && ((N + ((int64_t)1 << s) - 1) >> s) > kBkMaxBuckets) ++s;
+    const int64_t nb = (N + ((int64_t)1 << s) - 1) >> s;
+    if (nb > kBkMaxBuckets) return false;
+    bk.shift = s, bk.nb = (int)nb;
+    return true;
 }
 
 static int run_build(Build &b, int nsides, hipStream_t stream, const char *what) {
@@ -621,6 +935,20 @@ static int run_build(Build &b, int nsides, hipStream_t stream, const char *what)
     }
     const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
     const int64_t slots = E + (b.self_loops ? N : 0);
+    Buckets bk{};
+    if (slots > 0 && bucket_plan(slots, N, bk)) {
+        for (int s = 0; s < nsides; ++s) hipMemsetAsync(b.s[s].bk_start, 0, 4 * (size_t)(bk.nb + 1), stream);
+        hipMemsetAsync(b.status, 0, sizeof(int32_t), stream);
+        const unsigned pb = (unsigned)((slots + 1024 * kBkEpt - 1) / (1024 * kBkEpt));
+        DC_LAUNCH(k_bk_count, dim3(pb), dim3(1024), 0, stream, b, bk, nsides);
+        DC_LAUNCH(k_bk_scan, dim3(nsides), dim3(1024), 0, stream, b, bk);
+        DC_LAUNCH(k_bk_scatter, dim3(pb), dim3(1024), 0, stream, b, bk, nsides);
+        DC_LAUNCH(k_bk_build, dim3((unsigned)bk.nb, nsides), dim3(1024), 0, stream, b, bk);
+        bool any_w = false;
+        for (int s = 0; s < nsides; ++s) any_w = any_w || b.s[s].w;
+        if (any_w) DC_LAUNCH(k_bk_weights, dim3((unsigned)((slots + 255) / 256), nsides), dim3(256), 0, stream, b);
+        return check_launch(what);
+    }
     DC_LAUNCH(k_init, dim3((unsigned)((N + 255) / 256), nsides), dim3(256), 0, stream, b);
     if (E > 0)
         DC_LAUNCH(k_count, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, b, nsides);
