@@ -22,6 +22,10 @@
 //                in place in global memory beyond) -- O(S log^2 S), no O(deg^2) walk
 //                on hubs; then perm/other/w are written at ptr[key]+rank, so the
 //                result is the stable sort no matter how the atomics interleaved.
+//
+// Large edge lists (run_build: bucket_plan) take the bucketed build further down instead - k_bk_count / k_bk_scan /
+// k_bk_scatter partition the slots by node bucket, k_bk_build finishes a bucket per workgroup in LDS, k_bk_weights
+// writes the gcn_norm weights: same arrays, no atomic per edge, indifferent to the order of the edges.
 #include "dc_common.h"
 
 namespace dc {

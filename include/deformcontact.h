@@ -91,7 +91,10 @@ int dc_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int key_row,
  * source, the transposed hop of the backward pass), identical to two dc_csr_build calls with
  * deg_ptr = ptr_f for the second.  w_f / w_b both NULL or both set.  This is what one
  * `conv(x, edge_index)` of the reference needs per NEW edge_index (model.py:71,77); it is cheap
- * enough (tens of microseconds at the batch-32 shape) to sit inside a captured training step. */
+ * enough (tens of microseconds at the batch-32 shape) to sit inside a captured training step.
+ * Edge lists of 2^19 slots and more (E, + N with self loops) take the bucketed build - partition by
+ * node bucket, one workgroup per bucket, no atomic per edge: the same arrays whatever the order of
+ * the edges (a relabelled radius graph; env DC_CSR_BUCKETS = 0 / 1 forces the choice). */
 int64_t dc_graph_workspace_bytes(int64_t E, int64_t N);
 int dc_graph_build(const int64_t *edge_index, int64_t E, int64_t N, int self_loops,
                    int32_t *ptr_f, int32_t *other_f, int32_t *perm_f, float *w_f,
