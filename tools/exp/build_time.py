@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""dc_graph_build (both sides + gcn_norm) on the B=32 graphs, graph-replayed: us per build (soft, rigid, merged;
-and the one-launch segmented build of the same batches)."""
+"""dc_graph_build (both sides + gcn_norm) on the B=32 graphs (or `build_time.py B`), graph-replayed: us per build (soft,
+rigid, merged; and the one-launch segmented build of the same batches).  DC_CSR_BUCKETS=0 / 1 forces the windowed /
+the bucketed pipeline for the three global builds."""
 import os
 import sys
 
@@ -14,7 +15,7 @@ from deformcontact_amd.graph import GraphIndex  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    rest, _, rig = synth.make_batch(32)
+    rest, _, rig = synth.make_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
     parts = [(rest.edge_index.to(dev), rest.x.shape[0]), (rig.edge_index.to(dev), rig.x.shape[0])]
     seg = [GraphIndex(*parts[0], segments=rest.segments()), GraphIndex(*parts[1], segments=rig.segments())]
     assert all(g._segments is not None for g in seg)
