@@ -517,11 +517,177 @@ k_dw_bf16(DwBf16Params p) {
     }
 }
 
+// ---- the same block with both operands by LDS-DMA (r04) --------------------------------------------------------------
+// k_dw_bf16 above moves every stage through registers, two stages deep, one __syncthreads() per 32 nodes: on the
+// 100k-point graph of configs[4] (98 stages per workgroup) a launch took 212 us - 2.1 us per stage, the loaded HBM
+// latency of one register-staged prefetch, 0.10 of the MFMA peak and 1.2 TB/s of compulsory bytes.  Here the eight MFMA
+// waves only read LDS and multiply; four loading waves (LDS-DMA: no registers, no VALU, no ds_write) keep FIVE stages
+// of 24 KiB in flight per CU in a ring of six, retired with a counted vmcnt and one raw s_barrier per stage (the
+// protocol of k_fwd_bf16).  The DMA writes lane-linear 1 KiB pieces, so a stage image is dense ([node][o] 256 B rows,
+// [node][f] 512 B rows) and the bank spread the padded rows gave the transposing reads comes from an XOR of the 64-byte
+// column chunk with node & 3, applied to the per-lane SOURCE offset.  Rows past the chunk's end fall out of the buffer
+// resource's range and arrive as zeros.  Same products in the same order, the bias sums taken from the LDS image with
+// the thread -> (row, columns) map of k_dw_bf16: bit-identical partials.
+constexpr int kDwdSlots = 6, kDwdAhead = 5;
+constexpr int kDwdRowA = 128 * 2, kDwdRowB = 256 * 2;                    // dense node rows of the g / x image
+constexpr int kDwdStage = kDwbK * (kDwdRowA + kDwdRowB);                 // 24,576 B
+#define DC_DWD_WAITVM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))   // s_waitcnt vmcnt(n) only
+
+template <int ROWB>
+__device__ __forceinline__ bf16x8 dwd_tr_operand(const char *plane, int m0) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int h = g >> 1;
+    // node rows 8 h + q and + 4 (both have node & 3 = q), column chunk m0 / 32 stored at chunk ^ q
+    const char *a = plane + (8 * h + q) * ROWB + (((m0 >> 5) ^ q) << 6) + 32 * (g & 1) + 8 * pp;
+    const dwb_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dwb_lds_s16x4 *)(uintptr_t)(a));
+    const dwb_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((dwb_lds_s16x4 *)(uintptr_t)(a + 4 * ROWB));
+    union { dwb_s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo4, u.s[1] = hi4;
+    return u.b;
+}
+
+__global__ void __launch_bounds__(768)
+k_dw_bf16d(DwBf16Params p) {
+    __shared__ __attribute__((aligned(16))) char lds[kDwdSlots * kDwdStage];
+    const unsigned nto = (unsigned)(p.Fo / 128), nfb = (unsigned)(p.Fi / 256);
+    const unsigned per_chunk = nto * nfb * (unsigned)p.nseg;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned chunk = lb / per_chunk, rem = lb % per_chunk;
+    const int s = (int)(rem / (nto * nfb));
+    const int64_t o0 = (int64_t)((rem / nfb) % nto) * 128, f0 = (int64_t)(rem % nfb) * 256;
+    const int64_t n_beg = (int64_t)chunk * p.chunk_rows;
+    const int64_t n_end = (n_beg + p.chunk_rows < p.N) ? n_beg + p.chunk_rows : p.N;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const bool do_bias = p.bias_partial && s == 0 && f0 == 0;
+    const int nst = (int)((n_end - n_beg + kDwbK - 1) / kDwbK);
+    const int64_t rows = n_end - n_beg;
+
+    if (wid >= 8) {
+        // ------------------------------------------------------------------ loading waves: LDS-DMA only
+        // g plane: 8 instructions per stage (4 node rows x 256 B each; lane l = row l >> 4, piece l & 15), x plane: 16
+        // (2 node rows x 512 B; lane l = row l >> 5, piece l & 31); piece i = chunk i >> 2, part i & 3 of its row
+        // fetches source chunk (i >> 2) ^ (node & 3).  Wave w issues g instructions 2 w, 2 w + 1 and x instructions
+        // 4 w .. 4 w + 3 of every stage: 6 per wave and stage.
+        const int w = wid - 8;
+        if (rows > 0) {
+            const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t *>(p.g + n_beg * p.ldg + o0), 0, (int)(((rows - 1) * p.ldg + 128) * 2), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t *>(p.x + n_beg * p.ldx + (int64_t)s * p.Fi + f0), 0,
+                (int)(((rows - 1) * p.ldx + 256) * 2), 0x00020000);
+            const int rgl = lane >> 4, ig = lane & 15;
+            const int voffg = (int)((int64_t)rgl * p.ldg * 2) + ((((ig >> 2) ^ rgl) << 6) | ((ig & 3) << 4));
+            const int rxl = lane >> 5, ix = lane & 31;
+            int voffx[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                voffx[e] = (int)((int64_t)rxl * p.ldx * 2) + ((((ix >> 2) ^ (2 * e + rxl)) << 6) | ((ix & 3) << 4));
+            const int gstep = (int)(4 * p.ldg * 2), xstep = (int)(2 * p.ldx * 2);       // bytes per instruction's rows
+            const int gstage = (int)(kDwbK * p.ldg * 2), xstage = (int)(kDwbK * p.ldx * 2);
+            auto stage = [&](int st) {
+                char *dst = lds + (st % kDwdSlots) * kDwdStage;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = 2 * w + j;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg_, (void __attribute__((address_space(3))) *)(dst + c * 1024), 16,
+                                                             voffg, c * gstep + st * gstage, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * w + j;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rx_, (void __attribute__((address_space(3))) *)(dst + kDwbK * kDwdRowA + c * 1024), 16, voffx[j & 1],
+                        c * xstep + st * xstage, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int st = 0; st < kDwdAhead; ++st)
+                if (st < nst) stage(st);
+            for (int it = 0; it < nst; ++it) {
+                // all but the stages after `it` (at most kDwdAhead - 1 of them, 6 instructions each) have landed
+                const int later = nst - 1 - it;
+                if (later >= 4) DC_DWD_WAITVM(24);
+                else if (later == 3) DC_DWD_WAITVM(18);
+                else if (later == 2) DC_DWD_WAITVM(12);
+                else if (later == 1) DC_DWD_WAITVM(6);
+                else DC_DWD_WAITVM(0);
+                __builtin_amdgcn_s_barrier();            // publishes stage it; the MFMA waves have left stage it - 1
+                if (it + kDwdAhead < nst) stage(it + kDwdAhead);
+            }
+        }
+        if (do_bias) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ eight MFMA waves (2 x 4), 64 (o) x 64 (f) each
+    const int wm = wid >> 2, wn = wid & 3;
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;                  // bias sums: k_dw_bf16's staging map
+    const int bias_off = rg * kDwdRowA + ((((cg >> 2) ^ (rg & 3)) << 6) | ((cg & 3) << 4));
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[2][2];
+    zero_acc<2>(acc);
+    for (int it = 0; it < nst; ++it) {
+        __builtin_amdgcn_s_barrier();
+        const char *buf = lds + (it % kDwdSlots) * kDwdStage;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) fa[mb] = dwd_tr_operand<kDwdRowA>(buf + ks * 16 * kDwdRowA, wm * 64 + mb * 32);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                fb[nb] = dwd_tr_operand<kDwdRowB>(buf + kDwbK * kDwdRowA + ks * 16 * kDwdRowB, wn * 64 + nb * 32);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+        }
+        if (do_bias) {
+            const uint4 vg = *reinterpret_cast<const uint4 *>(buf + bias_off);
+            const uint32_t d[4] = {vg.x, vg.y, vg.z, vg.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bsum[2 * i] += __uint_as_float(d[i] << 16);
+                bsum[2 * i + 1] += __uint_as_float(d[i] & 0xffff0000u);
+            }
+        }
+    }
+
+    float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
+    for_each_acc<2>(acc, wm, wn, [&](int r, int c, float v) { out[(o0 + r) * p.Fi + f0 + c] = v; });
+    if (do_bias) {                                      // column sums of gm over the chunk's nodes
+        __builtin_amdgcn_s_barrier();                   // every wave has left the ring
+        float *red = reinterpret_cast<float *>(lds);    // [32 node rows][128 o]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[rg * 128 + 8 * cg + i] = bsum[i];
+        __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the stores have reached LDS
+        __builtin_amdgcn_s_barrier();
+        if (threadIdx.x < 128) {
+            float t = 0.f;
+            for (int r = 0; r < 32; ++r) t += red[r * 128 + threadIdx.x];
+            p.bias_partial[(int64_t)chunk * p.Fo + o0 + threadIdx.x] = t;
+        }
+    }
+}
+
 bool dw_bf16_launch(const DwBf16Params &p, hipStream_t hs) {
     if (p.Fo % 128 != 0 || p.Fi % 256 != 0 || p.chunk_rows % kDwbK != 0) return false;
     if (p.ldg % 8 != 0 || p.ldx % 8 != 0 || ((uintptr_t)p.g & 15) || ((uintptr_t)p.x & 15)) return false;
     const int64_t grid = (p.Fo / 128) * (p.Fi / 256) * p.nseg * p.nchunks;
     if (grid >= (int64_t)INT32_MAX) return false;
+    // both operands by LDS-DMA when a chunk's byte offsets fit the buffer instructions' 32 bits (DC_DW_BF16_DMA=0: the
+    // register-staged kernel; bit-identical partials)
+    const char *dma = getenv("DC_DW_BF16_DMA");
+    const int64_t span = (p.chunk_rows + kDwbK) * (p.ldg > p.ldx ? p.ldg : p.ldx) * 2;
+    if (!(dma && atoi(dma) == 0) && span < ((int64_t)1 << 31)) {
+        DC_LAUNCH(k_dw_bf16d, dim3((unsigned)grid), dim3(768), 0, hs, p);
+        return true;
+    }
     DC_LAUNCH(k_dw_bf16, dim3((unsigned)grid), dim3(512), 0, hs, p);
     return true;
 }

@@ -55,6 +55,38 @@ def test_dw_bf16_kernel_vs_float64(n, fi, fo, nseg, bias):
         assert torch.allclose(gws[s], 2 * first[s], rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("n,fi,fo,nseg,bias", [(4096, 256, 256, 4, True), (1003, 256, 128, 1, True), (31, 256, 128, 2, False),
+                                               (100000, 256, 256, 4, True), (1, 256, 128, 1, True)])
+def test_dw_bf16_by_lds_dma_equals_the_register_staged_kernel_bitwise(n, fi, fo, nseg, bias, monkeypatch):
+    """k_dw_bf16d (both operands by LDS-DMA, dense swizzled images, loading waves) against k_dw_bf16: the same
+    products in the same order - identical weight and bias gradients, ragged last stages and chunks included."""
+    L = _lib.lib()
+    st = current_stream_ptr(torch.device(DEV))
+    gen = torch.Generator().manual_seed(n + fo)
+    slab = torch.randn(n, nseg * fi + 64, generator=gen).to(DEV).bfloat16()[:, :nseg * fi]
+    g = torch.randn(n, fo + 8, generator=gen).to(DEV).bfloat16()[:, :fo]
+    nb = L.dc_tag_linear_bwd_dw_bf16_workspace_bytes(n, fi, fo, nseg)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    got = {}
+    for mode, kernel in (("0", "k_dw_bf16"), ("1", "k_dw_bf16d")):
+        monkeypatch.setenv("DC_DW_BF16_DMA", mode)
+        gws = [torch.full((fo, fi), 7.0, device=DEV) for _ in range(nseg)]
+        gb = torch.full((fo,), 7.0, device=DEV) if bias else None
+        scratch.fill_(0xFF)
+        _lib.kernel_trace(True)
+        _lib.check(L.dc_tag_linear_bwd_dw_bf16(g.data_ptr(), g.stride(0), slab.data_ptr(), slab.stride(0), nseg,
+                                               _ptr_array(gws), gb.data_ptr() if bias else None, 0,
+                                               scratch.data_ptr(), nb, n, fi, fo, st), "dw")
+        _lib.kernel_trace(False)
+        names = _lib.kernel_trace_counts()
+        assert any(k.split("(")[0].endswith(kernel) for k in names), (kernel, sorted(names))
+        got[mode] = (gws, gb)
+    for a, b in zip(got["0"][0], got["1"][0]):
+        assert torch.equal(a, b)
+    if bias:
+        assert torch.equal(got["0"][1], got["1"][1])
+
+
 def _double_stack(convs, x, ei, masks=None):
     """float64 evaluation of a stack of TAGConv + ReLU layers on bf16-rounded weights (masks: the HIP path's)."""
     refs = []
