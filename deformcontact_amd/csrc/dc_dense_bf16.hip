@@ -381,6 +381,43 @@ k_mask_grad_bf16(MaskBf16Params p) {
     p.gm[row * p.ldgm + c] = f32_to_bf16_rne_d(v);
 }
 
+// The same with 8 columns per thread and 16-byte accesses (F, the leading dimensions and the pointers allow it whenever
+// the operands are the layer's own buffers): the scalar form above - a 64-bit division per element, 2-byte stores -
+// took 83 us for [100k, 256] (2.5 TB/s).  Same values: the rounding is per element.
+template <bool G_BF16, bool M_BF16>
+__global__ void __launch_bounds__(256)
+k_mask_grad_bf16x8(MaskBf16Params p) {
+    const int per_row = p.F >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = i / per_row;
+    const int c = (int)(i - row * per_row) << 3;
+    if (row >= p.N) return;
+    float v[8], m[8];
+    auto ld8 = [&](const void *base, int64_t off, bool bf, float (&o)[8]) {
+        if (bf) {
+            const uint4 u = *reinterpret_cast<const uint4 *>((const uint16_t *)base + off);
+            const uint32_t d[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[2 * j] = __uint_as_float(d[j] << 16), o[2 * j + 1] = __uint_as_float(d[j] & 0xffff0000u);
+        } else {
+            const float4 a = *reinterpret_cast<const float4 *>((const float *)base + off);
+            const float4 b = *reinterpret_cast<const float4 *>((const float *)base + off + 4);
+            o[0] = a.x, o[1] = a.y, o[2] = a.z, o[3] = a.w, o[4] = b.x, o[5] = b.y, o[6] = b.z, o[7] = b.w;
+        }
+    };
+    ld8(p.g, row * p.ldg + c, G_BF16, v);
+    if (p.mask) {
+        ld8(p.mask, row * p.ldm + c, M_BF16, m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (!(m[j] > 0.f)) v[j] = 0.f;
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (uint32_t)f32_to_bf16_rne_d(v[2 * j]) | ((uint32_t)f32_to_bf16_rne_d(v[2 * j + 1]) << 16);
+    *reinterpret_cast<uint4 *>(p.gm + row * p.ldgm + c) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // dW[o, f] of segment s = sum over nodes n of gm[n, o] * x_s[n, f], fp32 accumulate, per node chunk (partials summed in
 // chunk order by the slab reduce: deterministic).  Shape of k_dw_h2w (dc_dense_split.hip) with plain bf16 operands: a
 // 512-thread workgroup owns a 128 (o) x 256 (f) tile of one segment over one node chunk, a stage is 32 nodes, the [k][m]
@@ -754,6 +791,17 @@ extern "C" int dc_tag_mask_grad_bf16(const void *g, int64_t ldg, int g_is_bf16, 
     DC_REQUIRE(g && gm, "dc_tag_mask_grad_bf16: null pointer");
     MaskBf16Params p{g, out_for_mask, gm, ldg, ldo, ldgm, N, (int)F, g_is_bf16, mask_is_bf16};
     const int64_t total = N * F;
+    auto al = [](const void *q, int64_t ld, int bf) {        // 16-byte pieces of 8 columns: pointer and row pitch aligned
+        return !q || (((uintptr_t)q & 15) == 0 && ld % (bf ? 8 : 4) == 0);
+    };
+    if (F % 8 == 0 && al(g, ldg, g_is_bf16) && al(out_for_mask, ldo, mask_is_bf16) && al(gm, ldgm, 1)) {
+        const dim3 grid((unsigned)((total / 8 + 255) / 256));
+        if (g_is_bf16 && mask_is_bf16) DC_LAUNCH((k_mask_grad_bf16x8<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (g_is_bf16) DC_LAUNCH((k_mask_grad_bf16x8<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (mask_is_bf16) DC_LAUNCH((k_mask_grad_bf16x8<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else DC_LAUNCH((k_mask_grad_bf16x8<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("dc_tag_mask_grad_bf16");
+    }
     DC_LAUNCH(k_mask_grad_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("dc_tag_mask_grad_bf16");
 }

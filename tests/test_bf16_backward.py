@@ -87,6 +87,38 @@ def test_dw_bf16_by_lds_dma_equals_the_register_staged_kernel_bitwise(n, fi, fo,
         assert torch.equal(got["0"][1], got["1"][1])
 
 
+@pytest.mark.parametrize("n,f,off,g_bf16,m_bf16,kernel", [
+    (1000, 256, 0, False, True, "k_mask_grad_bf16x8<false, true>"), (1000, 256, 8, True, True, "k_mask_grad_bf16x8<true, true>"),
+    (333, 64, 0, False, False, "k_mask_grad_bf16x8<false, false>"), (333, 64, 8, True, False, "k_mask_grad_bf16x8<true, false>"),
+    (1000, 256, 4, False, True, "k_mask_grad_bf16"),              # a column slice off the 16-byte grid: scalar kernel
+    (77, 20, 0, False, False, "k_mask_grad_bf16"), (5, 8, 0, True, True, "k_mask_grad_bf16x8<true, true>")])
+def test_mask_grad_bf16_is_the_rounded_masked_gradient(n, f, off, g_bf16, m_bf16, kernel):
+    """dc_tag_mask_grad_bf16 = bf16(g * (out > 0)) element by element (RNE), through the 8-column kernel and the
+    scalar one (model.py:69-78: the ReLU between the layers, backward)."""
+    L = _lib.lib()
+    st = current_stream_ptr(torch.device(DEV))
+    gen = torch.Generator().manual_seed(n + f + off)
+    gfull = torch.randn(n, f + 16, generator=gen).to(DEV)
+    ofull = torch.randn(n, f + 16, generator=gen).to(DEV)
+    ofull[ofull.abs() < 0.3] = 0.0                                          # exact zeros: masked
+    if g_bf16:
+        gfull = gfull.bfloat16()
+    if m_bf16:
+        ofull = ofull.bfloat16()
+    g, o = gfull[:, off:off + f], ofull[:, off:off + f]
+    gm = torch.full((n, f + 8), 3.0, device=DEV).bfloat16()
+    _lib.kernel_trace(True)
+    _lib.check(L.dc_tag_mask_grad_bf16(g.data_ptr(), g.stride(0), int(g_bf16), o.data_ptr(), o.stride(0), int(m_bf16),
+                                       gm.data_ptr(), gm.stride(0), n, f, st), "mask")
+    _lib.kernel_trace(False)
+    names = _lib.kernel_trace_counts()
+    norm = lambda k: k.replace(" ", "").replace("(", "").replace(")", "").replace("dc::", "")   # noqa: E731
+    assert [norm(k) for k in names] == [norm(kernel)], sorted(names)
+    want = torch.where(o.float() > 0, g.float(), torch.zeros((), device=DEV)).bfloat16()
+    assert torch.equal(gm[:, :f], want)
+    assert torch.all(gm[:, f:] == 3.0)                                      # nothing written past F
+
+
 def _double_stack(convs, x, ei, masks=None):
     """float64 evaluation of a stack of TAGConv + ReLU layers on bf16-rounded weights (masks: the HIP path's)."""
     refs = []
