@@ -687,6 +687,16 @@ def radius100k(dev, reps: int = 30):
     t_d = timeit(lambda: L.dc_tag_linear_fwd_bf16(slab.data_ptr(), 4 * f, w.data_ptr(), None, 1, out.data_ptr(),
                                                   f, 1, n, 4 * f, f, st), reps)
     flop = 2.0 * n * 4 * f * f
+    # ... and the weight-gradient block alone: dW_k = gm^T . slab_k (4 segments) + the bias sums, partials reduced
+    import ctypes
+    gmb = torch.randn(n, f, device=dev).bfloat16()
+    gws = [torch.zeros(f, f, device=dev) for _ in range(4)]
+    gbias = torch.zeros(f, device=dev)
+    nb_dw = L.dc_tag_linear_bwd_dw_bf16_workspace_bytes(n, f, f, 4)
+    ws_dw = torch.empty(max(int(nb_dw), 16), dtype=torch.uint8, device=dev)
+    gw_ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in gws])
+    t_dw = timeit(lambda: L.dc_tag_linear_bwd_dw_bf16(gmb.data_ptr(), f, slab.data_ptr(), 4 * f, 4, gw_ptrs, gbias.data_ptr(),
+                                                      0, ws_dw.data_ptr(), nb_dw, n, f, f, st), reps)
     return {
         "workload": f"radius graph, N={n} points (30 % in a dense blob), E={e} (in-degree <= 32), F=256 stored as "
                     "bf16, nodes in Morton order; 2 x TAGConv(256,256,K=3) forward + backward, ReLU fused (configs[4])",
@@ -707,10 +717,15 @@ def radius100k(dev, reps: int = 30):
         "hop_f32": {"us_morton": round(t32_m * 1e3, 1), "us_unordered": round(t32_raw * 1e3, 1),
                     "frac_morton": round(comp32 / t32_m / 1e6 / HBM_PEAK_GBS, 4),
                     "frac_unordered": round(comp32 / t32_raw / 1e6 / HBM_PEAK_GBS, 4)},
-        "dense_bf16": {"kernel": "dc::k_fwd_bf16 (both operands by LDS-DMA, loader wave + 4 MFMA waves)",
+        "dense_bf16": {"kernel": "dc::k_fwd_bf16x<true> (256 x 256 tiles, both operands by LDS-DMA in a four-stage ring)",
                        "us": round(t_d * 1e3, 1), "TFLOPs": round(flop / t_d / 1e9, 1),
                        "frac_of_2500_TF": round(flop / t_d / 1e9 / 2500.0, 4),
                        "GBps_operand_bytes": round((slab.numel() * 2 + out.numel() * 2) / t_d / 1e6, 1)},
+        "dw_bf16": {"kernel": "dc::k_dw_bf16d (128 x 256 tiles per segment and node chunk, both operands by LDS-DMA in a "
+                              "six-stage ring, transposing LDS reads) + dc::k_dw_reduce",
+                    "us": round(t_dw * 1e3, 1), "TFLOPs": round(flop / t_dw / 1e9, 1),
+                    "frac_of_2500_TF": round(flop / t_dw / 1e9 / 2500.0, 4),
+                    "GBps_operand_bytes": round((slab.numel() * 2 + gmb.numel() * 2) / t_dw / 1e6, 1)},
     }
 
 
