@@ -49,6 +49,14 @@ done
 (cd "$R" && timeout -s KILL 300 python tools/exp/dense_h2d_trace.py > "$O/dense_h2d_anatomy.txt" 2>&1)
 (cd "$R" && for f in 0 1; do echo "DC_FUSED_ATTN=$f"; DC_FUSED_ATTN=$f timeout -s KILL 300 python tools/full_step.py --batch 4 --steps 50 --graph 2>&1 | tail -1; done > "$O/attn_b4_stock_vs_library.txt")
 (cd "$R" && timeout -s KILL 600 tools/exp/ab_headline.sh DC_H2_DMA=0 DC_H2_DMA=1 > "$O/ab_headline.txt" 2>&1; timeout -s KILL 600 tools/exp/ab_headline.sh DC_HOP_CHAIN=0 DC_HOP_CHAIN=1 >> "$O/ab_headline.txt" 2>&1)
+# r04 (last day): the global adjacency build of the relabelled 100k-point radius graph, windowed vs bucketed, per kernel;
+# the same on ordered mesh batches; the kernel list of configs[4]'s forward + backward with and without the LDS-DMA dW block
+(cd "$R" && timeout -s KILL 200 python tools/exp/prep_parts.py > "$O/prep_parts.txt" 2>&1)
+(cd "$R" && GRAFT_REPO_ROOT="$R" timeout -s KILL 300 bash tools/exp/csr_ab.sh DC_CSR_BUCKETS=0 DC_CSR_BUCKETS=1 > "$O/csr_build_windowed_vs_bucketed.txt" 2>&1)
+(cd "$R" && for b in 32 128; do for m in 0 1; do echo "== B=$b DC_CSR_BUCKETS=$m"; DC_CSR_BUCKETS=$m timeout -s KILL 200 python tools/exp/build_time.py $b 2>&1 | grep "us per build"; done; done > "$O/csr_build_mesh_batches.txt")
+for M in 0 1; do
+    (cd /tmp && DC_DW_BF16_DMA=$M timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/radius100k_dwdma$M" -- python3 "$R/bench.py" --workload radius100k --no-cpu-baseline > "$R/$O/radius100k_dwdma$M.log" 2>&1)
+done
 # keep the summaries, drop the bulky per-dispatch traces (gpurun_out/ travels back, 64 MiB cap)
 find "$R/$O" -name "*kernel_trace.csv" -delete
 find "$R/$O" -name "*counter_collection.csv" -delete
