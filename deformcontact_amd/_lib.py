@@ -29,6 +29,7 @@ _SIGNATURES = {
     "dc_graph_build_parts": (c_int, [POINTER(_vp), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int,
                                      c_int64, c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, c_int64,
                                      _vp]),
+    "dc_graph_build_plan": (c_int, [c_int64, c_int64, c_int, POINTER(c_int), POINTER(c_int)]),
     "dc_graph_build_segmented": (c_int, [_vp, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64), c_int,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dc_attn_flash_prep": (c_int, [_vp, c_int64, c_int64, _vp, _vp, _vp]),

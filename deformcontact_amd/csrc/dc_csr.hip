@@ -982,6 +982,16 @@ extern "C" int64_t dc_csr_workspace_bytes(int64_t E, int64_t N) {
     return side_bytes(E, N);
 }
 
+extern "C" int dc_graph_build_plan(int64_t E, int64_t N, int self_loops, int *bucket_shift, int *buckets) {
+    DC_REQUIRE(E >= 0 && N >= 0, "dc_graph_build_plan: negative size E=%lld N=%lld", (long long)E, (long long)N);
+    Buckets bk{};
+    const int64_t slots = E + (self_loops ? N : 0);
+    if (N == 0 || slots == 0 || !bucket_plan(slots, N, bk)) return 0;
+    if (bucket_shift) *bucket_shift = bk.shift;
+    if (buckets) *buckets = bk.nb;
+    return 1;
+}
+
 extern "C" int64_t dc_graph_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return DC_EINVAL;
     return 2 * side_bytes(E, N);

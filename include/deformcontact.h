@@ -120,6 +120,14 @@ int dc_graph_build_parts(const int64_t *const *edge_index_parts, const int64_t *
                          int32_t *ptr_b, int32_t *other_b, int32_t *perm_b, float *w_b,
                          int32_t *status, void *workspace, int64_t workspace_bytes, dc_stream_t stream);
 
+/* Which pipeline dc_csr_build / dc_graph_build / dc_graph_build_parts take for an edge set of this size (host only,
+ * no HIP call): returns 1 = bucketed build, with *bucket_shift = log2 of the nodes per bucket and *buckets = buckets
+ * per side; 0 = windowed pipeline (outputs untouched); DC_EINVAL for negative sizes.  The rule: at least
+ * DC_CSR_BUCKETS_MIN slots (env, default 2^19; slots = E, + N with self loops), buckets such that an average
+ * bucket fills at most a quarter of one 12,288-slot LDS pass, at most 2,048 nodes per bucket and 8,192 buckets.
+ * (Diagnostic / test hook: nothing in the reference corresponds to it.) */
+int dc_graph_build_plan(int64_t E, int64_t N, int self_loops, int *bucket_shift, int *buckets);
+
 /* dc_graph_build for a BATCH of graphs whose layout is known (Batch.from_data_list, the loaders of
  * /root/reference/loaders/everyday.py:96 via torch_geometric.data.Batch): graph i owns nodes
  * [node_ptr[i], node_ptr[i+1]) and input edges [edge_ptr[i], edge_ptr[i+1]) and no edge leaves its

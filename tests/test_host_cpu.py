@@ -46,6 +46,35 @@ def test_abi_argument_errors_without_gpu():
     assert rc == -1 and b"key_row" in L.dc_last_error()
 
 
+def test_adjacency_build_plan_rule(monkeypatch):
+    """dc_graph_build_plan: which pipeline an edge set of a given size takes (dc_csr.hip: bucket_plan) - host logic."""
+    L = _lib.lib()
+    for k in ("DC_CSR_BUCKETS", "DC_CSR_BUCKETS_MIN", "DC_CSR_BUCKET_SHIFT"):
+        monkeypatch.delenv(k, raising=False)
+    shift, nb = ctypes.c_int(-1), ctypes.c_int(-1)
+
+    def plan(e, n, loops=0):
+        rc = L.dc_graph_build_plan(e, n, loops, ctypes.byref(shift), ctypes.byref(nb))
+        return rc, shift.value, nb.value
+    assert plan(1_118_107, 100_000) == (1, 8, 391)             # BASELINE configs[4]: 256 nodes per bucket
+    assert plan(196_224, 32_768)[0] == 0                        # the batch-32 soft graph: windowed pipeline
+    assert plan(342_144, 57_344, 1)[0] == 0                     # ... merged with the rigid one, self loops appended
+    assert plan((1 << 19) - 1, 1000)[0] == 0 and plan(1 << 19, 1000)[0] == 1
+    rc, s, b = plan(1 << 20, 1 << 24)                           # many nodes: at most 2,048 per bucket, 8,192 buckets
+    assert (rc, s, b) == (1, 11, 8192)
+    assert plan(1 << 20, (1 << 24) + 1)[0] == 0                 # one bucket too many: windowed
+    rc, s, b = plan(100_000_000, 4096)                          # very dense: the smallest buckets
+    assert (rc, s, b) == (1, 4, 256)
+    assert plan(0, 5)[0] == 0 and plan(5, 0)[0] == 0
+    assert L.dc_graph_build_plan(-1, 5, 0, None, None) < 0
+    monkeypatch.setenv("DC_CSR_BUCKETS", "1")
+    assert plan(100, 50) == (1, 10, 1)                           # forced (tests of the kernels on small graphs)
+    monkeypatch.setenv("DC_CSR_BUCKET_SHIFT", "6")
+    assert plan(100, 50) == (1, 6, 1)
+    monkeypatch.setenv("DC_CSR_BUCKETS", "0")
+    assert plan(1_118_107, 100_000)[0] == 0
+
+
 def test_no_cpu_fallback():
     conv = dc.nn.TAGConv(4, 8)
     x = torch.zeros(5, 4)
