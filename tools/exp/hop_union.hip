@@ -1,4 +1,6 @@
-// tools/exp/hop_union.hip -- EXPERIMENT (written at the end of round 4, NOT yet run on a GPU: no budget left).
+// tools/exp/hop_union.hip -- EXPERIMENT (end of round 4).  Ran once: output bit-identical to dc_spmm_bf16 on both
+// adjacencies of the 100k-point graph; 93 - 98 us per hop against 53 - 55 us for dc_spmm_bf16 on the same box (every
+// workgroup runs its phases serially: ~5.8 us of chained latencies); lists 65 / 99 us per side.  DESIGN.md section 8.
 //
 // The bf16 hop of BASELINE configs[4] (100k-point radius graph, Morton order) gathers E x 512 B = 572 MB of neighbour
 // rows per launch from the L2s and runs at ~72 % of the L2 -> CU rate.  Consecutive Morton
@@ -165,17 +167,27 @@ hu_hop(const int32_t *__restrict__ ptr, const float *__restrict__ w, const uint1
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-    for (int p = beg; p < end; ++p) {
-        const float wv = s_w[p];
-        const uint4 q = *reinterpret_cast<const uint4 *>(rows + (int)s_li[p] * kPartB + 16 * (tid & 7));
-        const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+    for (int p = beg; p < end; p += 4) {                           // four slots' LDS reads in flight, summed in p order
+        float wv[4];
+        uint4 q[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float m0 = wv * __uint_as_float(d[i] << 16);
-            acc[2 * i] = acc[2 * i] + m0;
-            const float m1 = wv * __uint_as_float(d[i] & 0xffff0000u);
-            acc[2 * i + 1] = acc[2 * i + 1] + m1;
+        for (int j = 0; j < 4; ++j) {
+            const int pj = p + j < end ? p + j : end - 1;
+            wv[j] = s_w[pj];
+            q[j] = *reinterpret_cast<const uint4 *>(rows + (int)s_li[pj] * kPartB + 16 * (tid & 7));
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (p + j < end) {
+                const uint32_t d[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float m0 = wv[j] * __uint_as_float(d[i] << 16);
+                    acc[2 * i] = acc[2 * i] + m0;
+                    const float m1 = wv[j] * __uint_as_float(d[i] & 0xffff0000u);
+                    acc[2 * i + 1] = acc[2 * i + 1] + m1;
+                }
+            }
     }
     uint4 o;
     o.x = f32_to_bf16_rne(acc[0]) | ((uint32_t)f32_to_bf16_rne(acc[1]) << 16);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Drive tools/exp/hop_union.hip (the bf16 hop with a run's neighbour rows staged in LDS once) on the Morton-ordered
 100k-point radius graph of BASELINE configs[4]: list build time, bit-identity of the hop against `ops.hop_bf16`
-(dc_spmm_bf16: same products, same order), both timed graph-replayed.  NOT yet run on a GPU (written when round 4's
-budget was spent): the first thing to do with it is to run it.
+(dc_spmm_bf16: same products, same order), both timed graph-replayed.  Round 4's last run: bit-identical, 93 - 98 us
+against 53 - 55 us (DESIGN.md section 8 says why and what it would take).
 
     python tools/exp/hop_union.py
 """
@@ -22,8 +22,10 @@ from deformcontact_amd.graph import GraphIndex, NodeOrder, current_stream_ptr  #
 
 def build():
     so = os.path.join(HERE, "libhopunion.so")
-    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
-                           os.path.join(HERE, "hop_union.hip"), "-o", so])
+    src = os.path.join(HERE, "hop_union.hip")
+    if not (os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src)):
+        subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+                               "-ffp-contract=off", src, "-o", so])
     X = ctypes.CDLL(so)
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
     X.hu_build_lists.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
@@ -56,7 +58,6 @@ def main():
     order = NodeOrder.morton(pos)
     g = GraphIndex(order.relabel(ei), n)
     x = torch.randn(n, f, device=dev).bfloat16()
-    st = current_stream_ptr(dev)
     runs = (n + X.hu_run_rows() - 1) // X.hu_run_rows()
     ulist = torch.empty(runs * X.hu_run_max(), dtype=torch.int32, device=dev)
     ucnt = torch.empty(runs, dtype=torch.int32, device=dev)
@@ -65,7 +66,7 @@ def main():
     for name, adj in (("forward", g.fwd), ("transposed", g.bwd)):
         def lists():
             X.hu_build_lists(adj.ptr.data_ptr(), adj.other.data_ptr(), n, ulist.data_ptr(), ucnt.data_ptr(), lidx.data_ptr(),
-                             status.data_ptr(), st)
+                             status.data_ptr(), current_stream_ptr(dev))
         lists()
         torch.cuda.synchronize()
         assert int(status) == 0, f"{name}: a run exceeds the caps (status {int(status)})"
@@ -77,7 +78,7 @@ def main():
 
         def hop_u():
             X.hu_hop_bf16(adj.ptr.data_ptr(), adj.w.data_ptr(), lidx.data_ptr(), ulist.data_ptr(), ucnt.data_ptr(), x.data_ptr(),
-                          x.stride(0), got.data_ptr(), got.stride(0), n, st)
+                          x.stride(0), got.data_ptr(), got.stride(0), n, current_stream_ptr(dev))
         hop_u()
         torch.cuda.synchronize()
         same = torch.equal(got, want)
