@@ -774,43 +774,28 @@ def measure_traffic(timeout_s: float = 300.0):
 
 
 def launch_ranks(n: int) -> int:
-    """`python bench.py --gpus N` without torchrun: start the N ranks as child processes (this
-    parent never touches the GPU), relay rank 0's JSON line, return the worst exit code."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    import tempfile
-    procs = []
-    with tempfile.TemporaryFile() as out0:
-        for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                          env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
-        rc = 0
-        live = list(procs)
-        deadline = time.time() + float(os.environ.get("DC_LAUNCH_TIMEOUT", "1500"))
-        while live and rc == 0:
-            time.sleep(0.2)
-            if time.time() > deadline:                # a stuck rendezvous must not hold the caller for ever
-                sys.stderr.write("bench.py: ranks still running at the launch deadline (DC_LAUNCH_TIMEOUT): stopping\n")
-                rc = 124
-                break
-            for p in list(live):
-                code = p.poll()
-                if code is not None:
-                    live.remove(p)
-                    rc = rc or code
-        for p in live:                                # a rank failed: stop exactly the PIDs started here
-            p.kill()
-            p.wait()
-        out0.seek(0)
-        sys.stdout.write(out0.read().decode())
+    """`python bench.py --gpus N` without torchrun: start the N ranks as child processes (this parent never touches
+    the GPU; `deformcontact_amd.launch`), relay rank 0's JSON line, return non-zero when a rank failed or the launch
+    deadline (DC_LAUNCH_TIMEOUT seconds, default 1500) passed.  Every rank's stdout / stderr and phase markers go to
+    DC_RANK_LOG_DIR (default: a fresh temporary directory, named on failure).  On failure a JSON line with `error`
+    and the ranks' last phases (`dist.ranks_seen`) is printed instead of the result line."""
+    from deformcontact_amd import launch
+    res = launch.launch_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              timeout=float(os.environ.get("DC_LAUNCH_TIMEOUT", "1500")),
+                              log_dir=os.environ.get("DC_RANK_LOG_DIR") or None)
+    if res.rc == 0:
+        sys.stdout.write(res.stdout0)
         sys.stdout.flush()
-    return 1 if rc else 0
+        return 0
+    if res.timed_out:
+        sys.stderr.write("bench.py: ranks still running at the launch deadline (DC_LAUNCH_TIMEOUT): stopped\n")
+    sys.stderr.write(res.describe() + "\n")
+    summ = res.summary()
+    print(json.dumps({"metric": "M edges/sec fwd+bwd, everyday-deform batch=32 per GPU (encoder hot path)",
+                      "value": None, "n_gpus": n, "error": "launch deadline passed" if res.timed_out else
+                      "a rank exited with a non-zero code", "launch": summ,
+                      "dist": {"world_size": n, "ranks_seen": summ["ranks"]}}), flush=True)
+    return 1
 
 
 def main():
@@ -821,6 +806,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    from deformcontact_amd.launch import install_watchdog, phase
+    if world > 1:
+        install_watchdog()                 # DC_RANK_WATCHDOG_S: periodic stack dumps of a rank that is stuck
+    stall = os.environ.get("DC_TEST_STALL_RANK")       # tests/test_z_launch.py: a rank that never gets anywhere
+    if stall is not None and stall in ("all", str(rank)):
+        phase("stalled (DC_TEST_STALL_RANK)")
+        time.sleep(3600)
+    phase("start")
     traffic, traffic_note = None, "not measured at N > 1"
     if world == 1:
         traffic, traffic_note = (None, "--no-pmc") if args.no_pmc else measure_traffic()
@@ -852,7 +845,9 @@ def main():
             # resolves to an address the ranks cannot reach each other on leaves them waiting in the rendezvous)
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             import datetime
-            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=240))
+            dist.init_process_group(backend, timeout=datetime.timedelta(
+                seconds=float(os.environ.get("DC_GLOO_TIMEOUT_S", "120"))))
+        phase(f"process group up ({backend})")
 
     from deformcontact_amd import dp, ops, synth
     from deformcontact_amd.graph import clear_cache, graph_index
@@ -920,7 +915,10 @@ def main():
 
     ar_events = []                                     # HIP events around the gradient all-reduce (N > 1)
 
+    ar_calls = [0]                                     # all-reduces this rank has issued (phase markers carry it)
+
     def tail():
+        ar_calls[0] += 1
         if world > 1 and len(ar_events) < 4096:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1005,9 +1003,12 @@ def main():
                 if tail_in_graph:
                     tail()
             load(0, 0)
+            phase(f"serial: warm (all-reduces so far {ar_calls[0]})")
             warm(lambda: (fwd_bwd(0), tail()))
             dc_graph.clear_cache()
+            phase(f"serial: capture (all-reduces so far {ar_calls[0]})")
             g = capture(body)
+            phase(f"serial: captured={g is not None}")
 
             def step(i):
                 load(i, 0)
@@ -1024,6 +1025,7 @@ def main():
     def timed(step, steps, warmup):
         for i in range(warmup):
             step(i)
+        phase(f"timed: warmup steps done (all-reduces so far {ar_calls[0]})")
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -1032,6 +1034,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+        phase(f"timed: {steps} steps done (all-reduces so far {ar_calls[0]})")
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1289,9 +1292,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
+    phase("result line printed" if rank == 0 else "waiting for rank 0's kernel-level measurements")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    phase("done")
 
 
 if __name__ == "__main__":

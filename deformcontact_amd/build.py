@@ -28,13 +28,43 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale() -> bool:
-    if not os.path.exists(SO_PATH):
-        return True
-    t = os.path.getmtime(SO_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
         [os.path.join(os.path.dirname(PKG_DIR), "include", "deformcontact.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _digest(paths) -> str:
+    """sha256 over the compile flags and the names + contents of ``paths``."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def source_hash() -> str:
+    """What ``libdeformcontact_hip.so`` is a function of: every ``csrc/*.hip``, every header, the flags."""
+    return _digest(sources() + headers())
+
+
+HASH_PATH = SO_PATH + ".srchash"
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _stale() -> bool:
+    """Content, not mtime: a tree pushed to another machine (gpurun snapshots, checkouts) carries arbitrary file
+    times, and a pushed ``.so`` that matches its sources must never trigger a multi-minute rebuild there."""
+    return not os.path.exists(SO_PATH) or _read(HASH_PATH) != source_hash()
 
 
 def _compile_one(args):
@@ -47,8 +77,8 @@ def _compile_one(args):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """One object per ``csrc/*.hip`` (compiled in parallel, rebuilt only when the source or a
-    header is newer), linked into ``libdeformcontact_hip.so``."""
+    """One object per ``csrc/*.hip`` (compiled in parallel, rebuilt only when the content of the source or of a
+    header has changed), linked into ``libdeformcontact_hip.so``; the library's source hash is stored beside it."""
     if not force and not _stale():
         return SO_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -56,25 +86,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc not found: cannot build libdeformcontact_hip.so for gfx950")
     objdir = os.path.join(os.path.dirname(PKG_DIR), "build", "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")) +
-                [os.path.join(os.path.dirname(PKG_DIR), "include", "deformcontact.h")])
-    jobs, objs = [], []
+    want = source_hash()
+    hdrs = headers()
+    jobs, objs, stamps = [], [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if (force or not os.path.exists(obj)
-                or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)):
+        d = _digest([src] + hdrs)
+        if force or not os.path.exists(obj) or _read(obj + ".srchash") != d:
             jobs.append((hipcc, src, obj, verbose))
+            stamps.append((obj + ".srchash", d))
     if jobs:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 8)) as ex:
             list(ex.map(_compile_one, jobs))
+        for path, d in stamps:
+            with open(path, "w") as f:
+                f.write(d + "\n")
     tmp = SO_PATH + ".tmp"
     cmd = [hipcc, f"--offload-arch={ARCH}", "-fPIC", "-shared"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     os.replace(tmp, SO_PATH)
+    with open(HASH_PATH, "w") as f:
+        f.write(want + "\n")
     return SO_PATH
 
 

@@ -128,8 +128,18 @@ __device__ __forceinline__ void load_chunk(Chunk &c, __amdgpu_buffer_rsrc_t ro, 
 // (one exposed LDS latency per step, not one per slot).  Slots >= MFROM are tested against `rem`, the neighbours the
 // lane's row still has: past its end a slot reads the row of zeros with weight 0.  Slots < MFROM are known - by a
 // wave-wide vote of the caller - to exist in all 8 rows: no test, one address instruction per piece.
+//
+// A neighbour id outside the workgroup's graph - only possible when the caller's layout is wrong (Batch.assume_segments on a
+// batch that is not block-diagonal; the build flags such edges in its status word) - must not read another row of the slice or
+// LDS that was never written: `off - win.lo < win.span` (unsigned, ids below the graph wrap around) sends it to the row
+// of zeros with weight 0, like a slot past the end of the row.
+struct LdsWindow {
+    unsigned lo, span;               // byte address of this lane's piece of row 0, bytes of the graph's rows (nn * 128)
+};
+
 template <bool W, int NS, int MFROM, int J0 = 0>
-__device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem, unsigned lbase, unsigned zsub) {
+__device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem, unsigned lbase, unsigned zsub,
+                                            const LdsWindow win) {
     const unsigned id[8] = {c.i0.x, c.i0.y, c.i0.z, c.i0.w, c.i1.x, c.i1.y, c.i1.z, c.i1.w};
     const unsigned wb[8] = {c.w0.x, c.w0.y, c.w0.z, c.w0.w, c.w1.x, c.w1.y, c.w1.z, c.w1.w};
     float4 v[NS];
@@ -139,11 +149,10 @@ __device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem
     for (int j = 0; j < NS; ++j) {
         unsigned off = id[J0 + j] * 128u + lbase;
         float wt = W ? __uint_as_float(wb[J0 + j]) : 1.0f;
-        if (J0 + j >= MFROM) {
-            const bool valid = J0 + j < rem;
-            off = valid ? off : zsub;
-            wt = valid ? wt : 0.0f;
-        }
+        bool valid = off - win.lo < win.span;
+        if (J0 + j >= MFROM) valid = valid && J0 + j < rem;
+        off = valid ? off : zsub;
+        wt = valid ? wt : 0.0f;
         v[j] = lds_read4(off);
         ww[j] = wt;
     }
@@ -166,24 +175,24 @@ __device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem
 // rows' degrees (triangle meshes: 5, 6 or 7 almost everywhere), and the rare longer rows chunk by chunk
 template <bool W>
 __device__ __forceinline__ void step_rows(float4 &a, const Chunk &c, int pbeg, int rem, unsigned lbase, unsigned zsub,
-                                          __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rw) {
+                                          const LdsWindow win, __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rw) {
     if (__all(rem >= 5) && !__any(rem > 7)) {
         if (__any(rem > 6))
-            chunk_slots<W, 7, 5>(a, c, rem, lbase, zsub);
+            chunk_slots<W, 7, 5>(a, c, rem, lbase, zsub, win);
         else
-            chunk_slots<W, 6, 5>(a, c, rem, lbase, zsub);
+            chunk_slots<W, 6, 5>(a, c, rem, lbase, zsub, win);
         return;
     }
     // the general path (padding rows, short or long rows) runs rarely: four pieces in flight keep its registers
     // below what the common paths need
-    chunk_slots<W, 4, 0, 0>(a, c, rem, lbase, zsub);
-    if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, c, rem, lbase, zsub);
+    chunk_slots<W, 4, 0, 0>(a, c, rem, lbase, zsub, win);
+    if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, c, rem, lbase, zsub, win);
     while (__any(rem > 8)) {                                     // rows with more than 8 neighbours (mesh poles, hubs)
         pbeg += 8, rem -= 8;
         Chunk n;
         load_chunk<W>(n, ro, rw, pbeg);
-        chunk_slots<W, 4, 0, 0>(a, n, rem, lbase, zsub);
-        if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, n, rem, lbase, zsub);
+        chunk_slots<W, 4, 0, 0>(a, n, rem, lbase, zsub, win);
+        if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, n, rem, lbase, zsub, win);
     }
 }
 
@@ -247,6 +256,7 @@ k_hop_chain(ChainParams p) {
     const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned lbase = sbase + 16u * sub - ((DC_CHAIN_ABL & 128) ? 0u : (unsigned)n0 * 128u);   // LDS address of a neighbour's piece: id * 128 + lbase
     const unsigned zsub = sbase + zoff + 16u * sub;
+    const LdsWindow win{sbase + 16u * sub, (unsigned)nn * 128u};
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.slab + (int64_t)n0 * p.ld, 0, (int)((unsigned)nn * (unsigned)p.ld * 4u), 0x00020000);
     const unsigned ldb = (unsigned)p.ld * 4u;
@@ -265,7 +275,7 @@ k_hop_chain(ChainParams p) {
                 load_chunk<W>(ck[(s + 1) & 1], ro, rw, bd[(s + 1) & 1].x);
             }
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            step_rows<W>(a, ck[s & 1], pbeg, rem, lbase, zsub, ro, rw);
+            step_rows<W>(a, ck[s & 1], pbeg, rem, lbase, zsub, win, ro, rw);
             acc[s] = a;
             pm[s] = fmaxf(pm[s], chain_absmax(a));
             store_piece(a, rs, (unsigned)(rwave + 8 * s + grp) * ldb + dcol);               // streams out meanwhile
@@ -360,7 +370,7 @@ k_hop_chain_gcn(ChainParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {                        // a neighbour outside the graph (flagged by the build)
                 const unsigned loc = g[j] - (unsigned)n0;       // must not leave the LDS tables: it reads the zeros
-                l[j] = (j < d && loc < (unsigned)R) ? loc : (unsigned)R;
+                l[j] = (j < d && loc < (unsigned)nn) ? loc : (unsigned)R;
             }
             *reinterpret_cast<uint4 *>(smem + kIds + 16 * r) =
                 make_uint4(l[0] | l[1] << 16, l[2] | l[3] << 16, l[4] | l[5] << 16, l[6] | l[7] << 16);
@@ -380,6 +390,7 @@ k_hop_chain_gcn(ChainParams p) {
     const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
     const unsigned lbase = sbase + 16u * sub, dbase = sbase + kDis;
     const unsigned gbase = lbase - (unsigned)n0 * 128u, zsub = lbase + R * 128u;    // global-id addressing of the tail path
+    const LdsWindow win{lbase, (unsigned)nn * 128u};
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.slab + (int64_t)n0 * p.ld, 0, (int)((unsigned)nn * (unsigned)p.ld * 4u), 0x00020000);
     const unsigned ldb = (unsigned)p.ld * 4u;
@@ -408,8 +419,8 @@ k_hop_chain_gcn(ChainParams p) {
                     pbeg += 8, rem -= 8;
                     Chunk n;
                     load_chunk<true>(n, ro, rw, pbeg);
-                    chunk_slots<true, 4, 0, 0>(a, n, rem, gbase, zsub);
-                    if (__any(rem > 4)) chunk_slots<true, 4, 0, 4>(a, n, rem, gbase, zsub);
+                    chunk_slots<true, 4, 0, 0>(a, n, rem, gbase, zsub, win);
+                    if (__any(rem > 4)) chunk_slots<true, 4, 0, 4>(a, n, rem, gbase, zsub, win);
                 }
             }
             acc[s] = a;
@@ -511,6 +522,7 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
     DC_REQUIRE(src_block >= 0 && src_block + K * dir >= 0 && (int64_t)(src_block + 1) * F <= ld &&
                    (int64_t)(src_block + K * dir + 1) * F <= ld,
                "dc_hop_chain_f32: column blocks outside the slab");
+    DC_REQUIRE(ld < ((int64_t)1 << 20), "dc_hop_chain_f32: leading dimension %lld exceeds the 32-bit row offsets", (long long)ld);
     DC_REQUIRE(cap >= 0 && cap < (int64_t)1 << 29 && N < (int64_t)1 << 24,
                "dc_hop_chain_f32: adjacency of %lld edges / %lld nodes exceeds the 32-bit LDS / buffer offsets",
                (long long)cap, (long long)N);

@@ -88,7 +88,9 @@ k_codes(const float *__restrict__ pos, int64_t ld, int64_t n, const unsigned *__
 __global__ void __launch_bounds__(256)
 k_invert_order(const int32_t *__restrict__ perm, int32_t *inv, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) inv[perm[i]] = (int32_t)i;
+    if (i >= n) return;
+    const int32_t q = perm[i];
+    if ((uint64_t)(int64_t)q < (uint64_t)n) inv[q] = (int32_t)i;        // (an id outside [0, n) writes nothing)
 }
 
 __global__ void __launch_bounds__(256)
@@ -99,7 +101,8 @@ k_relabel(const int64_t *__restrict__ ei, int64_t count, const int32_t *__restri
     out[i] = ((uint64_t)v < (uint64_t)n) ? (int64_t)inv[v] : v;      // out-of-range ids stay what they are (flagged later)
 }
 
-// out row i = x row idx[i]; 16 bytes per lane, a row's lanes side by side
+// out row i = x row idx[i]; 16 bytes per lane, a row's lanes side by side.  An index outside [0, n) reads nothing:
+// its row comes out as zeros (index_select would raise; NodeOrder checks a caller's permutation once, on the host)
 __global__ void __launch_bounds__(256)
 k_gather_rows(const char *__restrict__ x, int64_t ldx, const int32_t *__restrict__ idx, char *out, int64_t ldo,
               int64_t n, int vec_per_row) {
@@ -107,8 +110,9 @@ k_gather_rows(const char *__restrict__ x, int64_t ldx, const int32_t *__restrict
     const int64_t row = t / vec_per_row;
     if (row >= n) return;
     const int v = (int)(t - row * vec_per_row);
+    const int64_t src = idx[row];
     *reinterpret_cast<uint4 *>(out + row * ldo + 16 * v) =
-        *reinterpret_cast<const uint4 *>(x + (int64_t)idx[row] * ldx + 16 * v);
+        (uint64_t)src < (uint64_t)n ? *reinterpret_cast<const uint4 *>(x + src * ldx + 16 * v) : make_uint4(0u, 0u, 0u, 0u);
 }
 
 static inline int64_t al256(int64_t b) { return (b + 255) & ~int64_t(255); }

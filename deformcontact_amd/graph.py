@@ -458,8 +458,14 @@ class NodeOrder:
     def __init__(self, perm: torch.Tensor, inv: Optional[torch.Tensor] = None):
         self.perm = perm.to(torch.int32).contiguous()
         if inv is None:
+            # a caller's own permutation (``morton`` passes the inverse its kernel built): checked ONCE here - the
+            # kernels index with it unchecked (index_select / indexed assignment used to raise on a bad one)
+            n = self.perm.numel()
+            p64 = self.perm.long()
+            if n and (int(p64.min()) < 0 or int(p64.max()) >= n or int(torch.bincount(p64, minlength=n).max()) != 1):
+                raise IndexError(f"NodeOrder: perm is not a permutation of 0..{n - 1}")
             inv = torch.empty_like(self.perm)
-            inv[self.perm.long()] = torch.arange(self.perm.numel(), device=self.perm.device, dtype=torch.int32)
+            inv[p64] = torch.arange(n, device=self.perm.device, dtype=torch.int32)
         self.inv = inv.to(torch.int32).contiguous()
 
     @classmethod
@@ -485,7 +491,8 @@ class NodeOrder:
                                                out.data_ptr(), current_stream_ptr(ei.device)), "dc_relabel_edges")
         return out
 
-    def _gather(self, x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    @staticmethod
+    def _gather_raw(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         _require_cuda(x, "x")
         if x.dim() != 2 or x.size(0) != idx.numel():
             raise ValueError("NodeOrder: x must be [N, F] with N = number of nodes")
@@ -499,11 +506,30 @@ class NodeOrder:
                                              x.size(0), row_bytes, current_stream_ptr(x.device)), "dc_gather_rows")
         return out
 
+    def _gather(self, x: torch.Tensor, idx: torch.Tensor, idx_back: torch.Tensor) -> torch.Tensor:
+        """``x[idx]``; differentiable: ``idx`` and ``idx_back`` are inverse permutations, so the gradient of a row
+        gather is the row gather of the gradient by the opposite permutation (``index_select``'s backward,
+        without its ``index_add_`` atomics)."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _PermuteRows.apply(x, idx, idx_back)
+        return self._gather_raw(x, idx)
+
     def apply(self, x: torch.Tensor) -> torch.Tensor:
-        return self._gather(x, self.perm)
+        return self._gather(x, self.perm, self.inv)
 
     def undo(self, y: torch.Tensor) -> torch.Tensor:
-        return self._gather(y, self.inv)
+        return self._gather(y, self.inv, self.perm)
+
+
+class _PermuteRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, idx_back):
+        ctx.idx_back = idx_back
+        return NodeOrder._gather_raw(x, idx)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return NodeOrder._gather_raw(gy.contiguous(), ctx.idx_back), None, None
 
 
 def register(edge_index: torch.Tensor, g: GraphIndex) -> None:

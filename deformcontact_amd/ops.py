@@ -255,6 +255,10 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
 #: diagnostic tap (tools/exp/dp_flake2.py): ``DEBUG_TAP(name, tensor)`` is called with intermediate tensors of
 #: ``_TagConvFn.backward`` when set; None in production
 DEBUG_TAP = None
+#: diagnostic hook (tools/exp/chain_hunt.py): called as ``DEBUG_CHAIN(g, adj, slab, f, k, transposed)`` right after a
+#: ``dc_hop_chain_f32`` launch of ``chained_hops`` (``DEBUG_CHAIN_PRE``: right before it); None in production
+DEBUG_CHAIN = None
+DEBUG_CHAIN_PRE = None
 
 
 def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bool,
@@ -275,8 +279,12 @@ def chained_hops(g: GraphIndex, slab: torch.Tensor, f: int, k: int, backward: bo
     elif hop_chain_eligible(g, adj, slab, f, k):
         # mode: 1 = fresh maxima over blocks 0..K (the entry clears the buffer first), 2 = joined with block 0's, which
         # the buffer already holds, 3 = over blocks 0..K joined with a buffer the caller has cleared (``rowmax_zeroed``)
+        if DEBUG_CHAIN_PRE is not None:
+            DEBUG_CHAIN_PRE(g, adj, slab, f, k, transposed)
         hop_chain(g, adj, slab, f, k, weighted=g.normalize, rowmax=rowmax,
                   rowmax_mode=2 if rowmax_has_block0 else (3 if rowmax_zeroed else 1))
+        if DEBUG_CHAIN is not None:
+            DEBUG_CHAIN(g, adj, slab, f, k, transposed)
     else:
         for j in range(k):
             hop(adj, blocks[j], out=blocks[j + 1], weighted=g.normalize, rowmax=rowmax,

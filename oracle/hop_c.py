@@ -13,10 +13,22 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
+    """Rebuilt when the CONTENT of hop_ref.c changed (file times do not survive a push to another machine)."""
+    import hashlib
     src = os.path.join(_DIR, "hop_ref.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    with open(src, "rb") as f:
+        want = hashlib.sha256(f.read()).hexdigest()
+    stamp = _SO + ".srchash"
+    have = None
+    if os.path.exists(stamp):
+        with open(stamp) as f:
+            have = f.read().strip()
+    if force or not os.path.exists(_SO) or have != want:
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC",
-                               src, "-o", _SO, "-lm"])
+                               src, "-o", _SO + ".tmp", "-lm"])
+        os.replace(_SO + ".tmp", _SO)
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     return _SO
 
 

@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "launch: asserts on a multi-process GPU scenario run at session start "
+                                       "(tests/launch_scenarios.py)")
     # make sure the C-ABI library exists (hipcc cross-compiles without a GPU)
     from deformcontact_amd import build as dc_build
     dc_build.build()
@@ -34,6 +36,39 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_collection_finish(session):
+    """The multi-process GPU scenarios run HERE - after collection / deselection, before the first test, while this
+    process has not initialised HIP (child processes are never started from one that has) - and only when a selected
+    test asserts on them (tests/test_z_launch.py, which sorts last)."""
+    from tests import launch_scenarios as ls
+    wanted = [it for it in session.items if "launch" in it.keywords]
+    if not wanted or session.config.option.collectonly:
+        return
+    import torch
+    if torch.cuda.device_count() == 0:
+        ls.SKIPPED = "no GPU visible"
+    elif os.environ.get("DC_SKIP_LAUNCH") == "1":
+        ls.SKIPPED = "DC_SKIP_LAUNCH=1"
+    elif torch.cuda.is_initialized():
+        ls.SKIPPED = "HIP already initialised in the pytest process before the launch scenarios could start"
+    else:
+        names = []
+        for it in wanted:                                   # only the scenarios the selected tests read
+            for name in ls.SCENARIOS:
+                tag = {"bench_two_rank_gloo": "direct_two_rank", "rccl_single": "rccl",
+                       "dp_graphed_serial": "graphed_train_step", "dp_graphed_two_streams": "graphed_train_step"}[name]
+                if tag in it.name and (not name.startswith("dp_graphed_") or name[len("dp_graphed_"):] in it.name):
+                    if name not in names:
+                        names.append(name)
+        tr = session.config.pluginmanager.get_plugin("terminalreporter")
+        if tr is not None:
+            tr.write_line(f"launch scenarios before the first test: {names}")
+        ls.run_all(names)
+        if tr is not None:
+            for k, v in ls.RESULTS.items():
+                tr.write_line(f"  {k}: rc={v['rc']} timed_out={v['timed_out']} {v['wall_s']:.0f}s")
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -62,6 +97,9 @@ def pytest_sessionfinish(session, exitstatus):
                "worst_ratio_hip_to_oracle_distance_from_float64_where_widened": max(
                    (r["hip_vs_float64"] / max(r["fp32_oracle_vs_float64"], 1e-30) for r in fired
                     if r["hip_vs_float64"] is not None and r["hip_vs_float64"] > r["tol"]), default=None),
+               # round 5: a widened comparison passes only with HIP within tol of float64; a wider bound needs `special`
+               "widened_non_special_beyond_tol_of_float64": sum(
+                   1 for r in fired if r["hip_vs_float64"] is not None and r["hip_vs_float64"] > r["tol"]),
                "tests": len({r["test"] for r in log}), "special_comparisons": len(special)}
     with open(path, "w") as f:
         json.dump({"summary": summary, "widened": fired, "special": special, "all": log}, f, indent=1)

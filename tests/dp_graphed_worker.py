@@ -1,4 +1,4 @@
-"""Worker of tests/test_a_dp_graphed.py: one data-parallel rank (env RANK / WORLD_SIZE / MASTER_*), every rank on
+"""Worker of tests/launch_scenarios.py (dp_graphed_*; asserted on by tests/test_z_launch.py): one data-parallel rank (env RANK / WORLD_SIZE / MASTER_*), every rank on
 cuda:0, collectives over gloo.  The reference's whole train step through `train.GraphedTrainStep` with
 world_size 2: forward + losses + backward replayed from one hipGraph, gradient all-reduce + Adam OUTSIDE the
 graph.  Rank 0 then replays the same steps in ONE process - both ranks' batches one after the other, mean of the
@@ -28,7 +28,12 @@ def main():
     out_path = sys.argv[1]
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")            # one node: pairwise connections over loopback
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
+    from deformcontact_amd.launch import install_watchdog, phase
+    install_watchdog()
+    phase("start")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(
+        seconds=float(os.environ.get("DC_GLOO_TIMEOUT_S", "60"))))
+    phase("process group up")
     from deformcontact_amd import dp
     from deformcontact_amd.graphnet import EVERYDAY_NETWORK, ContactEncoder, load_model
     from deformcontact_amd.train import GraphedTrainStep, losses
@@ -47,6 +52,7 @@ def main():
     loss_curve = []
     for s in range(STEPS):
         loss_curve.append(float(stepper(*batch(s, rank, world, dev))["loss"]))
+        phase(f"step {s} done")
     torch.cuda.synchronize()
     assert stepper.replays == STEPS - 1
     mine = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
@@ -81,6 +87,7 @@ def main():
         differing = [n for (n, p), q in zip(model.named_parameters(), ref.parameters()) if not torch.equal(p.detach(), q.detach())]
         result.update(max_abs_diff=diff, scale=scale, bit_identical=bool(torch.equal(mine, want)), differing=differing[:12],
                       n_differing=len(differing))
+    phase("compared")
     dist.barrier()
     with open(out_path + f".rank{rank}.json", "w") as f:
         json.dump(result, f)

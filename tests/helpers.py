@@ -53,38 +53,34 @@ def record_parity(name, d, widened=False, e_h=None, e_o=None, tol=1e-5, metric="
                        "fp32_oracle_vs_float64": None if e_o is None else float(e_o)})
 
 
-def three_way(d, e_h_fn, e_o_fn, tol=1e-5, name="", fac=2, metric="rel_err"):
-    """The three-way rule on already computed distances: ``d`` (HIP vs fp32 oracle) < tol, or - evaluated lazily -
-    HIP within ``max(fac * oracle's distance, tol)`` of the float64 truth.  Records the outcome."""
+def three_way(d, e_h_fn, e_o_fn, tol=1e-5, name="", metric="rel_err", special=None, special_bound=None):
+    """The parity rule on already computed distances: ``d`` (HIP vs fp32 oracle) < tol, or - evaluated lazily - HIP
+    within ``tol`` of the float64 truth (round 5: the ``2 x the oracle's own distance`` allowance is gone; every
+    widened comparison of round 4 was within 4.4e-6 of float64).  Only a comparison registered ``special`` (a stated
+    reason why it is not on north_star's scale) may pass a wider ``special_bound(e_o)``.  Records the outcome."""
     if d < tol:
-        record_parity(name, d, tol=tol, metric=metric)
+        record_parity(name, d, tol=tol, metric=metric, special=special)
         return d
     e_h, e_o = e_h_fn(), e_o_fn()
-    record_parity(name, d, True, e_h, e_o, tol=tol, metric=metric)
-    assert e_h <= max(fac * e_o, tol), (
+    record_parity(name, d, True, e_h, e_o, tol=tol, metric=metric, special=special)
+    bound = tol if special is None else max(tol, special_bound(e_o))
+    assert e_h <= bound, (
         f"{name}: HIP vs fp32 oracle {d:.2e} >= {tol:g}, and vs the float64 truth the HIP path is off by "
-        f"{e_h:.2e} while the fp32 oracle is off by {e_o:.2e}: not explained by fp32 rounding of the oracle")
+        f"{e_h:.2e} > {bound:.2e} (the fp32 oracle is off by {e_o:.2e})")
     return d
 
 
-def assert_parity(got, ref32, truth64=None, tol=1e-5, name="", metric=None):
-    """north_star's bar: ``metric(got, fp32 oracle) < tol`` (1e-5).  Where two correct fp32
-    evaluations legitimately differ by more (gradients through several layers: different but
-    equally valid summation orders), the widening must be JUSTIFIED against a float64 evaluation
-    of the same maths: the HIP result has to be within ``tol`` of the float64 truth, or at most
-    twice as far from it as the fp32 oracle itself is.  Returns the HIP-vs-oracle distance."""
+def assert_parity(got, ref32, truth64=None, tol=1e-5, name="", metric=None, special=None, special_bound=None):
+    """north_star's bar: ``metric(got, fp32 oracle) < tol`` (1e-5).  Where two correct fp32 evaluations legitimately
+    differ by more (gradients through several layers: different but equally valid summation orders), the HIP result has
+    to be within ``tol`` of a float64 evaluation of the same maths - nothing wider, unless the comparison is registered
+    ``special`` with its own stated bound (``three_way``).  Returns the HIP-vs-oracle distance."""
     metric = metric or rel_err
     d = metric(got, ref32)
-    if d < tol:
-        record_parity(name, d, tol=tol, metric=metric.__name__)
-        return d
-    assert truth64 is not None, f"{name}: {d:.2e} >= {tol:g} vs the fp32 oracle and no float64 truth given"
-    e_h, e_o = metric(got, truth64), metric(ref32, truth64)
-    record_parity(name, d, True, e_h, e_o, tol=tol, metric=metric.__name__)
-    assert e_h <= max(2 * e_o, tol), (
-        f"{name}: HIP vs fp32 oracle {d:.2e} >= {tol:g}, and vs the float64 truth the HIP path is off by "
-        f"{e_h:.2e} while the fp32 oracle is off by {e_o:.2e}: not explained by fp32 rounding of the oracle")
-    return d
+    if d >= tol:
+        assert truth64 is not None, f"{name}: {d:.2e} >= {tol:g} vs the fp32 oracle and no float64 truth given"
+    return three_way(d, lambda: metric(got, truth64), lambda: metric(ref32, truth64), tol=tol, name=name,
+                     metric=metric.__name__, special=special, special_bound=special_bound)
 
 
 class G:

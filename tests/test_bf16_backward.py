@@ -160,7 +160,7 @@ def test_two_layer_bf16_stack_forward_backward_vs_float64():
             assert rel_err(_np(p.grad), q.grad.numpy()) < 1.5e-2, name        # gm / activations went through bf16
 
 
-def test_tagconv_bf16_forward_backward_on_100k_radius_graph_vs_float64():
+def test_config4_radius100k_bf16_tagconv_forward_backward_vs_float64():
     """configs[4] at full size: TAGConv(256, 256) + ReLU on the 100k-point radius graph, bf16 features, forward AND
     backward, against the float64 closed forms on the same bf16-rounded inputs (mask = the HIP path's own)."""
     import scipy.sparse as sp

@@ -49,7 +49,7 @@ class _MaskedBranch(torch.nn.Module):
 
 @pytest.mark.parametrize("backbone,merged", [("TAGConv", False), ("TAGConv", True), ("GCNConv", False),
                                              ("GATConv", False)])
-def test_b32_default_init_step_with_relu_masks_vs_oracle(everyday_b32, backbone, merged):
+def test_config1_b32_default_init_step_with_relu_masks_vs_oracle(everyday_b32, backbone, merged):
     """The step the bench times: B=32, DEFAULT initialisation (zero biases: half of the 15 M pre-activations are
     negative, a few lie within fp32 rounding of the kink).  Outputs per row against the fp32 oracle / float64.
     Gradients: the fp32 oracle, the float64 oracle and the HIP path may each decide a handful of near-zero
@@ -127,20 +127,21 @@ def test_b32_default_init_step_with_relu_masks_vs_oracle(everyday_b32, backbone,
         # GAT's attention vectors: their gradient is a sum over all nodes of terms that cancel to ~1 % of their
         # size (the softmax weights of a segment sum to one), so it sits 1e-5 from float64 in the fp32 oracle
         # already; the HIP path's dense blocks carry 22 rather than 24 bits - 3 x the oracle's distance there
-        fac = 3 if ".att_" in name else 2
+        special = ("a gradient that is mathematically zero: rounding noise of the softmax backward; bar 3 x the fp32 "
+                   "oracle's distance from float64" if name.endswith("att_dst") else
+                   "GAT attention vector: a sum of terms that cancel to ~1 % of their size; bar 3 x the fp32 "
+                   "oracle's distance from float64" if ".att_" in name else None)
         record_parity(name + " (vs float64 over the HIP masks)", rel_err(_np(p.grad), _np(rp[name].grad)), True, e_h, e_o,
-                      special=("a gradient that is mathematically zero: rounding noise of the softmax backward"
-                               if name.endswith("att_dst") else
-                               "GAT attention vector: a sum of terms that cancel to ~1 % of their size; bar 3 x the fp32 "
-                               "oracle's distance from float64" if ".att_" in name else None))
-        assert e_h <= max(fac * e_o, TOL), (f"{name}: {e_h:.2e} from the float64 backward over the HIP path's own "
-                                            f"masks (fp32 oracle vs float64: {e_o:.2e})")
+                      special=special)
+        bound = TOL if special is None else max(3 * e_o, TOL)
+        assert e_h <= bound, (f"{name}: {e_h:.2e} from the float64 backward over the HIP path's own "
+                              f"masks (bound {bound:.2e}; fp32 oracle vs float64: {e_o:.2e})")
         # and the north-star bar against the fp32 oracle wherever the two fp32 evaluations took the same masks
         if flips == 0:
             assert_parity(_np(p.grad), _np(rp[name].grad), _np(truth[name]), TOL, name)
 
 
-def test_loss_curve_of_the_shipped_configuration_vs_oracle():
+def test_config2_loss_curve_of_the_shipped_configuration_vs_oracle():
     """BASELINE.json configs[2] at the SHIPPED configuration (configs/everyday.json: hidden 256, 2 + 2 TAGConv
     layers, 2 attention heads, batch 4; full-size meshes): 8 training steps, a new batch every step, same init,
     Adam(4e-4) - HIP path (FlatAdam over the direct-gradient bucket, steps replayed from one hipGraph) vs the CPU
@@ -177,9 +178,12 @@ def test_loss_curve_of_the_shipped_configuration_vs_oracle():
         record_parity(f"loss of step {i}", d, d >= TOL, abs(g - t) / abs(t), abs(r - t) / abs(t),
                       special=None if i == 0 else f"loss after {i} Adam steps (every parameter has moved ~lr per step)")
         if d >= TOL:
+            # step 0 (identical parameters): the plain bar.  Later steps are `special`: every parameter has moved ~lr
+            # per step along rounding-dependent directions; bound = twice the fp32 oracle's own drift from float64
             e_h, e_o = abs(g - t) / abs(t), abs(r - t) / abs(t)
-            assert e_h <= max(2 * e_o, TOL), (f"step {i}: HIP {g:.9g} vs fp32 oracle {r:.9g} ({d:.2e}); vs float64 "
-                                              f"{t:.9g}: HIP {e_h:.2e}, oracle {e_o:.2e}", curves)
+            assert e_h <= (TOL if i == 0 else max(2 * e_o, TOL)), (
+                f"step {i}: HIP {g:.9g} vs fp32 oracle {r:.9g} ({d:.2e}); vs float64 {t:.9g}: HIP {e_h:.2e}, oracle {e_o:.2e}",
+                curves)
     assert curves["gpu"][-1] < curves["gpu"][0]
     # the parameters after 8 steps: against the float64 run, no worse than twice the fp32 oracle's drift
     for (name, pg), pr, pt in zip(gpu.named_parameters(), ref.parameters(), ref64.parameters()):
@@ -363,10 +367,8 @@ def test_full_model_b16_through_the_flash_attention_vs_oracle(variant, monkeypat
         d = rel_err(got, ctx["grad32"][name])
         record_parity(f"{variant}: grad {name} (float64 over each path's own masks; {same_as_f32} mask elements differ "
                       f"between HIP and the fp32 oracle)", d, d >= TOL, e_h, e_o)
-        assert e_h <= max(2 * e_o, TOL), (f"{name}: {e_h:.2e} from the float64 backward over the HIP path's own masks "
-                                          f"(fp32 oracle vs float64 over its masks: {e_o:.2e})")
-        if same_as_f32 == 0:
-            assert d < TOL or e_h <= max(2 * e_o, TOL), name
+        assert e_h <= TOL, (f"{name}: {e_h:.2e} from the float64 backward over the HIP path's own masks "
+                            f"(fp32 oracle vs float64 over its masks: {e_o:.2e})")
 
 
 @pytest.mark.parametrize("merged", [False, True])

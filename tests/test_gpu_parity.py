@@ -602,7 +602,7 @@ def test_tagconv_alternative_dense_paths_vs_oracle(path):
                                              ("GCNConv", "graphnet_gcn_h32.npz"),
                                              ("GATConv", "graphnet_gat_h32.npz")])
 @pytest.mark.parametrize("fused_attn", [False, True])
-def test_full_model_golden(backbone, fname, fused_attn):
+def test_config0_full_model_golden(backbone, fname, fused_attn):
     """Fixtures produced by the reference's GraphNet + losses (oracle/make_golden.py)."""
     from deformcontact_amd.graphnet import EVERYDAY_NETWORK, gradient_consistency_loss, load_model
     z = load_golden(fname)
@@ -661,7 +661,7 @@ def test_full_model_golden(backbone, fname, fused_attn):
         # gradients that pass through several layers / the softmax backward dS = P * (dP - delta)
         # (which cancels the common part of dP in fp32 in BOTH computations) can differ between two
         # correct fp32 evaluations by more than 1e-5: accepted only where the float64 evaluation
-        # shows the HIP result is no further from the truth than twice the fp32 fixture itself
+        # shows the HIP result is within 1e-5 of the truth
         d = assert_parity(_np(p.grad), ref, truth[name], TOL, name)
         assert d < 1e-4, (name, d)
 
@@ -713,7 +713,7 @@ def everyday_b32():
     return rest.to(DEV), rig.to(DEV)
 
 
-def test_full_size_csr_and_hop_properties(everyday_b32):
+def test_config1_b32_csr_and_hop_properties(everyday_b32):
     rest, rig = everyday_b32
     for b, n_exp, e_exp in ((rest, 32768, 196224), (rig, 24384, 145920)):
         ei = _np(b.edge_index)
@@ -749,7 +749,7 @@ def test_full_size_csr_and_hop_properties(everyday_b32):
         assert np.array_equal(_np(ops.hop(g.fwd, a)), hop_c.hop(ei, w_edge, _np(a)))
 
 
-def test_full_size_encoder_vs_oracle(everyday_b32):
+def test_config1_b32_encoder_vs_oracle(everyday_b32):
     """B=32 encoder forward AND backward (every parameter gradient) against the oracle's ATen-op
     sequence on the host; gradients that differ by more than 1e-5 between the two fp32
     evaluations are judged against the oracle run in float64."""
@@ -1135,7 +1135,7 @@ def _radius100k():
     return pos.to(DEV), ei.to(DEV)
 
 
-def test_tagconv_bf16_storage_on_100k_radius_graph_vs_float64():
+def test_config4_radius100k_bf16_tagconv_forward_vs_float64():
     """configs[4]: one TAGConv(256, 256) layer on the 100k-point radius graph with the features
     stored as bf16 (dc_spmm_bf16 hops, bf16 MFMA dense block), against the float64 closed form
     sum_k A^k X W_k^T + b on the same bf16-rounded inputs.  Stated bf16 tolerance: 2e-2 of max |ref|

@@ -74,7 +74,7 @@ def run_both(g, adj, n, f, k, mode, weighted=True, src=0, direction=1, with_rowm
 
 @pytest.mark.parametrize("gcn", [True, False])
 @pytest.mark.parametrize("bwd", [False, True])
-def test_everyday_batch_chains_equal_three_hops_bitwise(bwd, gcn):
+def test_config1_b32_chains_equal_three_hops_bitwise(bwd, gcn):
     rest, _, rig = synth.make_batch(8)
     for b in (rest, rig):
         g = GraphIndex(b.edge_index.to(DEV), b.x.shape[0], segments=b.segments())

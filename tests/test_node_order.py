@@ -80,3 +80,45 @@ def test_ordering_a_new_cloud_is_capturable():
         want = NodeOrder.morton(pos.clone())
         assert torch.equal(o.perm, want.perm) and torch.equal(xa, x.index_select(0, want.perm.long()))
         assert torch.equal(er, want.inv.long()[ei]) and torch.equal(back, x)
+
+
+def test_gathers_are_differentiable_through_undo_conv_apply():
+    """apply / undo went from index_select (differentiable) to a raw-pointer gather with no grad_fn, which
+    silently cut the graph of `undo(conv(apply(x), relabel(edge_index)))`.  The gathers are autograd functions now; the
+    gradients of the reordered computation equal those of the unordered one bit for bit (same per-row sums)."""
+    from deformcontact_amd import nn as dc_nn
+    n, e = 3000, 18_000
+    rng = np.random.default_rng(3)
+    pos = torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32)).to(DEV)
+    ei = torch.from_numpy(rng.integers(0, n, (2, e))).to(DEV)
+    o = NodeOrder.morton(pos)
+    torch.manual_seed(0)
+    conv = dc_nn.TAGConv(64, 64).to(DEV)
+    x0 = torch.randn(n, 64, device=DEV)
+    gy = torch.randn(n, 64, device=DEV)
+    x1 = x0.clone().requires_grad_(True)
+    y1 = conv(x1, ei)
+    y1.backward(gy)
+    gw1 = [p.grad.clone() for p in conv.parameters()]
+    conv.zero_grad()
+    x2 = x0.clone().requires_grad_(True)
+    y2 = o.undo(conv(o.apply(x2), o.relabel(ei)))
+    assert y2.grad_fn is not None
+    y2.backward(gy)
+    assert torch.equal(y1, y2) and x2.grad is not None
+    assert torch.equal(x1.grad, x2.grad)
+    for a, p in zip(gw1, conv.parameters()):
+        # dW sums over nodes in memory order, which the relabelling changes: equal up to fp32 summation order
+        assert p.grad is not None and float((a - p.grad).abs().max()) <= 1e-5 * float(a.abs().max())
+    # no graph under no_grad / for inputs that need none
+    with torch.no_grad():
+        assert o.apply(x2).grad_fn is None
+    assert o.apply(x0).grad_fn is None
+
+
+def test_a_bad_user_permutation_is_refused():
+    good = torch.tensor([2, 0, 1], device=DEV)
+    assert torch.equal(NodeOrder(good).inv.cpu(), torch.tensor([1, 2, 0], dtype=torch.int32))
+    for bad in ([0, 1, 3], [0, 0, 1], [-1, 0, 1]):
+        with pytest.raises(IndexError):
+            NodeOrder(torch.tensor(bad, device=DEV))

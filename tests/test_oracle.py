@@ -22,7 +22,7 @@ def _net(backbone, hidden):
 @pytest.mark.parametrize("backbone,fname", [("TAGConv", "graphnet_tag_h32.npz"),
                                              ("GCNConv", "graphnet_gcn_h32.npz"),
                                              ("GATConv", "graphnet_gat_h32.npz")])
-def test_oracle_reproduces_reference_run(backbone, fname):
+def test_config0_oracle_reproduces_reference_run(backbone, fname):
     """Fixtures came from /root/reference/models/model.py run end to end; the oracle convs
     inside the restated wiring must give the same activations, loss and gradients."""
     z = load_golden(fname)

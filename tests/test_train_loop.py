@@ -50,7 +50,7 @@ def test_train_step_cpu_oracle_loss_decreases(tmp_path):
 
 
 @pytest.mark.gpu
-def test_loss_curve_matches_oracle_on_gpu():
+def test_config2_loss_curve_matches_oracle_on_gpu():
     """Same init, same batches, Adam(4e-4): HIP path vs CPU oracle, 8 steps."""
     torch.set_num_threads(1)
     torch.manual_seed(0)
@@ -71,7 +71,7 @@ def test_loss_curve_matches_oracle_on_gpu():
 
 
 @pytest.mark.gpu
-def test_graphed_train_loop_follows_oracle_curve_with_changing_batches(tmp_path):
+def test_config2_graphed_train_loop_follows_oracle_curve_with_changing_batches(tmp_path):
     """BASELINE.json configs[2]: the real loop - a NEW batch every step (new edge_index, new
     features), FlatAdam over the direct-gradient bucket, steps replayed from one hipGraph that
     contains the adjacency build - against the CPU oracle with torch.optim.Adam on the same
