@@ -877,11 +877,22 @@ k_bk_weights(Build b) {
 
 static inline int64_t align16(int64_t b) { return (b + 15) & ~int64_t(15); }
 
+// Can a build over E edges and N nodes take the bucketed path (bucket_plan below)?  Its slots are E, or E + N with self
+// loops - the workspace entries do not know which, so E + N decides.  Mesh batches (the reference's configurations) stay
+// far below the threshold and do not pay for the bucket arrays (~10 B x (E + N) + 64 KiB per side).
+static bool may_bucket(int64_t E, int64_t N) {
+    const char *mode = getenv("DC_CSR_BUCKETS"), *min_s = getenv("DC_CSR_BUCKETS_MIN");
+    if (mode && atoi(mode) == 0) return false;
+    if (mode && atoi(mode) == 1) return true;
+    return E + N >= (min_s ? atoll(min_s) : (int64_t)1 << 19);
+}
+
 static inline int64_t side_bytes(int64_t E, int64_t N) {
     const int64_t ntiles = (N + kScanTile - 1) / kScanTile;
-    return 2 * align16(4 * (N + 4)) + align16(4 * (E + N + 1)) + align16(4 * (ntiles + 2)) +
-           align16(4 * (N + 2)) +
-           2 * align16(4 * (kBkMaxBuckets + 1)) + 2 * align16(4 * (E + N)) + align16(2 * (E + N));   // bucketed build
+    const int64_t windowed = 2 * align16(4 * (N + 4)) + align16(4 * (E + N + 1)) + align16(4 * (ntiles + 2)) +
+                             align16(4 * (N + 2));
+    if (!may_bucket(E, N)) return windowed;
+    return windowed + 2 * align16(4 * (kBkMaxBuckets + 1)) + 2 * align16(4 * (E + N)) + align16(2 * (E + N));   // bucketed build
 }
 
 static char *carve_side(Side &sd, char *ws, int64_t E, int64_t N) {
@@ -896,6 +907,11 @@ static char *carve_side(Side &sd, char *ws, int64_t E, int64_t N) {
     ws += align16(4 * (ntiles + 2));
     sd.big = (int32_t *)ws;
     ws += align16(4 * (N + 2));
+    if (!may_bucket(E, N)) {                    // (run_build cannot choose the bucketed path then: slots <= E + N)
+        sd.bk_start = sd.bk_cur = sd.bk_eid = sd.bk_oth = nullptr;
+        sd.bk_kl = nullptr;
+        return ws;
+    }
     sd.bk_start = (int32_t *)ws;
     ws += align16(4 * (kBkMaxBuckets + 1));
     sd.bk_cur = (int32_t *)ws;
@@ -941,6 +957,9 @@ static int run_build(Build &b, int nsides, hipStream_t stream, const char *what)
     const int64_t slots = E + (b.self_loops ? N : 0);
     Buckets bk{};
     if (slots > 0 && bucket_plan(slots, N, bk)) {
+        for (int s = 0; s < nsides; ++s)
+            DC_REQUIRE(b.s[s].bk_start, "%s: the workspace was sized without the bucket arrays (DC_CSR_BUCKETS* changed "
+                                        "between sizing and building?)", what);
         for (int s = 0; s < nsides; ++s) hipMemsetAsync(b.s[s].bk_start, 0, 4 * (size_t)(bk.nb + 1), stream);
         hipMemsetAsync(b.status, 0, sizeof(int32_t), stream);
         const unsigned pb = (unsigned)((slots + 1024 * kBkEpt - 1) / (1024 * kBkEpt));

@@ -98,6 +98,20 @@ __device__ __forceinline__ void publish_rowmax(const float (&pm)[8], int sub, in
     if (sub < steps && row < nn) atomicMax(reinterpret_cast<int *>(rowmax + row), __float_as_int(rm));
 }
 
+// the same for LPR (2 or 4) lanes per row piece: one xor-butterfly over the row's lanes per step, lane sub == 0 publishes
+template <int STEPS, int LPR>
+__device__ __forceinline__ void publish_rowmax_narrow(const float (&pm)[8], int sub, int row0, int nn, float *rowmax) {
+    constexpr int RPW = 64 / LPR;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        float m = pm[s];
+#pragma unroll
+        for (int d = 1; d < LPR; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+        const int row = row0 + RPW * s;
+        if (sub == 0 && row < nn) atomicMax(reinterpret_cast<int *>(rowmax + row), __float_as_int(m));
+    }
+}
+
 struct Chunk {                        // ids and weights of 8 consecutive edges
     u32x4 i0, i1, w0, w1;
 };
@@ -137,7 +151,7 @@ struct LdsWindow {
     unsigned lo, span;               // byte address of this lane's piece of row 0, bytes of the graph's rows (nn * 128)
 };
 
-template <bool W, int NS, int MFROM, int J0 = 0>
+template <bool W, int NS, int MFROM, int J0 = 0, int RB = 128>
 __device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem, unsigned lbase, unsigned zsub,
                                             const LdsWindow win) {
     const unsigned id[8] = {c.i0.x, c.i0.y, c.i0.z, c.i0.w, c.i1.x, c.i1.y, c.i1.z, c.i1.w};
@@ -147,7 +161,7 @@ __device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem
     if (DC_CHAIN_ABL & 2) return;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        unsigned off = id[J0 + j] * 128u + lbase;
+        unsigned off = id[J0 + j] * (unsigned)RB + lbase;
         float wt = W ? __uint_as_float(wb[J0 + j]) : 1.0f;
         bool valid = off - win.lo < win.span;
         if (J0 + j >= MFROM) valid = valid && J0 + j < rem;
@@ -173,67 +187,68 @@ __device__ __forceinline__ void chunk_slots(float4 &acc, const Chunk &c, int rem
 
 // one step: the wave's 8 rows against the chunk of their first 8 neighbours, specialised by a wave-wide vote on the
 // rows' degrees (triangle meshes: 5, 6 or 7 almost everywhere), and the rare longer rows chunk by chunk
-template <bool W>
+template <bool W, int RB = 128>
 __device__ __forceinline__ void step_rows(float4 &a, const Chunk &c, int pbeg, int rem, unsigned lbase, unsigned zsub,
                                           const LdsWindow win, __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rw) {
     if (__all(rem >= 5) && !__any(rem > 7)) {
         if (__any(rem > 6))
-            chunk_slots<W, 7, 5>(a, c, rem, lbase, zsub, win);
+            chunk_slots<W, 7, 5, 0, RB>(a, c, rem, lbase, zsub, win);
         else
-            chunk_slots<W, 6, 5>(a, c, rem, lbase, zsub, win);
+            chunk_slots<W, 6, 5, 0, RB>(a, c, rem, lbase, zsub, win);
         return;
     }
     // the general path (padding rows, short or long rows) runs rarely: four pieces in flight keep its registers
     // below what the common paths need
-    chunk_slots<W, 4, 0, 0>(a, c, rem, lbase, zsub, win);
-    if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, c, rem, lbase, zsub, win);
+    chunk_slots<W, 4, 0, 0, RB>(a, c, rem, lbase, zsub, win);
+    if (__any(rem > 4)) chunk_slots<W, 4, 0, 4, RB>(a, c, rem, lbase, zsub, win);
     while (__any(rem > 8)) {                                     // rows with more than 8 neighbours (mesh poles, hubs)
         pbeg += 8, rem -= 8;
         Chunk n;
         load_chunk<W>(n, ro, rw, pbeg);
-        chunk_slots<W, 4, 0, 0>(a, n, rem, lbase, zsub, win);
-        if (__any(rem > 4)) chunk_slots<W, 4, 0, 4>(a, n, rem, lbase, zsub, win);
+        chunk_slots<W, 4, 0, 0, RB>(a, n, rem, lbase, zsub, win);
+        if (__any(rem > 4)) chunk_slots<W, 4, 0, 4, RB>(a, n, rem, lbase, zsub, win);
     }
 }
 
-// STEPS: row groups per wave = ceil(largest graph of the launch / 128), a compile-time constant: the step sequence
-// is then straight-line code (no "s < steps" exits), and only in straight-line code does hipcc count the in-flight
-// id / weight loads and block stores exactly (counted vmcnt(N) instead of vmcnt(0) - which would wait for the stores)
-template <bool W, int STEPS>
+// STEPS: row groups per wave = ceil(largest graph of the launch / rows per workgroup step), a compile-time constant: the
+// step sequence is then straight-line code (no "s < steps" exits), and only in straight-line code does hipcc count the
+// in-flight id / weight loads and block stores exactly (counted vmcnt(N) instead of vmcnt(0) - which would wait for the stores).
+// LPR: lanes per row piece = slice width / 4 columns.  8 (32 columns, 128-byte pieces: whole cache lines) holds graphs of up
+// to 1,024 nodes in the 160 KB of LDS; 4 (16 columns) up to 2,048, 2 (8 columns) up to 4,096 - the reference feeds whole
+// meshes (configs/everyday.json:6 n_points = -1, loaders/everyday_deform.py:60-65), not only the ~1k-vertex ones of the
+// benchmark shape.  A wave-instruction covers 64 / LPR rows; everything else is the same arithmetic in the same order.
+template <bool W, int STEPS, int LPR>
 __global__ void __launch_bounds__(1024)
 k_hop_chain(ChainParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RPW = 64 / LPR, RB = 16 * LPR, COLS = 4 * LPR;   // rows per wave-instruction, bytes / columns per row piece
+    constexpr int R = 16 * RPW * STEPS;                          // rows of the LDS slice
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);      // the slices of a graph run side by side on one XCD
     const int seg = (int)(lb / (unsigned)p.nslices), slice = (int)(lb - (unsigned)seg * (unsigned)p.nslices);
     const int n0 = p.node_ptr[seg], nn = p.node_ptr[seg + 1] - n0;
-    constexpr int steps = STEPS;                                // nn <= 128 * STEPS (host-checked)
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, grp = lane >> 3, sub = lane & 7;
-    const int rwave = wid * 8 * steps;                          // the wave's rows: [rwave, rwave + 8 steps)
-    const int zoff = steps * 128 * 128;                         // a row of zeros behind the slice
-    float *blk = p.slab + (int64_t)n0 * p.ld + slice * kChainCols + 4 * sub;
+    const int lane = threadIdx.x & 63, grp = lane / LPR, sub = lane % LPR;
+    const int rwave = wid * RPW * STEPS;                        // the wave's rows: [rwave, rwave + RPW * STEPS)
+    constexpr int zoff = R * RB;                                // a row of zeros behind the slice
+    float *blk = p.slab + (int64_t)n0 * p.ld + slice * COLS + 4 * sub;
 
-    // ---- source block slice -> LDS (one wave-instruction = 8 rows x 128 B, contiguous in LDS) ----
+    // ---- source block slice -> LDS (one wave-instruction = RPW rows x RB bytes = 1 KiB, contiguous in LDS) ----
     {
         const float *src = blk + (int64_t)p.src0 * p.F;
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s)
-            if (s < steps) {
-                const int row = rwave + 8 * s + grp;
-                if (row < nn && !(DC_CHAIN_ABL & 8))
-                    __builtin_amdgcn_global_load_lds(
-                        (const void __attribute__((address_space(1))) *)(src + (int64_t)row * p.ld),
-                        (void __attribute__((address_space(3))) *)(smem + (rwave + 8 * s) * 128), 16, 0, 0);
-            }
+        for (int s = 0; s < STEPS; ++s) {
+            const int row = rwave + RPW * s + grp;
+            if (row < nn && !(DC_CHAIN_ABL & 8))
+                __builtin_amdgcn_global_load_lds(
+                    (const void __attribute__((address_space(1))) *)(src + (int64_t)row * p.ld),
+                    (void __attribute__((address_space(3))) *)(smem + (rwave + RPW * s) * RB), 16, 0, 0);
+        }
     }
-    if (threadIdx.x < 8) *reinterpret_cast<float4 *>(smem + zoff + 16 * threadIdx.x) = make_float4(0.f, 0.f, 0.f, 0.f);
-    // segment bounds {first edge, degree} of every row: the same for every hop, kept in LDS behind the zero row
-    // (16 registers per lane otherwise; a row's 8 lanes read one address - a broadcast)
-    int2 *bounds = reinterpret_cast<int2 *>(smem + zoff + 128);
-    for (int r = threadIdx.x; r < 128 * steps; r += 1024) {
-        const int b = r < nn ? p.ptr[n0 + r] : 0, e = r < nn ? p.ptr[n0 + r + 1] : 0;
-        bounds[r] = make_int2(b, e - b);
-    }
+    if (threadIdx.x < LPR) *reinterpret_cast<float4 *>(smem + zoff + 16 * threadIdx.x) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the graph's slice of `ptr` (first edge of every row; degree = the next entry minus it): the same for every hop, kept
+    // in LDS behind the zero row (registers otherwise; a row's lanes read one address - a broadcast)
+    int *ptrl = reinterpret_cast<int *>(smem + zoff + 128);
+    for (int r = threadIdx.x; r <= R; r += 1024) ptrl[r] = p.ptr[n0 + (r < nn ? r : nn)];
     const __amdgpu_buffer_rsrc_t ro =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(p.other), 0, p.cap * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw =
@@ -242,53 +257,63 @@ k_hop_chain(ChainParams p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): the slice has landed (a wait hipcc can see:
     lds_barrier();                                               // behind an asm wait it drains vmcnt before every ds_read)
 
-    // row maxima: every lane keeps the running maximum of ITS four columns of each of its 8 rows; the 8 lanes of a
-    // row piece are joined once, at the end
+    // row maxima: every lane keeps the running maximum of ITS four columns of each of its rows; the lanes of a row piece
+    // are joined once, at the end
     const bool want_rm = p.rowmax != nullptr;
     float pm[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         pm[s] = 0.f;
         if (s < STEPS && want_rm && (p.rm_mode & 1))             // the row's own piece of the source block
-            pm[s] = chain_absmax(*reinterpret_cast<const float4 *>(smem + (rwave + 8 * s + grp) * 128 + 16 * sub));
+            pm[s] = chain_absmax(*reinterpret_cast<const float4 *>(smem + (rwave + RPW * s + grp) * RB + 16 * sub));
     }
 
     const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-    const unsigned lbase = sbase + 16u * sub - ((DC_CHAIN_ABL & 128) ? 0u : (unsigned)n0 * 128u);   // LDS address of a neighbour's piece: id * 128 + lbase
+    const unsigned lbase = sbase + 16u * sub - ((DC_CHAIN_ABL & 128) ? 0u : (unsigned)n0 * (unsigned)RB);   // LDS address of a neighbour's piece: id * RB + lbase
     const unsigned zsub = sbase + zoff + 16u * sub;
-    const LdsWindow win{sbase + 16u * sub, (unsigned)nn * 128u};
+    const LdsWindow win{sbase + 16u * sub, (unsigned)nn * (unsigned)RB};
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.slab + (int64_t)n0 * p.ld, 0, (int)((unsigned)nn * (unsigned)p.ld * 4u), 0x00020000);
     const unsigned ldb = (unsigned)p.ld * 4u;
     for (int h = 0; h < p.K; ++h) {
-        const unsigned dcol = (unsigned)((p.src0 + (h + 1) * p.dir) * p.F + slice * kChainCols + 4 * sub) * 4u;
+        const unsigned dcol = (unsigned)((p.src0 + (h + 1) * p.dir) * p.F + slice * COLS + 4 * sub) * 4u;
         float4 acc[STEPS];
         Chunk ck[2];                                             // ids / weights: this step's and the next one's
         int2 bd[2];
-        bd[0] = bounds[rwave + grp];
+        {
+            const int b = ptrl[rwave + grp], e = ptrl[rwave + grp + 1];
+            bd[0] = make_int2(b, e - b);
+        }
         load_chunk<W>(ck[0], ro, rw, bd[0].x);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int pbeg = bd[s & 1].x, rem = bd[s & 1].y;
             if (s + 1 < STEPS) {                                 // one step ahead
-                bd[(s + 1) & 1] = bounds[rwave + 8 * (s + 1) + grp];
-                load_chunk<W>(ck[(s + 1) & 1], ro, rw, bd[(s + 1) & 1].x);
+                const int r1 = rwave + RPW * (s + 1) + grp;
+                const int b = ptrl[r1], e = ptrl[r1 + 1];
+                bd[(s + 1) & 1] = make_int2(b, e - b);
+                load_chunk<W>(ck[(s + 1) & 1], ro, rw, b);
             }
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            step_rows<W>(a, ck[s & 1], pbeg, rem, lbase, zsub, win, ro, rw);
+            step_rows<W, RB>(a, ck[s & 1], pbeg, rem, lbase, zsub, win, ro, rw);
             acc[s] = a;
             pm[s] = fmaxf(pm[s], chain_absmax(a));
-            store_piece(a, rs, (unsigned)(rwave + 8 * s + grp) * ldb + dcol);               // streams out meanwhile
+            store_piece(a, rs, (unsigned)(rwave + RPW * s + grp) * ldb + dcol);             // streams out meanwhile
         }
         if (h + 1 == p.K) break;
         if (DC_CHAIN_ABL & 4) continue;
         lds_barrier();                                           // every wave has read what it needs of block h
 #pragma unroll
         for (int s = 0; s < STEPS; ++s)
-            *reinterpret_cast<float4 *>(smem + (rwave + 8 * s + grp) * 128 + 16 * sub) = acc[s];
+            *reinterpret_cast<float4 *>(smem + (rwave + RPW * s + grp) * RB + 16 * sub) = acc[s];
         lds_barrier();
     }
-    if (want_rm) publish_rowmax(pm, sub, STEPS, rwave + 8 * sub + grp, nn, p.rowmax + n0);
+    if (want_rm) {
+        if constexpr (LPR == 8)
+            publish_rowmax(pm, sub, STEPS, rwave + 8 * sub + grp, nn, p.rowmax + n0);
+        else
+            publish_rowmax_narrow<STEPS, LPR>(pm, sub, rwave + grp, nn, p.rowmax + n0);
+    }
 }
 
 // ---- gcn_norm weights: adjacency resident in LDS too -------------------------------------------------------------------
@@ -336,6 +361,13 @@ k_hop_chain_gcn(ChainParams p) {
     float *blk = p.slab + (int64_t)n0 * p.ld + slice * kChainCols + 4 * sub;
     // LDS: slice [R][128 B] | zeros [128 B] | ids [R][8] u16 | dis [R + 1] f32 (16-byte padded) | {first edge, degree} [R]
     constexpr int kIds = (R + 1) * 128, kDis = kIds + R * 16, kBounds = kDis + ((R + 1) * 4 + 15) / 16 * 16;
+#ifdef DC_CHAIN_POISON
+    // diagnostic build (tools/r05): every byte of the workgroup's LDS starts as a quiet NaN, so that a read of LDS this
+    // launch has not written yet cannot pass for data
+    for (int i = threadIdx.x; i < (kBounds + R * 8) / 16; i += 1024)
+        reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u);
+    __syncthreads();
+#endif
     // prologue, by wave role: waves 8-15 issue ALL the LDS-DMA of the slice (one instruction = 8 rows x 128 B, contiguous
     // in LDS), waves 0-7 build the tables.  hipcc makes a wave with LDS-DMA in flight wait for vmcnt(0) before each of
     // its own LDS accesses: with both jobs in every wave the tables' loads were only issued once the slice had landed.
@@ -436,6 +468,13 @@ k_hop_chain_gcn(ChainParams p) {
         lds_barrier();
     }
     if (want_rm) publish_rowmax(pm, sub, STEPS, rwave + 8 * sub + grp, nn, p.rowmax + n0);
+#ifdef DC_CHAIN_POISON_END
+    // diagnostic build (tools/r05): leave quiet NaNs behind in the slice, so that a LATER workgroup on this CU that reads LDS
+    // it has not (yet) written cannot pass for data of the right magnitude; the prologue's timing stays what it is
+    lds_barrier();
+    for (int i = threadIdx.x; i < (R + 1) * 8; i += 1024)
+        reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u);
+#endif
 }
 
 template <int STEPS>
@@ -443,16 +482,21 @@ static bool launch_chain_gcn_steps(unsigned grid, hipStream_t stream, const Chai
     constexpr int R = 128 * STEPS;
     constexpr size_t lds = (size_t)(R + 1) * 128 + (size_t)R * 16 + ((size_t)(R + 1) * 4 + 15) / 16 * 16 + (size_t)R * 8;
     static_assert(lds <= 160 * 1024, "k_hop_chain_gcn: tables do not fit the LDS");
+#ifdef DC_CHAIN_LDS_FULL
+    constexpr size_t lds_req = 160 * 1024;      // diagnostic build: the whole CU's LDS, no other LDS-using workgroup beside it
+#else
+    constexpr size_t lds_req = lds;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain_gcn<STEPS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) != hipSuccess)
             return false;
         attr_set = true;
     }
     static const std::string name = "k_hop_chain_gcn<" + std::to_string(STEPS) + ">";
     trace_kernel(name.c_str());
-    hipLaunchKernelGGL((k_hop_chain_gcn<STEPS>), dim3(grid), dim3(1024), lds, stream, p);
+    hipLaunchKernelGGL((k_hop_chain_gcn<STEPS>), dim3(grid), dim3(1024), lds_req, stream, p);
     return true;
 }
 
@@ -469,34 +513,37 @@ static bool launch_chain_gcn(int steps, unsigned grid, hipStream_t stream, const
     }
 }
 
-template <bool W, int STEPS>
+template <bool W, int STEPS, int LPR>
 static bool launch_chain_steps(unsigned grid, hipStream_t stream, const ChainParams &p) {
-    // slice + zero row + {first edge, degree} per row
-    constexpr size_t lds = ((size_t)128 * STEPS + 1) * 128 + (size_t)128 * STEPS * 8;
+    // slice + zero row (in a 128-byte slot) + the graph's slice of ptr
+    constexpr int R = 16 * (64 / LPR) * STEPS;
+    constexpr size_t lds = (size_t)R * 16 * LPR + 128 + ((size_t)(R + 1) * 4 + 15) / 16 * 16;
+    static_assert(lds <= 160 * 1024, "k_hop_chain: slice does not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain<W, STEPS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain<W, STEPS, LPR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return false;
         attr_set = true;
     }
-    static const std::string name = std::string("k_hop_chain<") + (W ? "true, " : "false, ") + std::to_string(STEPS) + ">";
+    static const std::string name = std::string("k_hop_chain<") + (W ? "true, " : "false, ") + std::to_string(STEPS) + ", " +
+                                    std::to_string(LPR) + ">";
     trace_kernel(name.c_str());
-    hipLaunchKernelGGL((k_hop_chain<W, STEPS>), dim3(grid), dim3(1024), lds, stream, p);
+    hipLaunchKernelGGL((k_hop_chain<W, STEPS, LPR>), dim3(grid), dim3(1024), lds, stream, p);
     return true;
 }
 
-template <bool W>
+template <bool W, int LPR>
 static bool launch_chain(int steps, unsigned grid, hipStream_t stream, const ChainParams &p) {
     switch (steps) {
-    case 1: return launch_chain_steps<W, 1>(grid, stream, p);
-    case 2: return launch_chain_steps<W, 2>(grid, stream, p);
-    case 3: return launch_chain_steps<W, 3>(grid, stream, p);
-    case 4: return launch_chain_steps<W, 4>(grid, stream, p);
-    case 5: return launch_chain_steps<W, 5>(grid, stream, p);
-    case 6: return launch_chain_steps<W, 6>(grid, stream, p);
-    case 7: return launch_chain_steps<W, 7>(grid, stream, p);
-    default: return launch_chain_steps<W, 8>(grid, stream, p);
+    case 1: return launch_chain_steps<W, 1, LPR>(grid, stream, p);
+    case 2: return launch_chain_steps<W, 2, LPR>(grid, stream, p);
+    case 3: return launch_chain_steps<W, 3, LPR>(grid, stream, p);
+    case 4: return launch_chain_steps<W, 4, LPR>(grid, stream, p);
+    case 5: return launch_chain_steps<W, 5, LPR>(grid, stream, p);
+    case 6: return launch_chain_steps<W, 6, LPR>(grid, stream, p);
+    case 7: return launch_chain_steps<W, 7, LPR>(grid, stream, p);
+    default: return launch_chain_steps<W, 8, LPR>(grid, stream, p);
     }
 }
 
@@ -504,7 +551,7 @@ static bool launch_chain(int steps, unsigned grid, hipStream_t stream, const Cha
 
 using namespace dc;
 
-extern "C" int64_t dc_hop_chain_max_nodes(void) { return 128 * kChainSteps; }
+extern "C" int64_t dc_hop_chain_max_nodes(void) { return 4 * 128 * kChainSteps; }      // 8-column slices: 4,096 nodes
 
 extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
                                 int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
@@ -529,9 +576,9 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
     DC_REQUIRE(node_ptr_host[0] == 0 && node_ptr_host[nseg] == N, "dc_hop_chain_f32: the graphs' offsets must cover [0, N]");
     for (int i = 0; i < nseg; ++i) {
         const int64_t dn = node_ptr_host[i + 1] - node_ptr_host[i];
-        DC_REQUIRE(dn >= 0 && dn <= 128 * kChainSteps,
+        DC_REQUIRE(dn >= 0 && dn <= 4 * 128 * kChainSteps,
                    "dc_hop_chain_f32: graph %d has %lld nodes (cap %d): use dc_spmm_f32 hop by hop", i, (long long)dn,
-                   128 * kChainSteps);
+                   4 * 128 * kChainSteps);
     }
     if (rowmax && !(mode & 2)) {
         if (hipMemsetAsync(rowmax, 0, (size_t)N * sizeof(float), stream) != hipSuccess)
@@ -551,11 +598,16 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
         }
         if (big == 0) continue;
         p.nseg = cnt;
-        const int smax = (int)((big + 127) / 128);
+        // slice width by the largest graph of the launch: 32 columns up to 1,024 nodes, 16 up to 2,048, 8 up to 4,096
+        const int lpr = big <= 128 * kChainSteps ? 8 : big <= 2 * 128 * kChainSteps ? 4 : 2;
+        const int rows_per_step = 16 * (64 / lpr);
+        const int smax = (int)((big + rows_per_step - 1) / rows_per_step);
+        p.nslices = (int)(F / (4 * lpr));
         const unsigned grid = (unsigned)cnt * (unsigned)p.nslices;
-        const bool ok = deg_ptr ? launch_chain_gcn(smax, grid, stream, p)
-                        : w     ? launch_chain<true>(smax, grid, stream, p)
-                                : launch_chain<false>(smax, grid, stream, p);
+        const bool ok = (deg_ptr && lpr == 8) ? launch_chain_gcn(smax, grid, stream, p)
+                        : lpr == 8 ? (w ? launch_chain<true, 8>(smax, grid, stream, p) : launch_chain<false, 8>(smax, grid, stream, p))
+                        : lpr == 4 ? (w ? launch_chain<true, 4>(smax, grid, stream, p) : launch_chain<false, 4>(smax, grid, stream, p))
+                                   : (w ? launch_chain<true, 2>(smax, grid, stream, p) : launch_chain<false, 2>(smax, grid, stream, p));
         DC_REQUIRE(ok, "dc_hop_chain_f32: cannot reserve the kernel's LDS");
     }
     return check_launch("dc_hop_chain_f32");

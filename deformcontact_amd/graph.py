@@ -136,11 +136,15 @@ class GraphIndex:
         self._num_edges = None if self_loops else self.num_input_edges
         #: nodes of the largest graph of the batch (``ops.chained_hops`` picks ``dc_hop_chain_f32`` by it)
         self._seg_max_nodes = 0
+        #: ``(node offsets, B)`` of the batch's graphs - all ``dc_hop_chain_f32`` needs of the layout (it holds for
+        #: graphs beyond the segmented BUILD's LDS caps too: a 4,096-node mesh has ~24k edges, the build takes 16k)
+        self._layout = None
         if segments is not None and parts is None and not self_loops:
             self._segments = _segment_arrays(segments, self.num_nodes, self.num_input_edges, self.device)
-            if self._segments is not None:
-                nodes = self._segments[0]
-                self._seg_max_nodes = max(nodes[i + 1] - nodes[i] for i in range(self._segments[2]))
+            self._layout = _layout_arrays(segments, self.num_nodes)
+            if self._layout is not None:
+                nodes = self._layout[0]
+                self._seg_max_nodes = max(nodes[i + 1] - nodes[i] for i in range(self._layout[1]))
         self.rebuild()
         if validate:
             self.validate()
@@ -286,6 +290,19 @@ def _segment_arrays(segments, num_nodes: int, num_edges: int, device):
             return None                      # (edges without nodes: the global pipeline flags them)
     import ctypes
     return ((ctypes.c_int64 * (nseg + 1))(*nodes), (ctypes.c_int64 * (nseg + 1))(*edges), nseg)
+
+
+def _layout_arrays(segments, num_nodes: int):
+    """Node offsets of a batch's graphs as the host array ``dc_hop_chain_f32`` takes (ascending, covering [0, N]), or
+    None.  Unlike ``_segment_arrays`` no per-graph cap applies here - the chain entry has its own (4,096 nodes)."""
+    if num_nodes <= 0:
+        return None
+    nodes = tuple(int(v) for v in segments[0])
+    nseg = len(nodes) - 1
+    if nseg < 1 or nodes[0] != 0 or nodes[-1] != num_nodes or any(nodes[i + 1] < nodes[i] for i in range(nseg)):
+        return None
+    import ctypes
+    return ((ctypes.c_int64 * (nseg + 1))(*nodes), nseg)
 
 
 #: DC_VALIDATE=1 graphs built under capture, waiting for their first replay (``validate_pending``)

@@ -214,9 +214,10 @@ _CHAIN_MAX_NODES = None
 
 def hop_chain_eligible(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int) -> bool:
     """Can ``dc_hop_chain_f32`` run this chain?  Needs the batch layout (``graph_index(..., segments=)``), graphs
-    of at most ``dc_hop_chain_max_nodes()`` nodes, F % 32 == 0 and 16-byte aligned slab rows."""
+    of at most ``dc_hop_chain_max_nodes()`` nodes (4,096: 32-column slices up to 1,024 nodes, 16 up to 2,048, 8 beyond),
+    F % 32 == 0 and 16-byte aligned slab rows."""
     global _CHAIN_MAX_NODES
-    seg = getattr(g, "_segments", None)
+    seg = getattr(g, "_layout", None)
     if not HOP_CHAIN or seg is None or k < 1 or f % 32 != 0 or adj.row_offset:
         return False
     if _CHAIN_MAX_NODES is None:
@@ -236,7 +237,7 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
               rowmax: Optional[torch.Tensor] = None, rowmax_mode: int = 0, src_block: int = 0, direction: int = 1) -> None:
     """``dc_hop_chain_f32``: blocks ``src_block + direction .. src_block + k * direction`` of ``slab`` from block
     ``src_block``, one launch (see ``hop_chain_eligible``)."""
-    nptr, _, nseg = g._segments
+    nptr, nseg = g._layout
     w = adj.w if weighted else None
     # the adjacency's weights are gcn_norm's (graph.GraphIndex builds nothing else): tell the kernel so - for graphs above
     # 512 nodes.  Below that a workgroup of the LDS-table form needs < 80 KB of LDS, several share a CU, and that is the only

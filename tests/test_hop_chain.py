@@ -88,12 +88,18 @@ def test_config1_b32_chains_equal_three_hops_bitwise(bwd, gcn):
     ((64,) * 5, (4,) * 5, 32, 1, None),
     ((1000, 24), (12, 3), 128, 3, (0, 200)),
     ((700,) * 100, (5,) * 100, 32, 2, (99, 41)),                                             # > 96 graphs: two launches
+    # beyond 1,024 nodes per graph: 16-column slices up to 2,048 nodes, 8-column ones up to 4,096;
+    # the batch layout alone decides (these graphs are beyond the segmented BUILD's edge cap: global build pipeline)
+    ((1500, 1025, 7), (6, 3, 2), 256, 3, (0, 90)),
+    ((2048, 2047, 0, 1), (5, 2, 0, 0), 64, 2, (1, 33)),
+    ((3000, 2049), (6, 4), 256, 3, (0, 19)),
+    ((4096, 10, 4095), (4, 1, 7), 32, 3, (2, 300)),
 ])
 def test_ragged_batches_hubs_and_caps(sizes, degs, f, k, hub):
     ei, segs = batch_of_graphs(sizes, degs, seed=len(sizes) + f, hub=hub)
     n = segs[0][-1]
     g = GraphIndex(ei.to(DEV), n, segments=segs)
-    assert g._segments is not None and g._seg_max_nodes == max(sizes)
+    assert g._layout is not None and g._seg_max_nodes == max(sizes)
     for adj, mode in ((g.fwd, 1), (g.bwd, 2), (g.fwd, 0), (g.bwd, 3)):
         for gcn in (True, False):
             run_both(g, adj, n, f, k, mode, seed=mode, gcn=gcn)
@@ -134,9 +140,10 @@ def test_c_abi_rejects_what_it_cannot_run():
                                   g.fwd.ptr.data_ptr() if deg else None, g.fwd.other.numel(),
                                   nptr, 2, slab.data_ptr(), slab.stride(0), n, f, k, src, direction, None, 0,
                                   current_stream_ptr(slab.device))
-    g, slab, n, nptr = setup((1025, 10))
+    assert L.dc_hop_chain_max_nodes() == 4096
+    g, slab, n, nptr = setup((4097, 10))
     assert not ops.hop_chain_eligible(g, g.fwd, slab, 32, 1)        # a graph beyond the cap: hop by hop
-    assert call(g, slab, n, nptr) != 0 and b"1025 nodes" in L.dc_last_error()
+    assert call(g, slab, n, nptr) != 0 and b"4097 nodes" in L.dc_last_error()
     g, slab, n, nptr = setup((1024, 11))
     assert ops.hop_chain_eligible(g, g.fwd, slab, 32, 1) and call(g, slab, n, nptr) == 0
     assert call(g, slab, n, nptr, f=24) != 0                        # F % 32
@@ -172,7 +179,8 @@ def test_small_graphs_take_the_loading_form_of_the_chain_kernel():
     weights loaded per step), larger ones `k_hop_chain_gcn<STEPS>` (adjacency tables in LDS) - by name, through the launch log
     (profiles/r04/e_chain_rerun_difference.txt: the only configuration in which the LDS-table form was ever seen to differ
     between two runs is several small workgroups per CU)."""
-    for sv, want, banned in ((256, "k_hop_chain<true", "k_hop_chain_gcn"), (1024, "k_hop_chain_gcn", "k_hop_chain<")):
+    for sv, want, banned in ((256, "k_hop_chain<true, 2, 8>", "k_hop_chain_gcn"), (1024, "k_hop_chain_gcn", "k_hop_chain<"),
+                             (1500, "k_hop_chain<true, 6, 4>", "k_hop_chain_gcn"), (3000, "k_hop_chain<true, 6, 2>", "k_spmm")):
         rest, _, _ = synth.make_batch(4, soft_vertices=sv, sphere_resolution=8)
         g = GraphIndex(rest.edge_index.to(DEV), rest.x.shape[0], segments=rest.segments())
         slab = ops._alloc_slab(rest.x.shape[0], 4 * 256, DEV).normal_()
