@@ -252,7 +252,8 @@ int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
  * in-degree: ptr of the by-destination set, for BOTH sets of dc_graph_build*): the kernel then
  * re-forms them from an LDS-resident table instead of loading them (same bits) and its hop loop
  * is free of vector-memory loads.  Needs F % 32 == 0, ld % 4 == 0, a 16-byte aligned slab and at most
- * dc_hop_chain_max_nodes() (1024) nodes per graph; DC_EINVAL otherwise (use dc_spmm_f32). */
+ * dc_hop_chain_max_nodes() (4096: 32-column slices up to 1,024 nodes, 16-column ones up to 2,048, 8-column ones beyond; the
+ * LDS-table form only with 32-column slices) nodes per graph; DC_EINVAL otherwise (use dc_spmm_f32). */
 int64_t dc_hop_chain_max_nodes(void);
 int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
                      int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,

@@ -48,3 +48,4 @@ def test_encoder_first_layer_uses_the_fused_launch_and_matches(monkeypatch):
         outs.append([a.detach().cpu().numpy(), b.detach().cpu().numpy()] + [p.grad.cpu().numpy() for p in enc.parameters()])
     for u, v in zip(*outs):
         assert np.array_equal(u, v)
+
