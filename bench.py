@@ -829,6 +829,10 @@ def main():
     from deformcontact_amd.launch import install_watchdog, phase
     if world > 1:
         install_watchdog()                 # DC_RANK_WATCHDOG_S: periodic stack dumps of a rank that is stuck
+        # N ranks share the node's cores: N machine-wide OpenMP / MKL pools starve each other (launch.py; torchrun sets
+        # OMP_NUM_THREADS = 1 for the same reason)
+        from deformcontact_amd.launch import rank_cpu_threads
+        torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", rank_cpu_threads(world))))
     stall = os.environ.get("DC_TEST_STALL_RANK")       # tests/test_z_launch.py: a rank that never gets anywhere
     if stall is not None and stall in ("all", str(rank)):
         phase("stalled (DC_TEST_STALL_RANK)")

@@ -36,6 +36,15 @@ namespace dc {
 constexpr int kChainCols = 32;        // columns per slice: 128-byte row pieces, one full cache line per store
 constexpr int kChainSteps = 8;        // 16 waves x 8 row groups x 8 steps = DC_CHAIN_MAX_NODES nodes per graph
 constexpr int kChainGraphs = 96;      // graphs per launch (their node offsets travel as kernel arguments)
+// Every chain workgroup asks for the WHOLE LDS of its compute unit (160 KB), whatever its slice needs: no other LDS-using
+// workgroup can then be resident beside it.  Round 5 traced the rare run-to-run difference of profiles/r04/
+// e_chain_rerun_difference.txt to exactly that co-residency (profiles/r05/README.md): with correct inputs in memory a chain
+// workgroup of 20 - 100 KB returned a few wrong elements in 0.3 - 1.75 % of two-stream train steps - only when the other
+// encoder branch's stream shared compute units with it (35 of 2,000 steps; 0 of 2,000 with disjoint CU masks), only with stock
+// PyTorch attention kernels (rocBLAS GEMMs / ATen softmax) in the step (0 of 2,000 with this library's own), and never once
+// it held the full 160 KB (0 of 2,000; 10 of 900 at 100 KB in round 4).  At the benchmark shape the slices are 131 - 150 KB
+// already: one workgroup per CU either way.
+constexpr size_t kChainLdsRequest = 160 * 1024;
 
 struct ChainParams {
     const int32_t *ptr, *other;
@@ -482,10 +491,10 @@ static bool launch_chain_gcn_steps(unsigned grid, hipStream_t stream, const Chai
     constexpr int R = 128 * STEPS;
     constexpr size_t lds = (size_t)(R + 1) * 128 + (size_t)R * 16 + ((size_t)(R + 1) * 4 + 15) / 16 * 16 + (size_t)R * 8;
     static_assert(lds <= 160 * 1024, "k_hop_chain_gcn: tables do not fit the LDS");
-#ifdef DC_CHAIN_LDS_FULL
-    constexpr size_t lds_req = 160 * 1024;      // diagnostic build: the whole CU's LDS, no other LDS-using workgroup beside it
+#ifdef DC_CHAIN_LDS_TIGHT
+    constexpr size_t lds_req = lds;              // diagnostic build (tools/r05): only what the slice needs, as up to round 4
 #else
-    constexpr size_t lds_req = lds;
+    constexpr size_t lds_req = kChainLdsRequest;
 #endif
     static bool attr_set = false;
     if (!attr_set) {
@@ -518,18 +527,18 @@ static bool launch_chain_steps(unsigned grid, hipStream_t stream, const ChainPar
     // slice + zero row (in a 128-byte slot) + the graph's slice of ptr
     constexpr int R = 16 * (64 / LPR) * STEPS;
     constexpr size_t lds = (size_t)R * 16 * LPR + 128 + ((size_t)(R + 1) * 4 + 15) / 16 * 16;
-    static_assert(lds <= 160 * 1024, "k_hop_chain: slice does not fit the LDS");
+    static_assert(lds <= kChainLdsRequest, "k_hop_chain: slice does not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hop_chain<W, STEPS, LPR>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsRequest) != hipSuccess)
             return false;
         attr_set = true;
     }
     static const std::string name = std::string("k_hop_chain<") + (W ? "true, " : "false, ") + std::to_string(STEPS) + ", " +
                                     std::to_string(LPR) + ">";
     trace_kernel(name.c_str());
-    hipLaunchKernelGGL((k_hop_chain<W, STEPS, LPR>), dim3(grid), dim3(1024), lds, stream, p);
+    hipLaunchKernelGGL((k_hop_chain<W, STEPS, LPR>), dim3(grid), dim3(1024), kChainLdsRequest, stream, p);
     return true;
 }
 

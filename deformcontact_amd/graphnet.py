@@ -205,7 +205,44 @@ class CrossAttention(nn.Module):
     fused = os.environ.get("DC_FUSED_ATTN", "auto")
     fused_min_scores = 1 << 26
 
-    def forward(self, x_resting, x_rigid):
+    #: SURVEY.md 8(f) rank 1, third part - an OPTION the reference does not have and that is OFF by default (parity): the
+    #: reference's attention is unmasked across the batch (``models/model.py:16-18``: a soft node attends to the rigid
+    #: nodes of EVERY sample of the device batch), which makes a sample's prediction depend on which other
+    #: samples share its batch and costs B x the work.  ``per_graph_mask = True`` restricts every soft node to the rigid
+    #: nodes of its own sample (a block-diagonal mask over the batch layout ``Batch.from_data_list`` records): the
+    #: batch-size-independent form, B separate [N_s/B, N_r/B] attentions instead of one [N_s, N_r] one.
+    per_graph_mask = False
+
+    def _per_graph(self, x_resting, x_rigid, seg_rest, seg_rig):
+        ns, nr = [int(v) for v in seg_rest[0]], [int(v) for v in seg_rig[0]]
+        if len(ns) != len(nr) or ns[-1] != x_resting.size(0) or nr[-1] != x_rigid.size(0):
+            raise ValueError("per-graph attention mask: the two batches must hold the same number of graphs and their "
+                             "layouts must cover the feature matrices")
+        b = len(ns) - 1
+        ds, dr = {ns[i + 1] - ns[i] for i in range(b)}, {nr[i + 1] - nr[i] for i in range(b)}
+        pooled = []
+        for head in self.attention_heads:
+            q, k = _linear(head, x_resting), _linear(head, x_rigid)
+            if len(ds) == 1 and len(dr) == 1 and 0 not in dr:
+                # equal-size graphs (the everyday shape): one batched product per step
+                qs, ks, vs = q.view(b, -1, q.size(1)), k.view(b, -1, k.size(1)), x_rigid.view(b, -1, x_rigid.size(1))
+                pooled.append((torch.softmax(qs @ ks.transpose(1, 2), dim=-1) @ vs).reshape(x_resting.size(0), -1))
+            else:
+                parts = []
+                for i in range(b):
+                    qi, ki, vi = q[ns[i]:ns[i + 1]], k[nr[i]:nr[i + 1]], x_rigid[nr[i]:nr[i + 1]]
+                    if ki.size(0) == 0:                  # a sample without rigid nodes: nothing to attend to
+                        parts.append(qi.new_zeros(qi.size(0), x_rigid.size(1)))
+                    else:
+                        parts.append(torch.softmax(qi @ ki.t(), dim=-1) @ vi)
+                pooled.append(torch.cat(parts, dim=0))
+        return torch.cat(pooled, dim=-1)
+
+    def forward(self, x_resting, x_rigid, segments=None):
+        if self.per_graph_mask:
+            if segments is None or segments[0] is None or segments[1] is None:
+                raise ValueError("per_graph_mask needs the layouts of both batches (data.Batch.segments())")
+            return self._per_graph(x_resting, x_rigid, segments[0], segments[1])
         pooled = []
         eligible = (x_resting.is_cuda and x_resting.dtype == torch.float32
                     and x_resting.size(1) % 16 == 0 and x_rigid.size(0) > 0)
@@ -248,7 +285,10 @@ class GraphNet(ContactEncoder):
 
     def forward(self, graph_resting, graph_rigid):
         x_rest, x_rig = self.encode(graph_resting, graph_rigid)
-        pooled = self.multihead_attention(x_rest, x_rig)     # always applied (reference quirk)
+        if self.multihead_attention.per_graph_mask:          # (opt-in; the reference attends across the whole batch)
+            pooled = self.multihead_attention(x_rest, x_rig, (_segments_of(graph_resting), _segments_of(graph_rigid)))
+        else:
+            pooled = self.multihead_attention(x_rest, x_rig)     # always applied (reference quirk)
         delta = self._decode(torch.cat([x_rest, pooled], dim=-1))
         out = graph_resting.clone()
         if self.mode == "res":

@@ -9,7 +9,13 @@ tests start their ranks through this module.  Rules it keeps (they come from the
 * a stuck rendezvous or collective cannot hold the caller for ever: ``timeout`` seconds, then every rank is stopped;
 * every rank's stdout / stderr go to their own files (``log_dir``) and every rank leaves PHASE MARKERS there, so a
   failure says which rank stopped where - round 4's only record of a two-rank hang was the last 2,000 bytes of two
-  interleaved tracebacks.
+  interleaved tracebacks;
+* the ranks' CPU thread pools are capped (``OMP_NUM_THREADS`` / ``MKL_NUM_THREADS``, unless the caller set them) - as
+  torchrun does.  THIS is what round 4's hang was: with N ranks each owning an OpenMP / MKL pool as wide as the machine, the
+  pools' spinning workers starve each other and every tiny MKL vector call of the synthetic-batch generation
+  (``features.to_log_freq``: sin / cos of a [1024, 3] tensor) takes ~0.1 s - round 5's watchdog caught both ranks of a
+  two-rank launch still generating their first batches after 160 s (``profiles/r05/e_two_rank_launch_failure/``), a job that takes
+  2 s alone; in round 4 the slower rank arrived at the first gradient all-reduce after the faster one's 240 s gloo timeout.
 
 Environment a rank sees: ``RANK``, ``LOCAL_RANK``, ``WORLD_SIZE``, ``MASTER_ADDR=127.0.0.1``, ``MASTER_PORT``,
 ``DC_RANK_LOG_DIR`` (phase markers), ``DC_RANK_WATCHDOG_S`` (``install_watchdog``).
@@ -29,6 +35,11 @@ def free_port() -> int:
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+def rank_cpu_threads(n: int) -> int:
+    """CPU threads per rank: the ranks of one node share its cores (half of them, split N ways, at most 8 each)."""
+    return max(1, min(8, (os.cpu_count() or 1) // (2 * max(n, 1))))
 
 
 def phase(name: str) -> None:
@@ -125,6 +136,9 @@ def launch_ranks(n: int, argv: Sequence[str], *, timeout: float, log_dir: Option
     port = free_port()
     base = dict(os.environ if env is None else env)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    threads = str(rank_cpu_threads(n))
+    base.setdefault("OMP_NUM_THREADS", threads)
+    base.setdefault("MKL_NUM_THREADS", threads)
     procs, files = [], []
     t0 = time.time()
     try:

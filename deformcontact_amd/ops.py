@@ -228,9 +228,11 @@ def hop_chain_eligible(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: i
 
 
 #: re-form gcn_norm weights from an LDS-resident degree table inside ``dc_hop_chain_f32`` (no vector-memory loads in its
-#: hop loop) instead of loading ``w``; same bits.  ``DC_HOP_CHAIN_GCN=0``: always load them.
+#: hop loop) instead of loading ``w``; same bits.  ``DC_HOP_CHAIN_GCN=0``: always load them.  (Round 4 kept graphs of up to
+#: 512 nodes off this form because of a rare run-to-run difference; round 5 traced that to other kernels' workgroups sharing
+#: the compute unit's LDS with a small chain workgroup and removed the condition itself - every chain workgroup now owns
+#: the whole LDS, ``dc_hopchain.hip: kChainLdsRequest`` - so the size rule is gone.)
 HOP_CHAIN_GCN = os.environ.get("DC_HOP_CHAIN_GCN", "1") != "0"
-HOP_CHAIN_GCN_MIN_NODES = int(os.environ.get("DC_HOP_CHAIN_GCN_MIN_NODES", "512"))
 
 
 def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weighted: bool = True,
@@ -239,12 +241,8 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
     ``src_block``, one launch (see ``hop_chain_eligible``)."""
     nptr, nseg = g._layout
     w = adj.w if weighted else None
-    # the adjacency's weights are gcn_norm's (graph.GraphIndex builds nothing else): tell the kernel so - for graphs above
-    # 512 nodes.  Below that a workgroup of the LDS-table form needs < 80 KB of LDS, several share a CU, and that is the only
-    # configuration in which the rare run-to-run difference of profiles/r04/e_chain_rerun_difference.txt was ever seen
-    # (0 of 2,600 steps with 1,024-node graphs, 0 of 800 repetitions with the id / weight loading form at any size)
-    deg = g.fwd.ptr if (HOP_CHAIN_GCN and w is not None and g.normalize and not g.self_loops
-                        and g._seg_max_nodes > HOP_CHAIN_GCN_MIN_NODES) else None
+    # the adjacency's weights are gcn_norm's (graph.GraphIndex builds nothing else): tell the kernel so
+    deg = g.fwd.ptr if (HOP_CHAIN_GCN and w is not None and g.normalize and not g.self_loops) else None
     rc = _lib.lib().dc_hop_chain_f32(
         adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
         deg.data_ptr() if deg is not None else None, adj.other.numel(),

@@ -30,6 +30,7 @@ def main():
     import datetime
     from deformcontact_amd.launch import install_watchdog, phase
     install_watchdog()
+    torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "4")))      # ranks share the node's cores (launch.py)
     phase("start")
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(
         seconds=float(os.environ.get("DC_GLOO_TIMEOUT_S", "60"))))

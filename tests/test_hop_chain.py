@@ -60,11 +60,10 @@ def run_both(g, adj, n, f, k, mode, weighted=True, src=0, direction=1, with_rowm
     reference_chain(adj, a, f, k, ra, mode, weighted, src, direction)
     assert ops.hop_chain_eligible(g, adj, b, f, k)
     keep, ops.HOP_CHAIN_GCN = ops.HOP_CHAIN_GCN, gcn
-    keep_min, ops.HOP_CHAIN_GCN_MIN_NODES = ops.HOP_CHAIN_GCN_MIN_NODES, 0      # the LDS-table form also on small graphs
     try:
         ops.hop_chain(g, adj, b, f, k, weighted=weighted, rowmax=rb, rowmax_mode=mode, src_block=src, direction=direction)
     finally:
-        ops.HOP_CHAIN_GCN, ops.HOP_CHAIN_GCN_MIN_NODES = keep, keep_min
+        ops.HOP_CHAIN_GCN = keep
     torch.cuda.synchronize()
     assert torch.equal(a, b), f"blocks differ: {(a != b).sum().item()} elements"
     if with_rowmax:
@@ -174,12 +173,12 @@ def test_tagconv_layer_and_encoder_identical_with_and_without_the_chain(monkeypa
         assert np.array_equal(u, v)
 
 
-def test_small_graphs_take_the_loading_form_of_the_chain_kernel():
-    """`ops.HOP_CHAIN_GCN_MIN_NODES`: batches whose graphs have at most 512 nodes run `k_hop_chain<true, STEPS>` (ids and
-    weights loaded per step), larger ones `k_hop_chain_gcn<STEPS>` (adjacency tables in LDS) - by name, through the launch log
-    (profiles/r04/e_chain_rerun_difference.txt: the only configuration in which the LDS-table form was ever seen to differ
-    between two runs is several small workgroups per CU)."""
-    for sv, want, banned in ((256, "k_hop_chain<true, 2, 8>", "k_hop_chain_gcn"), (1024, "k_hop_chain_gcn", "k_hop_chain<"),
+def test_which_chain_kernel_runs_by_graph_size():
+    """Graphs of up to 1,024 nodes run `k_hop_chain_gcn<STEPS>` (adjacency tables in LDS) - small ones too: round 4 kept
+    graphs of up to 512 nodes on the id / weight loading form because of a rare run-to-run difference, which round 5 traced
+    to LDS co-residency with other kernels and removed at its source (every chain workgroup owns the whole LDS) -, larger
+    ones `k_hop_chain<true, STEPS, LPR>` with 16- / 8-column slices; by name, through the launch log."""
+    for sv, want, banned in ((256, "k_hop_chain_gcn<2>", "k_hop_chain<"), (1024, "k_hop_chain_gcn<8>", "k_hop_chain<"),
                              (1500, "k_hop_chain<true, 6, 4>", "k_hop_chain_gcn"), (3000, "k_hop_chain<true, 6, 2>", "k_spmm")):
         rest, _, _ = synth.make_batch(4, soft_vertices=sv, sphere_resolution=8)
         g = GraphIndex(rest.edge_index.to(DEV), rest.x.shape[0], segments=rest.segments())

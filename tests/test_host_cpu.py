@@ -342,3 +342,41 @@ def test_edge_equality_marks_do_not_outlive_the_edges_they_describe():
     loaders.mark_edge_equality(rest, deff2)
     deff2.edge_index.add_(0)                                     # rewritten in place: the version the mark names is gone
     assert not train._edges_known_equal(deff2, rest.edge_index)
+
+
+def test_optional_per_graph_attention_mask_equals_a_block_diagonal_softmax():
+    """SURVEY.md 8(f) rank 1 (optional per-graph block mask, OFF by default for parity): with the option on, every soft node
+    attends only to the rigid nodes of its own sample - equal to the reference formula with -inf outside the diagonal
+    blocks, forward and backward, for equal-size and for ragged batches; with the option off nothing changes."""
+    import torch
+    from deformcontact_amd.graphnet import CrossAttention
+    torch.manual_seed(0)
+    for ns, nr in (((0, 5, 10, 15), (0, 4, 8, 12)), ((0, 3, 9, 9, 14), (0, 2, 3, 7, 11))):
+        att = CrossAttention(8, 2)
+        xs = torch.randn(ns[-1], 8, requires_grad=True)
+        xr = torch.randn(nr[-1], 8, requires_grad=True)
+        plain = att(xs, xr)
+        att.per_graph_mask = True
+        got = att(xs, xr, ((ns, None), (nr, None)))
+        mask = torch.full((ns[-1], nr[-1]), float("-inf"))
+        for i in range(len(ns) - 1):
+            mask[ns[i]:ns[i + 1], nr[i]:nr[i + 1]] = 0.0
+        want = []
+        for head in att.attention_heads:
+            sc = head(xs) @ head(xr).t() + mask
+            want.append(torch.softmax(sc, dim=-1) @ xr)
+        want = torch.cat(want, dim=-1)
+        assert torch.allclose(got, want, atol=1e-6)
+        assert not torch.allclose(got, plain, atol=1e-3)
+        g = torch.randn_like(got)
+        ga = torch.autograd.grad(got, [xs, xr] + list(att.parameters()), g, retain_graph=True)
+        gb = torch.autograd.grad(want, [xs, xr] + list(att.parameters()), g)
+        for a, b in zip(ga, gb):
+            assert torch.allclose(a, b, atol=1e-5)
+        with pytest.raises(ValueError):
+            att(xs, xr)
+    # a sample without rigid nodes pools zeros
+    att = CrossAttention(8, 1)
+    att.per_graph_mask = True
+    out = att(torch.randn(6, 8), torch.randn(4, 8), (((0, 3, 6), None), ((0, 4, 4), None)))
+    assert out.shape == (6, 8) and float(out[3:].abs().max()) == 0.0 and float(out[:3].abs().max()) > 0

@@ -85,6 +85,14 @@ def test_launch_ranks_reports_codes_phases_and_logs(tmp_path):
     assert "rank 1: rc=3" in res.describe() and "err" in res.describe()
     ok = launch_ranks(2, [sys.executable, "-c", "pass"], timeout=60, log_dir=str(tmp_path))
     assert ok.rc == 0 and ok.rcs == [0, 0] and ok.phases() == [[], []]      # older markers cleared
+    # the ranks' CPU thread pools are capped unless the caller chose (round 4's two-rank hang: two machine-wide pools)
+    show = "import os; print(os.environ['OMP_NUM_THREADS'], os.environ['MKL_NUM_THREADS'])"
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    capped = launch_ranks(2, [sys.executable, "-c", show], timeout=60, log_dir=str(tmp_path), env=env)
+    a, b = capped.stdout0.split()
+    assert a == b and 1 <= int(a) <= 8
+    kept = launch_ranks(2, [sys.executable, "-c", show], timeout=60, log_dir=str(tmp_path), env=dict(env, OMP_NUM_THREADS="3"))
+    assert kept.stdout0.split()[0] == "3"
 
 
 # --------------------------------------------------------------------------- GPU: what the scenarios left behind
