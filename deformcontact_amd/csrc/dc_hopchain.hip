@@ -333,7 +333,7 @@ k_hop_chain(ChainParams p) {
 // by buffer loads every step's id wait also waited for the older block stores, and the compute ran in series with
 // the write path (r04 ablation: stores and slots cost 54 + 47 us of a 148 us step and did not overlap; without
 // in-loop loads 108 us).  Rows with more than 8 neighbours (mesh poles, hubs) take their tail from global memory.
-template <int NS, int J0 = 0>
+template <int NS, int J0 = 0, int RB = 128>
 __device__ __forceinline__ void gcn_slots(float4 &acc, const uint4 &iv, float di, unsigned lbase, unsigned dbase) {
     const unsigned pk[4] = {iv.x, iv.y, iv.z, iv.w};
     float4 v[NS];
@@ -342,7 +342,7 @@ __device__ __forceinline__ void gcn_slots(float4 &acc, const uint4 &iv, float di
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const unsigned id = ((J0 + j) & 1) ? pk[(J0 + j) >> 1] >> 16 : pk[(J0 + j) >> 1] & 0xffffu;
-        v[j] = lds_read4(id * 128u + lbase);
+        v[j] = lds_read4(id * (unsigned)RB + lbase);
         const float dj = *(const __attribute__((address_space(3))) float *)(uintptr_t)(id * 4u + dbase);
         ww[j] = dj * di;                                         // dis[source] * dis[destination] (a row's ids are its sources
     }                                                            // in the forward set, its destinations in the transposed one)
