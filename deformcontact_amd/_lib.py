@@ -43,6 +43,7 @@ _SIGNATURES = {
     "dc_attn_flash_fwd": (c_int, [_vp, c_int64, _vp, _vp, _vp, _vp, _vp, c_int64, c_int64, c_int64, c_int64, _vp,
                                   c_int64, _vp, _vp]),
     "dc_hop_chain_max_nodes": (c_int64, []),
+    "dc_hop_chain_lds_request": (c_int64, []),
     "dc_hop_chain_f32": (c_int, [_vp, _vp, _vp, _vp, c_int64, POINTER(c_int64), c_int, _vp, c_int64, c_int64, c_int64,
                                  c_int, c_int, c_int, _vp, c_int, _vp]),
     "dc_spmm_f32_bias_act": (c_int, [_vp, _vp, _vp, _vp, c_int64, _vp, c_int, _vp, c_int64, c_int64, c_int64, _vp]),

@@ -560,6 +560,8 @@ static bool launch_chain(int steps, unsigned grid, hipStream_t stream, const Cha
 
 using namespace dc;
 
+extern "C" int64_t dc_hop_chain_lds_request(void) { return (int64_t)kChainLdsRequest; }
+
 extern "C" int64_t dc_hop_chain_max_nodes(void) { return 4 * 128 * kChainSteps; }      // 8-column slices: 4,096 nodes
 
 extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,

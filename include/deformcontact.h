@@ -255,6 +255,11 @@ int dc_spmm_f32_rowmax(const int32_t *ptr, const int32_t *other, const float *w,
  * dc_hop_chain_max_nodes() (4096: 32-column slices up to 1,024 nodes, 16-column ones up to 2,048, 8-column ones beyond; the
  * LDS-table form only with 32-column slices) nodes per graph; DC_EINVAL otherwise (use dc_spmm_f32). */
 int64_t dc_hop_chain_max_nodes(void);
+/* Bytes of LDS every dc_hop_chain_f32 workgroup requests: the WHOLE LDS of a compute unit (160 KiB), whatever its slice
+ * needs, so that no LDS-using workgroup of another kernel can be resident beside it (round 5: with LDS left free, a
+ * co-resident workgroup of a stock attention kernel on another stream made small chain workgroups return wrong elements
+ * in 0.3 - 1.75 % of two-stream train steps; profiles/r05/README.md). */
+int64_t dc_hop_chain_lds_request(void);
 int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const float *w, const int32_t *deg_ptr,
                      int64_t cap, const int64_t *node_ptr_host, int nseg, float *slab, int64_t ld, int64_t N,
                      int64_t F, int K, int src_block, int dir, float *rowmax, int mode,

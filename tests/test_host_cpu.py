@@ -380,3 +380,13 @@ def test_optional_per_graph_attention_mask_equals_a_block_diagonal_softmax():
     att.per_graph_mask = True
     out = att(torch.randn(6, 8), torch.randn(4, 8), (((0, 3, 6), None), ((0, 4, 4), None)))
     assert out.shape == (6, 8) and float(out[3:].abs().max()) == 0.0 and float(out[:3].abs().max()) > 0
+
+
+def test_chain_workgroups_request_the_whole_lds():
+    """Round 5's fix of the chain launch's rare run-to-run difference: every `dc_hop_chain_f32` workgroup owns the whole LDS of
+    its compute unit, so that no LDS-using workgroup of another kernel can be resident beside it (35 of 2,000 two-stream train
+    steps differed with shared CUs and free LDS, 0 of 3,000 with this request; profiles/r05/README.md).  Pinned here so that a
+    later "optimisation" of the request does not bring the condition back unnoticed."""
+    from deformcontact_amd import _lib
+    assert _lib.lib().dc_hop_chain_lds_request() == 160 * 1024
+    assert _lib.lib().dc_hop_chain_max_nodes() == 4096
