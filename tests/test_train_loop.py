@@ -199,3 +199,52 @@ def test_fused_contact_losses_match_reference_formulation_and_golden():
     finally:
         dc_train.LOSS_DEBUG = old_dbg
         ops.contact_losses = real
+
+
+def _predict(model, rest, rig):
+    with torch.no_grad():
+        return model(rest, rig).pos
+
+
+def test_per_graph_attention_mask_makes_predictions_independent_of_the_batch_cpu():
+    """the reference's attention is unmasked across the batch, so a sample's prediction depends on
+    which other samples share its batch.  With the opt-in `per_graph_mask` it does not: sample i predicted inside a batch of 3
+    equals sample i predicted alone (CPU, oracle convs: host-side logic only).  With the option off (reference semantics)
+    the two differ."""
+    from deformcontact_amd.synth import make_batch
+    torch.manual_seed(0)
+    model = load_model(SMALL, conv_module=pyg_ref).eval()
+    rest3, _, rig3 = make_batch(3, soft_vertices=64, sphere_resolution=4)
+    n_s = rest3.x.shape[0] // 3
+    for masked in (True, False):
+        model.multihead_attention.per_graph_mask = masked
+        full = _predict(model, rest3, rig3)
+        diffs = []
+        for i in range(3):
+            r1, _, g1 = make_batch(1, first_idx=i, soft_vertices=64, sphere_resolution=4)
+            alone = _predict(model, r1, g1)
+            diffs.append(float((full[i * n_s:(i + 1) * n_s] - alone).abs().max()))
+        if masked:
+            assert max(diffs) < 1e-5, diffs
+        else:
+            assert max(diffs) > 1e-4, diffs
+
+
+@pytest.mark.gpu
+def test_per_graph_attention_mask_on_the_gpu_path_equals_single_sample_predictions():
+    """The same property through the HIP encoder (batched layout taken from `Batch.segments()`), forward and gradients finite."""
+    from deformcontact_amd.synth import make_batch
+    torch.manual_seed(0)
+    model = load_model(EVERYDAY_NETWORK).to("cuda:0")
+    model.multihead_attention.per_graph_mask = True
+    rest3, def3, rig3 = (b.to("cuda:0") for b in make_batch(3, soft_vertices=256, sphere_resolution=8))
+    n_s = rest3.x.shape[0] // 3
+    full = _predict(model, rest3, rig3)
+    for i in range(3):
+        r1, _, g1 = (b.to("cuda:0") for b in make_batch(1, first_idx=i, soft_vertices=256, sphere_resolution=8))
+        alone = _predict(model, r1, g1)
+        ref = float(alone.abs().max())
+        assert float((full[i * n_s:(i + 1) * n_s] - alone).abs().max()) <= 1e-5 * ref
+    out = losses(model, rest3, def3, rig3, 1.0)
+    out["loss"].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
