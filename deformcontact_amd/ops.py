@@ -375,24 +375,23 @@ def _tag_uses_h2(fi: int, k: int, fo: Optional[int] = None) -> bool:
     return ok and DENSE_H2_K0 and fo is not None and fi >= 128 and fi % 32 == 0 and fo % 16 == 0 and fo >= 64
 
 
-def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3, refresh: bool = False) -> None:
+def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3) -> None:
     """Compute and cache, on the current stream, the hop slab a ``TAGConv(in, out, K=k)`` layer
     will need for the no-grad input ``x`` over topology ``g`` (what ``loaders.PrefetchLoader`` does
-    for the next batch while the current one trains).  ``refresh``: ``x`` / ``g`` are static
-    buffers that have been refilled - recompute INTO the buffers cached for them earlier (their
-    addresses may be baked into captured graphs) instead of allocating new ones."""
+    for the next batch while the current one trains).
+
+    (Until round 5 a ``refresh=True`` mode recomputed INTO the cached buffers of refilled static inputs.  Nothing used it,
+    and it was unsafe: re-filing an eagerly allocated slab under the id of the capture that refreshed it made the next EAGER
+    lookup miss, replace the entry and free a buffer whose address a captured graph still wrote to - a memory access
+    fault at batch 32 when round 5 tried it (``tools/r05/fault_bisect.py``).  Removed; refilled static inputs rebuild their
+    slabs inside the captured step, as ``bench.py`` does.)"""
     _require_cuda(x, "x")
     if not HOP_CACHE or k < 1 or x.dtype != torch.float32 or x.dim() != 2:
         return
     fi = x.size(1)
     want = _tag_uses_h2(fi, k)
     key = _hop_cache_key(x, k, tag_slab_geometry(fi, k)[2], want)
-    if refresh:
-        old = getattr(g, "_hop_cache", {}).get(key)
-        into = (old[0], old[1]) if old is not None else None
-        slab, rowmax = _build_input_slab(g, x, k, want, into=into)
-        _hop_cache_put(g, key, x, slab, rowmax, x.device)
-    elif _hop_cache_get(g, key, x, x.device) is None:
+    if _hop_cache_get(g, key, x, x.device) is None:
         slab, rowmax = _build_input_slab(g, x, k, want)
         _hop_cache_put(g, key, x, slab, rowmax, x.device)
 
