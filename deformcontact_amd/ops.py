@@ -383,7 +383,7 @@ def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3) -> None:
     (Until round 5 a ``refresh=True`` mode recomputed INTO the cached buffers of refilled static inputs.  Nothing used it,
     and it was unsafe: re-filing an eagerly allocated slab under the id of the capture that refreshed it made the next EAGER
     lookup miss, replace the entry and free a buffer whose address a captured graph still wrote to - a memory access
-    fault at batch 32 when round 5 tried it (``tools/r05/fault_bisect.py``).  Removed; refilled static inputs rebuild their
+    fault at batch 32 when round 5 tried it (``profiles/r05/j_refresh_mode_memory_fault.txt``).  Removed; refilled static inputs rebuild their
     slabs inside the captured step, as ``bench.py`` does.)"""
     _require_cuda(x, "x")
     if not HOP_CACHE or k < 1 or x.dtype != torch.float32 or x.dim() != 2:
