@@ -204,6 +204,8 @@ class CrossAttention(nn.Module):
     #: ``DC_FUSED_ATTN=1`` / ``0`` force it on / off.
     fused = os.environ.get("DC_FUSED_ATTN", "auto")
     fused_min_scores = 1 << 26
+    #: rows (soft + rigid) up to which the heads' shared Linear runs once over both graphs' rows (see ``forward``)
+    joint_max_rows = int(os.environ.get("DC_ATTN_JOINT_ROWS", "16384"))
 
     #: SURVEY.md 8(f) rank 1, third part - an OPTION the reference does not have and that is OFF by default (parity): the
     #: reference's attention is unmasked across the batch (``models/model.py:16-18``: a soft node attends to the rigid
@@ -249,8 +251,20 @@ class CrossAttention(nn.Module):
         mode = str(self.fused).lower()
         use_fused = eligible and (mode in ("1", "true", "on") or (
             mode == "auto" and x_resting.size(0) * x_rigid.size(0) >= self.fused_min_scores))
+        # queries and keys of a head share ONE Linear (models/model.py:11,16): one dense block over the rows of both graphs
+        # instead of two - and one dX / dW block in backward instead of two plus an add of the two weight gradients.  Small
+        # batches (the shipped batch 4) are bound by their launch count: 2 + 4 + 4 launches fewer per step; from
+        # `joint_max_rows` rows on the copy that joins the rows costs more than the launches it saves.
+        joint = (x_resting.is_cuda and x_resting.dtype == x_rigid.dtype and x_resting.size(1) == x_rigid.size(1)
+                 and x_resting.size(0) + x_rigid.size(0) <= self.joint_max_rows)
+        xcat = torch.cat([x_resting, x_rigid], dim=0) if joint else None
+        ns = x_resting.size(0)
         for head in self.attention_heads:
-            q, k = _linear(head, x_resting), _linear(head, x_rigid)
+            if joint:
+                qk = _linear(head, xcat)
+                q, k = qk[:ns], qk[ns:]
+            else:
+                q, k = _linear(head, x_resting), _linear(head, x_rigid)
             if use_fused:
                 from .attention import attention_core
                 pooled.append(attention_core(q, k, x_rigid))
