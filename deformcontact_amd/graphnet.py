@@ -206,6 +206,8 @@ class CrossAttention(nn.Module):
     fused_min_scores = 1 << 26
     #: rows (soft + rigid) up to which the heads' shared Linear runs once over both graphs' rows (see ``forward``)
     joint_max_rows = int(os.environ.get("DC_ATTN_JOINT_ROWS", "16384"))
+    #: with the joint Linear: all heads through one dense block and batched score / pooling products (stock attention path)
+    batched_heads = os.environ.get("DC_ATTN_BATCHED_HEADS", "1") != "0"
 
     #: SURVEY.md 8(f) rank 1, third part - an OPTION the reference does not have and that is OFF by default (parity): the
     #: reference's attention is unmasked across the batch (``models/model.py:16-18``: a soft node attends to the rigid
@@ -240,11 +242,12 @@ class CrossAttention(nn.Module):
                 pooled.append(torch.cat(parts, dim=0))
         return torch.cat(pooled, dim=-1)
 
-    def forward(self, x_resting, x_rigid, segments=None):
+    def forward(self, x_resting, x_rigid, segments=None, return_list=False):
         if self.per_graph_mask:
             if segments is None or segments[0] is None or segments[1] is None:
                 raise ValueError("per_graph_mask needs the layouts of both batches (data.Batch.segments())")
-            return self._per_graph(x_resting, x_rigid, segments[0], segments[1])
+            out = self._per_graph(x_resting, x_rigid, segments[0], segments[1])
+            return list(out.split(x_rigid.size(1), dim=-1)) if return_list else out
         pooled = []
         eligible = (x_resting.is_cuda and x_resting.dtype == torch.float32
                     and x_resting.size(1) % 16 == 0 and x_rigid.size(0) > 0)
@@ -255,11 +258,27 @@ class CrossAttention(nn.Module):
         # instead of two - and one dX / dW block in backward instead of two plus an add of the two weight gradients.  Small
         # batches (the shipped batch 4) are bound by their launch count: 2 + 4 + 4 launches fewer per step; from
         # `joint_max_rows` rows on the copy that joins the rows costs more than the launches it saves.
-        joint = (x_resting.is_cuda and x_resting.dtype == x_rigid.dtype and x_resting.size(1) == x_rigid.size(1)
+        joint = (x_resting.is_cuda and x_resting.dtype == torch.float32 and x_rigid.dtype == torch.float32
+                 and x_resting.dim() == 2 and x_resting.size(1) == x_rigid.size(1)
                  and x_resting.size(0) + x_rigid.size(0) <= self.joint_max_rows)
         xcat = torch.cat([x_resting, x_rigid], dim=0) if joint else None
         ns = x_resting.size(0)
-        for head in self.attention_heads:
+        heads = list(self.attention_heads)
+        if (joint and not use_fused and self.batched_heads and len(heads) > 1 and x_rigid.size(0) > 0
+                and all(h.weight.shape == heads[0].weight.shape and (h.bias is None) == (heads[0].bias is None) for h in heads)):
+            # ... and all heads at once: ONE dense block with the heads' weights stacked along the output ([N, H d]), the
+            # scores / softmax / pooling of all heads as batched products over strided views of it - the same sums per head,
+            # a third of the launches (the shipped batch 4 is bound by its launch count)
+            hn, d = len(heads), heads[0].weight.size(0)
+            w_cat = torch.cat([h.weight for h in heads], dim=0)
+            b_cat = torch.cat([h.bias for h in heads], dim=0) if heads[0].bias is not None else None
+            qk = ops.dense_linear(xcat, w_cat, b_cat)                          # [ns + nr, H d]
+            qk3 = qk.view(qk.size(0), hn, d).transpose(0, 1)                   # [H, ns + nr, d], no copy
+            p = torch.softmax(torch.bmm(qk3[:, :ns], qk3[:, ns:].transpose(1, 2)), dim=-1)
+            o = torch.bmm(p, x_rigid.unsqueeze(0).expand(hn, -1, -1))          # [H, ns, dv]
+            pooled = list(o.unbind(0))
+            return pooled if return_list else torch.cat(pooled, dim=-1)
+        for head in heads:
             if joint:
                 qk = _linear(head, xcat)
                 q, k = qk[:ns], qk[ns:]
@@ -270,6 +289,8 @@ class CrossAttention(nn.Module):
                 pooled.append(attention_core(q, k, x_rigid))
             else:
                 pooled.append(torch.softmax(q @ k.t(), dim=-1) @ x_rigid)
+        if return_list:
+            return pooled
         return torch.cat(pooled, dim=-1)
 
 
@@ -300,10 +321,11 @@ class GraphNet(ContactEncoder):
     def forward(self, graph_resting, graph_rigid):
         x_rest, x_rig = self.encode(graph_resting, graph_rigid)
         if self.multihead_attention.per_graph_mask:          # (opt-in; the reference attends across the whole batch)
-            pooled = self.multihead_attention(x_rest, x_rig, (_segments_of(graph_resting), _segments_of(graph_rigid)))
+            pooled = self.multihead_attention(x_rest, x_rig, (_segments_of(graph_resting), _segments_of(graph_rigid)),
+                                              return_list=True)
         else:
-            pooled = self.multihead_attention(x_rest, x_rig)     # always applied (reference quirk)
-        delta = self._decode(torch.cat([x_rest, pooled], dim=-1))
+            pooled = self.multihead_attention(x_rest, x_rig, return_list=True)     # always applied (reference quirk)
+        delta = self._decode(torch.cat([x_rest] + list(pooled), dim=-1))   # one concatenation for [x | head 0 | head 1 ...]
         out = graph_resting.clone()
         if self.mode == "res":
             out.pos = out.pos + delta
