@@ -26,7 +26,8 @@
 // construction): 1 no block stores, 2 no neighbour slots at all, 4 no LDS write-back / barriers between hops,
 // 8 no source-block staging, 16 no id / weight loads, 32 LDS gathers but no arithmetic, 64 block stores to a
 // contiguous 128 KiB region per workgroup and hop (is the row-strided 128-byte store pattern what costs?), 128 ids /
-// weights made up in registers instead of loaded (do the in-loop VMEM loads couple the compute to the stores?)
+// weights made up in registers instead of loaded (do the in-loop VMEM loads couple the compute to the stores?),
+// 256 row maxima formed but not published (what do the atomics cost?  ~2 us per launch, profiles/r05/o_chain_rowmax_atomics.txt)
 #ifndef DC_CHAIN_ABL
 #define DC_CHAIN_ABL 0
 #endif
@@ -90,7 +91,7 @@ __device__ __forceinline__ void store_piece(const float4 &a, __amdgpu_buffer_rsr
 
 // 8 lanes x 8 rows of per-lane maxima -> lane `sub` holds the maximum of the row of step `sub` (a transposing
 // butterfly); the slices of a row then meet in rowmax[row]: non-negative floats order like their bit patterns
-__device__ __forceinline__ void publish_rowmax(const float (&pm)[8], int sub, int steps, int row, int nn, float *rowmax) {
+__device__ __forceinline__ float rowmax_transpose(const float (&pm)[8], int sub) {
     float q[4], r[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -103,7 +104,12 @@ __device__ __forceinline__ void publish_rowmax(const float (&pm)[8], int sub, in
         r[i] = fmaxf(keep, __shfl_xor(send, 2));
     }
     const float keep = (sub & 4) ? r[1] : r[0], send = (sub & 4) ? r[0] : r[1];
-    const float rm = fmaxf(keep, __shfl_xor(send, 4));
+    return fmaxf(keep, __shfl_xor(send, 4));
+}
+
+__device__ __forceinline__ void publish_rowmax(const float (&pm)[8], int sub, int steps, int row, int nn, float *rowmax) {
+    const float rm = rowmax_transpose(pm, sub);
+    if (DC_CHAIN_ABL & 256) return;
     if (sub < steps && row < nn) atomicMax(reinterpret_cast<int *>(rowmax + row), __float_as_int(rm));
 }
 

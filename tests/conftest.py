@@ -57,7 +57,8 @@ def pytest_collection_finish(session):
         names = []
         for it in wanted:                                   # only the scenarios the selected tests read
             for name in ls.SCENARIOS:
-                tag = {"bench_two_rank_gloo": "direct_two_rank", "rccl_single": "rccl",
+                tag = {"bench_two_rank_gloo": "direct_two_rank", "bench_torchrun_gloo": "torchrun_two_rank",
+                       "rccl_single": "rccl",
                        "dp_graphed_serial": "graphed_train_step", "dp_graphed_two_streams": "graphed_train_step"}[name]
                 if tag in it.name and (not name.startswith("dp_graphed_") or name[len("dp_graphed_"):] in it.name):
                     if name not in names:

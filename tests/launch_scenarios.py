@@ -51,6 +51,41 @@ def _bench_two_rank(out):
             "describe": err, "phases": res.phases()}
 
 
+def _bench_torchrun(out):
+    """The driver's own N > 1 command form - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...` - on the one-device box (gloo, as above): bench.py finds RANK /
+    WORLD_SIZE in its environment and is a rank at once; torchrun is the parent and never touches the GPU."""
+    from deformcontact_amd.launch import LaunchResult, free_port
+    env = dict(os.environ, DC_DIST_BACKEND="gloo", DC_RANK_LOG_DIR=out, **DIAG_ENV)
+    for r in range(2):
+        try:
+            os.remove(os.path.join(out, f"rank{r}.phase"))
+        except OSError:
+            pass
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + BENCH_ARGS
+    t0 = time.time()
+    with open(os.path.join(out, "launcher.out"), "wb") as fo, open(os.path.join(out, "launcher.err"), "wb") as fe:
+        p = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc, timed_out = p.wait(timeout=170), False
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(p.pid, signal.SIGKILL)               # torchrun's own process group: the agent and its ranks
+            except OSError:
+                pass
+            p.wait()
+            rc, timed_out = 124, True
+    res = LaunchResult(rc, [None, None], timed_out, time.time() - t0, out, 2)
+    with open(os.path.join(out, "launcher.out")) as f:
+        stdout = f.read()
+    with open(os.path.join(out, "launcher.err"), errors="replace") as f:
+        err = f.read()[-6000:]
+    return {"rc": rc, "timed_out": timed_out, "wall_s": res.wall_s, "dir": out, "stdout": stdout,
+            "describe": err, "phases": res.phases()}
+
+
 def _dp_graphed(branches):
     def run(out):
         from deformcontact_amd.launch import launch_ranks
@@ -75,7 +110,8 @@ def _rccl_single(out):
             "describe": res.describe() if res.rc else "", "phases": res.phases()}
 
 
-SCENARIOS = {"bench_two_rank_gloo": _bench_two_rank, "dp_graphed_serial": _dp_graphed("serial"),
+SCENARIOS = {"bench_two_rank_gloo": _bench_two_rank, "bench_torchrun_gloo": _bench_torchrun,
+             "dp_graphed_serial": _dp_graphed("serial"),
              "dp_graphed_two_streams": _dp_graphed("two_streams"), "rccl_single": _rccl_single}
 
 

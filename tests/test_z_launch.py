@@ -121,6 +121,23 @@ def test_config3_direct_two_rank_launch_on_one_device_over_gloo():
 
 @pytest.mark.gpu
 @launch
+def test_config3_torchrun_two_rank_launch_as_the_driver_starts_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 2 ...`: ONE JSON line, from rank 0, with the whole job's figures."""
+    r = _result("bench_torchrun_gloo")
+    lines = [l for l in r["stdout"].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r["stdout"][-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    d = out["dist"]
+    assert d["world_size"] == 2 and [x["rank"] for x in d["ranks_seen"]] == [0, 1]
+    ph = r["phases"]
+    assert len(ph) == 2 and ph[0] and [p for p in ph[0] if "all-reduces" in p] == [p for p in ph[1] if "all-reduces" in p]
+
+
+@pytest.mark.gpu
+@launch
 @pytest.mark.parametrize("branches", ["serial", "two_streams"])
 def test_config3_two_rank_graphed_train_step_equals_single_process_mean_gradient(branches):
     """Two data-parallel ranks through `train.GraphedTrainStep` (forward + losses + backward replayed from one hipGraph,
