@@ -24,12 +24,11 @@ from . import _lib
 from .graph import _require_cuda, current_stream_ptr
 from .ops import _i64_array, _ptr_array
 
-import ctypes
 import os
 
 #: soft rows per block: the block's score matrix (x2 in the backward) should stay in the 256 MiB
 #: Infinity Cache between the GEMM that writes it and the row kernel / GEMM that reads it
-BLOCK_ROWS = int(os.environ.get("DC_ATTN_BLOCK", "2048"))
+BLOCK_ROWS = 2048
 
 
 def _ceil16(n: int) -> int:
@@ -100,15 +99,10 @@ def _flash_bwd_budget(dev) -> int:
 #: much the consistent delta differs (eps), and dK - the product that is sensitive to rows of dS not summing to zero -
 #: takes dS' - eps o P at load time (``dc_tag_linear_bwd_dw_h2_corr``).  ``DC_ATTN_FLASH_BWD_SINGLE=0``: two sweeps.
 FLASH_BWD_SINGLE = os.environ.get("DC_ATTN_FLASH_BWD_SINGLE", "1") != "0"
-#: one-sweep form: dQ = (dS' - eps o P) K as well (``dc_tag_linear_fwd_h2p_corr``).  What eps adds to an uncorrected dQ_i is
-#: eps_i times the attention-weighted mean of the centred keys - small next to dQ_i unless dP is nearly constant over the
-#: keys (values with a large common component: |delta_i| >> spread of dP_i.), which is exactly what post-ReLU features
-#: look like; ``DC_ATTN_CORRECT_DQ=0`` skips it (one operand stream less)
-CORRECT_DQ = os.environ.get("DC_ATTN_CORRECT_DQ", "1") != "0"
-
-#: recompute of a block's weights in the backward: exp(s - lse) in the score GEMM's epilogue (``DC_ATTN_FUSED_EXP=0``:
-#: separate ``dc_attn_exp_rows`` pass; bit-identical)
-FUSED_EXP = os.environ.get("DC_ATTN_FUSED_EXP", "1") != "0"
+#: (one-sweep form: dQ = (dS' - eps o P) K as well, ``dc_tag_linear_fwd_h2p_corr``: what eps adds to an uncorrected dQ_i is
+#: eps_i times the attention-weighted mean of the centred keys - small next to dQ_i unless dP is nearly constant over the keys,
+#: which is exactly what post-ReLU features look like.  The blocked backward recomputes a block's weights as exp(s - lse) in
+#: the score GEMM's epilogue, ``dc_tag_linear_fwd_h2p_exp``.)
 
 
 def _gemm(L, x, ldx, rows, k, img, fo, out, ldo, xmax, wmax, st, ws=None):
@@ -119,28 +113,10 @@ def _gemm(L, x, ldx, rows, k, img, fo, out, ldo, xmax, wmax, st, ws=None):
                                        ws.numel() if ws is not None else 0, st), "dc_tag_linear_fwd_h2p")
 
 
-#: The two score-shaped products whose error is AMPLIFIED downstream run on the exact 3-way bf16
-#: split (6 MFMA products, error of fp32 accumulation relative to every element): S = Q K^T feeds
-#: exp() - an absolute error e in a score is a relative error e in its weight - and dP = dO V^T is
-#: cancelled against delta in dS = P * (dP - delta).  The scaled fp16x2 form (3 products) is
-#: accurate to 2^-22 of the operand ROWS' maxima, which for un-normalised scores (the reference has
-#: no 1/sqrt(d)) showed up as 3.5e-5 in the head-weight gradients against a float64 evaluation
-#: (fp32 oracle: 1.5e-6).  ``DC_ATTN_EXACT_SCORES=0`` puts them back on the fp16x2 kernels.
-EXACT_SCORES = os.environ.get("DC_ATTN_EXACT_SCORES", "0") != "0"
-#: delta_i = sum_j P_ij dP_ij / sum_j P_ij formed inside dc_attn_ds_rows (default) instead of
-#: rowsum(dO * O): the latter leaves sum_j dS_ij ~ 3e-7 |delta_i| (the recomputed weights exp(S - lse)
-#: do not sum to exactly 1), a bias that survives into sum_j dK_j - mathematically zero - and cost
-#: 1e-5 .. 4e-5 in the shared head weights against float64 (r02 attn_diag: 1.9e-5 -> 2.2e-6).
-DELTA_IN_KERNEL = os.environ.get("DC_ATTN_DELTA_IN_KERNEL", "1") != "0"
-#: diagnostic: also O = P V and dQ = dS K on the six-product kernels (no split reduction: slow)
-EXACT_ALL = os.environ.get("DC_ATTN_EXACT_ALL", "0") == "1"
-
-
-def _gemm_exact(L, x, ldx, rows, k, w, fo, out, ldo, st):
-    """out[rows, fo] = x[rows, k] . w[fo, k]^T on the six-product bf16 split kernels."""
-    _lib.check(L.dc_tag_linear_fwd_split((ctypes.c_void_p * 1)(x), _i64_array([ldx]),
-                                         _ptr_array([w]), 1, None, 0, out, ldo, rows, k, fo, 6, st),
-               "dc_tag_linear_fwd_split")
+#: delta_i = sum_j P_ij dP_ij / sum_j P_ij is formed inside dc_attn_ds_rows / dc_attn_flash_ds, not as rowsum(dO * O): the
+#: latter leaves sum_j dS_ij ~ 3e-7 |delta_i| (the recomputed weights exp(S - lse) do not sum to exactly 1), a bias that
+#: survives into sum_j dK_j - mathematically zero - and cost 1e-5 .. 4e-5 in the shared head weights against float64
+#: (r02 attn_diag: 1.9e-5 -> 2.2e-6).
 
 
 def _splitk_ws(L, rows, k, fo, dev):
@@ -183,10 +159,9 @@ class _AttnCoreFn(torch.autograd.Function):
         ones = torch.ones(bq, dtype=torch.float32, device=dev)     # softmax weights are <= 1
         o = torch.empty((nsp, dv), dtype=torch.float32, device=dev)
         lse = torch.empty(nsp, dtype=torch.float32, device=dev)
-        flash = FLASH and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
+        flash = FLASH and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0
         s = None if flash else torch.empty((bq, nrp), dtype=torch.float32, device=dev)
         ws_o = None if flash else _splitk_ws(L, bq, nrp, dv, dev)
-        vt = vp.t().contiguous() if EXACT_ALL else None
         if flash:
             kuns = torch.empty_like(kmax)
             _lib.check(L.dc_attn_flash_prep(vtimg.data_ptr(), dv, nrp, kmax.data_ptr(), kuns.data_ptr(), st),
@@ -196,18 +171,10 @@ class _AttnCoreFn(torch.autograd.Function):
                                            lse.data_ptr(), st), "dc_attn_flash_fwd")
         for r0 in (() if flash else range(0, nsp, bq)):
             rows = min(bq, nsp - r0)
-            if EXACT_SCORES:
-                _gemm_exact(L, qp[r0:].data_ptr(), d, rows, d, kp, nrp, s.data_ptr(), nrp, st)
-            else:
-                _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, s.data_ptr(), nrp, qmax[r0:].data_ptr(),
-                      kmax, st)
+            _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, s.data_ptr(), nrp, qmax[r0:].data_ptr(), kmax, st)
             _lib.check(L.dc_attn_softmax_rows(s.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
                        "dc_attn_softmax_rows")
-            if EXACT_ALL:
-                _gemm_exact(L, s.data_ptr(), nrp, rows, nrp, vt, dv, o[r0:].data_ptr(), dv, st)
-            else:
-                _gemm(L, s.data_ptr(), nrp, rows, nrp, vtimg, dv, o[r0:].data_ptr(), dv, ones.data_ptr(), vtmax,
-                      st, ws_o)
+            _gemm(L, s.data_ptr(), nrp, rows, nrp, vtimg, dv, o[r0:].data_ptr(), dv, ones.data_ptr(), vtmax, st, ws_o)
         if need_bwd:
             ctx.save_for_backward(qp, kp, vp, o, lse, kimg, kmax, qmax, vimg, vmax, ktimg, ktmax)
         ctx.dims = (ns, nr, d, dv, bq)
@@ -223,11 +190,10 @@ class _AttnCoreFn(torch.autograd.Function):
         nsp, nrp = qp.size(0), kp.size(0)
         gop = _pad_rows(go.contiguous(), nsp)
         gomax = _rowabsmax(L, gop, st)
-        if (FLASH_BWD and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0 and not EXACT_SCORES and not EXACT_ALL
-                and DELTA_IN_KERNEL and 8 * nsp * nrp <= _flash_bwd_budget(dev)):
+        if (FLASH_BWD and d == FLASH_D and dv == FLASH_D and nrp % 32 == 0
+                and 8 * nsp * nrp <= _flash_bwd_budget(dev)):
             return _backward_flash(L, st, dev, qp, kp, gop, o, lse, kimg, kmax, qmax, gomax, vimg, vmax, ktimg, ktmax,
                                    ns, nr, d, dv)
-        delta = (gop * o).sum(dim=1)
         ones = torch.ones(bq, dtype=torch.float32, device=dev)
         gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
         gk = torch.empty((nrp, d), dtype=torch.float32, device=dev)
@@ -239,60 +205,29 @@ class _AttnCoreFn(torch.autograd.Function):
         nb_v = L.dc_tag_linear_bwd_dw_workspace_bytes(bq, dv, nrp, 1)
         scratch = torch.empty(max(nb_k, nb_v), dtype=torch.uint8, device=dev)
         ws_q = _splitk_ws(L, bq, nrp, d, dev)
-        kt = kp.t().contiguous() if EXACT_ALL else None
         for r0 in range(0, nsp, bq):
             rows = min(bq, nsp - r0)
             acc = int(r0 > 0)
-            # recompute the block's weights
-            if EXACT_SCORES:
-                _gemm_exact(L, qp[r0:].data_ptr(), d, rows, d, kp, nrp, p.data_ptr(), nrp, st)
-                _lib.check(L.dc_attn_exp_rows(p.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
-                           "dc_attn_exp_rows")
-            elif not FUSED_EXP:
-                _gemm(L, qp[r0:].data_ptr(), d, rows, d, kimg, nrp, p.data_ptr(), nrp, qmax[r0:].data_ptr(),
-                      kmax, st)
-                _lib.check(L.dc_attn_exp_rows(p.data_ptr(), nrp, rows, nr, nrp, lse[r0:].data_ptr(), st),
-                           "dc_attn_exp_rows")
-            else:
-                # scores + exp(s - lse) in the GEMM's epilogue: one pass over the 200 MB block less
-                _lib.check(L.dc_tag_linear_fwd_h2p_exp(qp[r0:].data_ptr(), d, kimg.data_ptr(), p.data_ptr(), nrp, rows,
-                                                       d, nrp, qmax[r0:].data_ptr(), kmax.data_ptr(),
-                                                       lse[r0:].data_ptr(), nr, st), "dc_tag_linear_fwd_h2p_exp")
+            # recompute the block's weights: scores + exp(s - lse) in the GEMM's epilogue
+            _lib.check(L.dc_tag_linear_fwd_h2p_exp(qp[r0:].data_ptr(), d, kimg.data_ptr(), p.data_ptr(), nrp, rows,
+                                                   d, nrp, qmax[r0:].data_ptr(), kmax.data_ptr(),
+                                                   lse[r0:].data_ptr(), nr, st), "dc_tag_linear_fwd_h2p_exp")
             # dP = dO V^T, then dS = P * (dP - delta) in place
-            if EXACT_SCORES:
-                _gemm_exact(L, gop[r0:].data_ptr(), dv, rows, dv, vp, nrp, ds.data_ptr(), nrp, st)
-            else:
-                _gemm(L, gop[r0:].data_ptr(), dv, rows, dv, vimg, nrp, ds.data_ptr(), nrp, gomax[r0:].data_ptr(),
-                      vmax, st)
+            _gemm(L, gop[r0:].data_ptr(), dv, rows, dv, vimg, nrp, ds.data_ptr(), nrp, gomax[r0:].data_ptr(), vmax, st)
             # delta formed inside the row kernel from the SAME P and dP, relative to the actual sum of the
             # recomputed weights (row sums of dS are then zero to rounding)
-            _lib.check(L.dc_attn_ds_rows(p.data_ptr(), ds.data_ptr(), nrp, rows, nrp,
-                                         None if DELTA_IN_KERNEL else delta[r0:].data_ptr(),
-                                         dsmax.data_ptr(), st), "dc_attn_ds_rows")
+            _lib.check(L.dc_attn_ds_rows(p.data_ptr(), ds.data_ptr(), nrp, rows, nrp, None, dsmax.data_ptr(), st),
+                       "dc_attn_ds_rows")
             # dQ_b = dS K
-            if EXACT_ALL:
-                _gemm_exact(L, ds.data_ptr(), nrp, rows, nrp, kt, d, gq[r0:].data_ptr(), d, st)
-            else:
-                _gemm(L, ds.data_ptr(), nrp, rows, nrp, ktimg, d, gq[r0:].data_ptr(), d, dsmax.data_ptr(), ktmax,
-                      st, ws_q)
+            _gemm(L, ds.data_ptr(), nrp, rows, nrp, ktimg, d, gq[r0:].data_ptr(), d, dsmax.data_ptr(), ktmax, st, ws_q)
             # dK += dS^T Q_b ; dV += P^T dO_b   (contraction over the block's rows: dW-shaped)
             for g_t, g_max, x_t, x_ld, x_max, out_t, fi, nb in (
                     (ds, dsmax, qp[r0:], d, qmax[r0:], gk, d, nb_k),
                     (p, ones, gop[r0:], dv, gomax[r0:], gv, dv, nb_v)):
-                if EXACT_SCORES:
-                    # the contraction runs over the block's soft rows, whose dS / P magnitudes are
-                    # heavy-tailed: the fp16x2 form scales a whole row chunk by its largest row, which
-                    # costs the small rows their relative precision (1e-5 .. 4e-5 in the head-weight
-                    # gradients against float64); the six-product bf16 split is exact per element
-                    _lib.check(L.dc_tag_linear_bwd_dw_split(
-                        g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1,
-                        _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp, 6, st),
-                        "dc_tag_linear_bwd_dw_split")
-                else:
-                    _lib.check(L.dc_tag_linear_bwd_dw_h2(
-                        g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1,
-                        _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp,
-                        g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
+                _lib.check(L.dc_tag_linear_bwd_dw_h2(
+                    g_t.data_ptr(), nrp, None, nrp, _ptr_array([x_t]), _i64_array([x_ld]), 1,
+                    _ptr_array([out_t]), 1, fi, None, acc, scratch.data_ptr(), nb, rows, fi, nrp,
+                    g_max.data_ptr(), x_max.data_ptr(), st), "dc_tag_linear_bwd_dw_h2")
         return gq[:ns], gk[:nr], gv[:nr], None
 
 
@@ -319,7 +254,7 @@ def _backward_flash(L, st, dev, qp, kp, gop, o, lse, kimg, kmax, qmax, gomax, vi
     gq = torch.empty((nsp, d), dtype=torch.float32, device=dev)
     gk = torch.empty((nrp, d), dtype=torch.float32, device=dev)
     gv = torch.empty((nrp, dv), dtype=torch.float32, device=dev)
-    if single and CORRECT_DQ:
+    if single:
         _lib.check(L.dc_tag_linear_fwd_h2p_corr(ds.data_ptr(), nrp, p.data_ptr(), eps.data_ptr(), ktimg.data_ptr(),
                                                 gq.data_ptr(), d, nsp, nrp, d, dsmax.data_ptr(), ktmax.data_ptr(), st),
                    "dc_tag_linear_fwd_h2p_corr")

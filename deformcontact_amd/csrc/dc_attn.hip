@@ -198,8 +198,7 @@ k_attn_ds_rows_reg(const float *__restrict__ p, float *__restrict__ dp, int64_t 
 using namespace dc;
 
 static inline bool attn_vec_ok(const void *a, const void *b, int64_t ld, int64_t npad) {
-    static const int reg = getenv("DC_ATTN_REG_ROWS") ? atoi(getenv("DC_ATTN_REG_ROWS")) : 1;
-    return reg && npad % 4 == 0 && ld % 4 == 0 && (((uintptr_t)a) & 15) == 0 && (!b || (((uintptr_t)b) & 15) == 0);
+    return npad % 4 == 0 && ld % 4 == 0 && (((uintptr_t)a) & 15) == 0 && (!b || (((uintptr_t)b) & 15) == 0);
 }
 
 static int attn_check(const char *what, const void *s, int64_t ld, int64_t rows, int64_t n, int64_t npad) {

@@ -431,8 +431,6 @@ static inline int env_int(const char *name, int dflt) {
 }
 
 static inline int pick_mb(int64_t rows, int64_t col_tiles) {
-    static const int forced = env_int("DC_DENSE_MB", 0);
-    if (forced == 1 || forced == 2) return forced;
     return (((rows + 127) / 128) * col_tiles >= 512) ? 2 : 1;
 }
 
@@ -440,22 +438,13 @@ static inline int pick_mb(int64_t rows, int64_t col_tiles) {
 // count is not a multiple of the 256 CUs (the rigid branch: 381 tiles of 64 rows): compare the
 // blocks-per-CU makespans, with a 12 % efficiency handicap on the small tile.
 static inline int split_mb(int64_t rows, int64_t col_tiles) {
-    static const int forced = env_int("DC_SPLIT_MB", 0);
-    if (forced == 1 || forced == 2) return forced;
     const int64_t nb2 = ((rows + 127) / 128) * col_tiles, nb1 = ((rows + 63) / 64) * col_tiles;
     const double t2 = (double)((nb2 + 255) / 256);
     const double t1 = (double)((nb1 + 255) / 256) * 0.5 * 1.12;
     return t1 < t2 ? 1 : 2;
 }
 
-static inline bool use_fast() {
-    static const int v = env_int("DC_DENSE_FAST", 1);
-    return v != 0;
-}
-
 static inline int dw_mb(int64_t Fo) {
-    static const int forced = env_int("DC_DENSE_MB_DW", 0);
-    if (forced == 1 || forced == 2) return forced;
     return Fo >= 128 ? 2 : 1;
 }
 
@@ -463,8 +452,7 @@ static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_
                     int *nchunks) {
     const int64_t BM = 64 * dw_mb(Fo);
     const int64_t tiles = ((Fo + BM - 1) / BM) * ((Fi + BN - 1) / BN) * nseg;
-    static const int target = env_int("DC_DW_BLOCKS", 512);
-    static const int maxchunks = env_int("DC_DW_MAXCHUNKS", 128);
+    constexpr int target = 512, maxchunks = 128;
     int64_t want = target / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
     if (want > maxchunks) want = maxchunks;   // keeps the slab-reduce pass short
@@ -521,8 +509,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
     DC_REQUIRE(grid < (int64_t)INT32_MAX, "dc_tag_linear_fwd: grid too large");
     const dim3 gd((unsigned)grid), bd(256);
     hipStream_t hs = (hipStream_t)stream;
-    static const int h2_tuned = env_int("DC_H2_TUNED", 1);
-    if (products == 2 && vec && h2_tuned) {
+    if (products == 2 && vec) {
         int smb = split_mb(N, ntn);
         // a long reduction with a small output (e.g. attention weights x values: [2048, 24384] x
         // [24384, 256]) has too few tiles for 256 CUs: cut the reduction, sum the partials
@@ -554,7 +541,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
         return check_launch("dc_tag_linear_fwd_split");
     DC_REQUIRE(products != 2, "dc_tag_linear_fwd_h2: needs Fi %% 16 == 0, 16-byte aligned operands, "
                               "equal leading dimensions (Fi=%lld)", (long long)Fi);
-    if (use_fast() && vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
+    if (vec && fwd_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_fwd");
     static const int trace = env_int("DC_DENSE_TRACE", 0);
     ++g_generic_dense_launches;
     if (trace)
@@ -604,7 +591,7 @@ static int dx_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
         return check_launch("dc_tag_linear_bwd_dx_split");
     DC_REQUIRE(products != 2, "dc_tag_linear_bwd_dx_h2: needs Fo %% 16 == 0, Fi %% 4 == 0 and 16-byte "
                               "aligned operands (Fi=%lld Fo=%lld)", (long long)Fi, (long long)Fo);
-    if (use_fast() && vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
+    if (vec && dx_fast_launch(p, mb, hs)) return check_launch("dc_tag_linear_bwd_dx");
     ++g_generic_dense_launches;
 #define DC_DX(MB_, V_, M_) DC_LAUNCH((k_tag_linear_bwd_dx<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (mb == 2) {
@@ -727,7 +714,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     // (the reference's shipped batch of 4 rigid spheres: 3,048 rows) used to send the whole block to the generic
     // kernel; now the first N - N % 16 rows take the fast kernels and the < 16 trailing rows go through the generic
     // one into a partial slot of their own (slot nchunks), summed with the others by the slab reduce.
-    const int64_t tail = (products || use_fast()) && vec ? N % BK : 0;
+    const int64_t tail = vec ? N % BK : 0;
     const bool ragged = tail != 0 && N > tail;
     const int nslots = p.nchunks + (ragged ? 1 : 0);
     p.bias_partial = gbias ? p.partial + (int64_t)nslots * nseg * Fo * Fi : nullptr;
@@ -775,7 +762,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     bool fast_done = products && vec && dw_split_launch(p, mb, products, hs);
     DC_REQUIRE(fast_done || products != 2, "dc_tag_linear_bwd_dw_h2: needs N %% 16 == 0, Fi %% 4 == 0, "
                "Fo %% 4 == 0 and 16-byte aligned operands (N=%lld)", (long long)N);
-    fast_done = fast_done || (use_fast() && vec && dw_fast_launch(p, mb, hs));
+    fast_done = fast_done || (vec && dw_fast_launch(p, mb, hs));
 #define DC_DW(MB_, V_, M_) DC_LAUNCH((k_tag_linear_bwd_dw<MB_, V_, M_>), gd, bd, 0, hs, p)
     if (!fast_done) ++g_generic_dense_launches;
     if (fast_done) {
@@ -1206,10 +1193,7 @@ extern "C" int dc_tag_weight_prep_zero(const float *const *ws, int nseg, int64_t
     p.nseg = nseg, p.Fo = Fo, p.Fi = Fi, p.w_rowmax = w_rowmax, p.wt_rowmax = wt_rowmax;
     p.wimg = (_Float16 *)w_image, p.wtimg = (_Float16 *)wt_image;
     p.zero = zero, p.zero_n = zero_n;
-    static const int tall_min = [] {
-        const char *v = getenv("DC_WPREP_TALL_MIN");
-        return (v && *v) ? atoi(v) : 2048;
-    }();
+    constexpr int tall_min = 2048;
     const bool tall = wt_image && Fo >= tall_min && Fo % 16 == 0;
     p.tall = tall ? 1 : 0;
     const int64_t blocks = (Fo + 3) / 4 + ((wt_image && !tall) ? (Fi + 3) / 4 : 0);

@@ -512,15 +512,10 @@ static void dispatch_bf16(const int32_t *ptr, const int32_t *other, const float 
     // measured (tools/hop_stress.py, r01): while x sits in L2 / the Infinity Cache the plain
     // half-wave kernel is as fast or faster (14.3 vs 16.3 us at the everyday shape); once x spills
     // to HBM the scalar-index row-pair kernel wins (842 vs 990 us at 2.1 M rows)
-    // DC_SPMM_BF16_KERNEL = pair | x8 overrides the size rule (experiments)
-    static const int forced = [] {
-        const char *e = getenv("DC_SPMM_BF16_KERNEL");
-        return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 2 : 0));
-    }();
     // the rule looks at what ONE hop gathers from - N rows of F values - not at the slab the block sits in (round 4: on the
     // 100k-point radius graph the slab's leading dimension made the rule pick the row-pair kernel for a 51 MB block that the
     // Infinity Cache holds: 67 vs 45 us per hop, forward 0.64 vs 0.51 ms)
-    const bool pair = forced ? forced == 1 : N * (int64_t)F * 2 > (int64_t)128 << 20;
+    const bool pair = N * (int64_t)F * 2 > (int64_t)128 << 20;
     if (x8 && F >= 256 && pair) {
         const unsigned grid = (unsigned)((N + 7) / 8);
         DC_LAUNCH((k_spmm_bf16_pair<8, OUT_F32>), dim3(grid), dim3(256), 0, stream, ptr,

@@ -271,7 +271,7 @@ class GraphIndex:
 
 #: per-graph caps of the one-launch segmented build (include/deformcontact.h DC_SEG_MAX_NODES / DC_SEG_MAX_EDGES)
 SEG_MAX_NODES, SEG_MAX_EDGES = 4096, 16384
-SEGMENTED_BUILD = os.environ.get("DC_SEGMENTED_BUILD", "1") == "1"
+SEGMENTED_BUILD = True
 def _segment_arrays(segments, num_nodes: int, num_edges: int, device):
     """Validate the layout of a batch - ``segments = (node offsets, edge offsets)``, two ascending host sequences
     of B + 1 ints as ``Batch.from_data_list`` records them - and return it as the host arrays

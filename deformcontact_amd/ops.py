@@ -194,9 +194,9 @@ DIRECT_PARAM_GRAD = True
 #: (or setting this to False) keeps everything on ``v_mfma_f32_32x32x2_f32``.
 DENSE_SPLIT_BF16 = os.environ.get("DC_DENSE_SPLIT", "1") != "0"
 
-#: bf16 MFMA products per tile in split mode: 6 = fp32-accurate (default), 3 = ~4e-6 relative,
-#: 1 = plain bf16 operands with fp32 accumulation (``DC_DENSE_PRODUCTS``).
-DENSE_PRODUCTS = int(os.environ.get("DC_DENSE_PRODUCTS", "6"))
+#: bf16 MFMA products per tile in split mode: 6 = fp32-accurate (the C-ABI also takes 3 = ~4e-6 relative and
+#: 1 = plain bf16 operands with fp32 accumulation; nothing in this package asks for them)
+DENSE_PRODUCTS = 6
 
 
 #: fp16x2 mode of the wide (Fi % 16 == 0, unconcatenated) dense blocks: two power-of-two-scaled
@@ -228,11 +228,11 @@ def hop_chain_eligible(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: i
 
 
 #: re-form gcn_norm weights from an LDS-resident degree table inside ``dc_hop_chain_f32`` (no vector-memory loads in its
-#: hop loop) instead of loading ``w``; same bits.  ``DC_HOP_CHAIN_GCN=0``: always load them.  (Round 4 kept graphs of up to
+#: hop loop) instead of loading ``w``; same bits.  False (tests): always load them.  (Round 4 kept graphs of up to
 #: 512 nodes off this form because of a rare run-to-run difference; round 5 traced that to other kernels' workgroups sharing
 #: the compute unit's LDS with a small chain workgroup and removed the condition itself - every chain workgroup now owns
 #: the whole LDS, ``dc_hopchain.hip: kChainLdsRequest`` - so the size rule is gone.)
-HOP_CHAIN_GCN = os.environ.get("DC_HOP_CHAIN_GCN", "1") != "0"
+HOP_CHAIN_GCN = True
 
 
 def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weighted: bool = True,
@@ -363,8 +363,7 @@ def _build_input_slab(g: GraphIndex, x: torch.Tensor, k: int, want_rowmax: bool,
 #: K = 0 layers (``dense_linear``: the ``lin`` of GCNConv / GATConv, the attention heads' Linear, the decoder) on the
 #: fp16x2 kernels too: no hop records their row maxima, so a ``dc_rowabsmax_f32`` pass over the input is added (8 us for
 #: [32768, 256]) and three MFMA products replace six.  From 128 input columns on, outputs a multiple of 16 wide
-#: (the 256 -> 3 output layer stays where it was).  ``DC_DENSE_H2_K0=0``: the six-product kernels.
-DENSE_H2_K0 = os.environ.get("DC_DENSE_H2_K0", "1") != "0"
+#: (the 256 -> 3 output layer stays where it was).
 
 
 def _tag_uses_h2(fi: int, k: int, fo: Optional[int] = None) -> bool:
@@ -372,7 +371,7 @@ def _tag_uses_h2(fi: int, k: int, fo: Optional[int] = None) -> bool:
     ok = (DENSE_F16X2 and DENSE_SPLIT_BF16 and DENSE_PRODUCTS == 6 and not concat and fi % 16 == 0 and wpad % 4 == 0)
     if k >= 1:
         return ok
-    return ok and DENSE_H2_K0 and fo is not None and fi >= 128 and fi % 32 == 0 and fo % 16 == 0 and fo >= 64
+    return ok and fo is not None and fi >= 128 and fi % 32 == 0 and fo % 16 == 0 and fo >= 64
 
 
 def precompute_input_hops(g: GraphIndex, x: torch.Tensor, k: int = 3) -> None:
@@ -424,8 +423,8 @@ _SLAB_TAG = "_dc_hop_slab"
 #: rows of a hop sit a power of two apart and alias in the memory channels - measured on MI355X
 #: (tools/exp/ld_pad.py, operands from beyond the Infinity Cache): F = 256 hop 20.7 -> 18.3 us, wide
 #: forward block 92.6 -> 82.3 us with 64 floats (256 B) of padding; +16 / +80 floats (rows no longer
-#: 128-byte aligned) give nothing.  ``DC_SLAB_PAD=0`` disables.
-SLAB_PAD = int(os.environ.get("DC_SLAB_PAD", "64"))
+#: 128-byte aligned) give nothing.
+SLAB_PAD = 64
 
 
 def _alloc_slab(n: int, wpad: int, dev, tag=None) -> torch.Tensor:
@@ -1170,7 +1169,7 @@ def gat_aggregate(g: GraphIndex, h, a_src, a_dst, slope: float) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # GCNConv / GATConv: aggregation + bias + ReLU as one node, row-wise passes fused (dc_gnn_epi.hip)
 # --------------------------------------------------------------------------- #
-FUSED_GNN_EPILOGUE = os.environ.get("DC_FUSED_GNN", "1") != "0"
+FUSED_GNN_EPILOGUE = True          # (False: the unfused layer composition - tests compare the two)
 
 
 def fused_gnn_ok(h: torch.Tensor) -> bool:
