@@ -185,3 +185,43 @@ def test_one_sweep_backward_when_the_values_share_a_large_common_component(monke
         sa, sb, sw = a.sum(axis=0), b.sum(axis=0), w.numpy().sum(axis=0)
         scale = np.abs(w.numpy()).sum(axis=0).max()
         assert np.abs(sa - sw).max() <= max(2 * np.abs(sb - sw).max(), 2e-6 * scale)
+
+
+@pytest.mark.parametrize("ns,nr", [(4 * 256, 4 * 114), (3 * 200 + 7, 5 * 61)])
+def test_cross_attention_host_paths_agree_with_float64(ns, nr):
+    """`graphnet.CrossAttention` on the stock-attention path (the shipped batch 4): per head and per graph / the heads' shared
+    Linear once over the rows of both graphs (`joint_max_rows`) / all heads through one dense block with batched score and
+    pooling products (`batched_heads`) - three launch structures of one function (`models/model.py:7-21`): outputs and every
+    gradient within 1e-5 of a float64 evaluation of the reference formula, scaled by the tensor's largest element."""
+    from deformcontact_amd.graphnet import CrossAttention
+    torch.manual_seed(3)
+    d, heads = 256, 2
+    att = CrossAttention(d, heads).to(DEV)
+    xs = (torch.rand(ns, d, device=DEV) * (torch.rand(ns, d, device=DEV) < 0.5)).requires_grad_(True)   # post-ReLU-like rows
+    xr = (torch.rand(nr, d, device=DEV) * (torch.rand(nr, d, device=DEV) < 0.5)).requires_grad_(True)
+    with torch.no_grad():
+        for h in att.attention_heads:
+            h.weight.mul_(0.35)                                            # scores of a few units: softmax neither flat nor one-hot
+    go = torch.randn(ns, heads * d, device=DEV)
+
+    def run(module, a, b, g):
+        out = module(a, b)
+        grads = torch.autograd.grad(out, [a, b] + list(module.parameters()), g)
+        return [out] + list(grads)
+
+    att64 = CrossAttention(d, heads).double()
+    att64.load_state_dict({k: v.detach().double().cpu() for k, v in att.state_dict().items()})
+    ref = run(att64, xs.detach().double().cpu().requires_grad_(True), xr.detach().double().cpu().requires_grad_(True),
+              go.double().cpu())
+    names = ["out", "d x_soft", "d x_rigid"] + [f"d {k}" for k, _ in att.named_parameters()]
+    results = {}
+    for label, joint, batched in (("per graph", 0, False), ("joint linear", 16384, False), ("batched heads", 16384, True)):
+        att.fused, att.joint_max_rows, att.batched_heads = "0", joint, batched
+        got = run(att, xs, xr, go)
+        results[label] = got
+        for name, r, gt in zip(names, ref, got):
+            scale = float(r.detach().abs().max())
+            err = float((gt.detach().double().cpu() - r.detach()).abs().max()) / max(scale, 1e-30)
+            assert err <= 1e-5, f"{label}: {name} is {err:.2e} of its scale from float64"
+    for name, a, b in zip(names, results["per graph"], results["batched heads"]):
+        assert float((a - b).detach().abs().max()) <= 4e-6 * float(a.detach().abs().max()), name
