@@ -973,7 +973,7 @@ def main():
             return None
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with dp.capture(g):         # (thread-local capture checks: RCCL's watchdog thread queries events meanwhile)
                 body()
             captured.append(g)
             return g

@@ -25,6 +25,18 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def capture(graph: "torch.cuda.CUDAGraph", **kw):
+    """``torch.cuda.graph(graph)`` for a step that is captured in a process that also owns a process group.
+    With the RCCL ("nccl") backend a watchdog THREAD polls the events of issued collectives (``hipEventQuery``); a
+    capture in the default ``capture_error_mode="global"`` makes that call from another thread an error (``operation
+    not permitted when stream is capturing``), the watchdog thread dies with the exception and the process aborts -
+    intermittently: it needs a poll to fall inside the ~0.1 s a step's capture takes (``tools/r05/rccl_step_probe.py``
+    hit it on the first run).  ``thread_local`` keeps the check for the capturing thread only."""
+    if "capture_error_mode" not in kw and dist.is_available() and dist.is_initialized():
+        kw["capture_error_mode"] = "thread_local"
+    return torch.cuda.graph(graph, **kw)
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every replica start from rank ``src``'s parameters and buffers."""
     if world_size(group) == 1:

@@ -163,7 +163,7 @@ class GraphedTrainStep:
             self._static = tuple(b.clone() for b in (rest, deff, rig))
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with dp.capture(graph):
                 self._out = self._fwd_bwd(*self._static)
                 if self._tail_in_graph:
                     self._tail()

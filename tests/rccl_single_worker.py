@@ -29,6 +29,24 @@ def main():
     torch.cuda.synchronize()
     assert float(bucket.flat.min()) == 3.0 and float(bucket.flat.max()) == 3.0 and float(t) == 1.25
     assert dist.get_backend() == "nccl" and bucket.flat.numel() * 4 >= 572416 * 4
+    # a hipGraph capture while the process group's watchdog thread polls the events of collectives issued just before
+    # (dp.capture: thread-local capture checks - in the default global mode that poll is an error which aborts the
+    # process, whenever it falls inside the capture: here the capture is held open long enough for several polls),
+    # with the collective itself captured and replayed
+    import time
+    for _ in range(4):
+        dist.all_reduce(bucket.flat, op=dist.ReduceOp.AVG)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with dp.capture(gr):
+        bucket.flat.mul_(2.0)
+        time.sleep(1.0)
+        dist.all_reduce(bucket.flat, op=dist.ReduceOp.AVG)
+        bucket.flat.add_(1.0)
+    gr.replay()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert float(bucket.flat.min()) == 15.0 and float(bucket.flat.max()) == 15.0      # ((3 * 2 + 1) * 2 + 1)
     dist.destroy_process_group()
     print("RCCL_OK", bucket.flat.numel())
 

@@ -2,7 +2,7 @@
 """One graph-replayed bench step as a timeline.  Input: a rocprofv3 --kernel-trace CSV of bench.py; steps are delimited by
 consecutive dc::k_adam_flat dispatches.  Prints, for a median-length step of the timed region: every kernel with its start
 offset, duration, queue, and the idle time on its queue before it; then per queue the summed kernel time and idle time, and the
-time during which NO kernel ran.   python tools/r05/timeline.py <kernel_trace.csv>"""
+time during which NO kernel ran.   python tools/r05/timeline.py <kernel_trace.csv> [longest]"""
 import csv
 import re
 import sys
@@ -25,7 +25,10 @@ def main(path):
         ks = rows[a + 1:b + 1]
         if ks:
             steps.append((rows[b][1] - rows[a][1], a, b))
-    nk = Counter(b - a for _, a, b in steps).most_common(1)[0][0]
+    counts = Counter(b - a for _, a, b in steps)
+    nk = counts.most_common(1)[0][0]
+    if len(sys.argv) > 2 and sys.argv[2] == "longest":       # the step shape with the most kernels among the frequent ones
+        nk = max(k for k, c in counts.items() if c >= 20)     # (the headline step: topology work inside)
     sel = sorted(s for s in steps if s[2] - s[1] == nk)
     wall, a, b = sel[len(sel) // 2]
     t0 = rows[a][1]
