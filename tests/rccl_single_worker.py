@@ -26,6 +26,9 @@ def main():
     t = torch.tensor([1.25], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # bench.py's max-over-ranks of the elapsed time
     dist.barrier()
+    seen = [None]
+    dist.all_gather_object(seen, {"rank": 0, "device": str(dev)})   # bench.py's `dist.ranks_seen`
+    assert seen == [{"rank": 0, "device": str(dev)}]
     torch.cuda.synchronize()
     assert float(bucket.flat.min()) == 3.0 and float(bucket.flat.max()) == 3.0 and float(t) == 1.25
     assert dist.get_backend() == "nccl" and bucket.flat.numel() * 4 >= 572416 * 4
