@@ -465,7 +465,7 @@ def backbone_extra(dev, rest, rig, backbone: str, steps: int = 20):
     torch.cuda.synchronize()
     dc_graph.clear_cache()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _capture(g):
         body()
     g.replay()
     torch.cuda.synchronize()
@@ -514,7 +514,7 @@ def full_step_b4(dev, steps: int = 20, batch: int = 4):
     run, captured = one, False
     try:
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _capture(g):
             loss_t = one()
         run, captured = g.replay, True
     except Exception as e:  # pragma: no cover
@@ -560,7 +560,7 @@ def full_forward(dev, batch: int = 32, steps: int = 10):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _capture(g):
             out = model(rest, rig)
         g.replay()
         torch.cuda.synchronize()
@@ -676,7 +676,7 @@ def radius100k(dev, reps: int = 30):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _capture(g):
             fn()
         return timeit(g.replay, r)
     t_fwd = graphed(fwd, max(reps // 3, 3))
@@ -800,6 +800,13 @@ def measure_traffic(timeout_s: float = 300.0):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def _capture(g):
+    """Every hipGraph capture of this file: `dp.capture` - thread-local capture checks once a process group exists (RCCL's
+    watchdog thread queries events while this thread captures; in the default mode that aborts the process)."""
+    from deformcontact_amd import dp
+    return dp.capture(g)
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: start the N ranks as child processes (this parent never touches
     the GPU; `deformcontact_amd.launch`), relay rank 0's JSON line, return non-zero when a rank failed or the launch
@@ -833,6 +840,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    # DC_BENCH_FORCE_DIST=1 (tests/launch_scenarios.py: bench_rccl_single): ONE rank goes through the N > 1 form of this
+    # file - RCCL process group, eager all-reduce + Adam behind the replayed graph, max-over-ranks timing, the `dist`
+    # block - because two ranks cannot share the test box's one device under RCCL
+    dist_on = world > 1 or os.environ.get("DC_BENCH_FORCE_DIST") == "1"
     from deformcontact_amd.launch import install_watchdog, phase
     if world > 1:
         install_watchdog()                 # DC_RANK_WATCHDOG_S: periodic stack dumps of a rank that is stuck
@@ -864,8 +875,14 @@ def main():
     dev_index = local_rank % max(ndev, 1)     # == local_rank on a real N-GPU node
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+            # one node: RCCL's socket bootstrap (not its data path: that is xGMI / shared memory) stays on the loopback interface
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL ("nccl") over xGMI; DC_DIST_BACKEND=gloo only exists to smoke-test the N > 1 code
         # path on a single-GPU box (several ranks sharing one device)
         backend = os.environ.get("DC_DIST_BACKEND", "nccl")
@@ -950,10 +967,15 @@ def main():
 
     def tail():
         ar_calls[0] += 1
-        if world > 1 and len(ar_events) < 4096:
+        if dist_on:
+            phase(f"collective {ar_calls[0]}")      # (a file append when DC_RANK_LOG_DIR is set, else nothing: progress markers
+                                                    # that let a slow launch be told from a stuck one)
+        if dist_on and len(ar_events) < 4096:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             bucket.all_reduce_mean()
+            if world == 1:                     # (forced one-rank form: GradBucket skips the collective at world size 1)
+                dist.all_reduce(bucket.flat, op=dist.ReduceOp.AVG)
             e1.record()
             ar_events.append((e0, e1))
         else:
@@ -962,7 +984,7 @@ def main():
             opt.step()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     captured = []
@@ -973,7 +995,7 @@ def main():
             return None
         try:
             g = torch.cuda.CUDAGraph()
-            with dp.capture(g):         # (thread-local capture checks: RCCL's watchdog thread queries events meanwhile)
+            with _capture(g):
                 body()
             captured.append(g)
             return g
@@ -996,7 +1018,7 @@ def main():
     # N > 1: the collective stays OUTSIDE the captured graph by default (the 2-rank tests cover exactly this form);
     # --graph-tail captures all-reduce + Adam with the step (RCCL collectives are capturable; falls back to eager if
     # the capture fails) - opt-in because it cannot be exercised on the one-GPU test box
-    tail_in_graph = world == 1 or bool(args.graph_tail)
+    tail_in_graph = not dist_on or bool(args.graph_tail)
 
     def make_mode(mode: str):
         """-> step(i).  serial: every step loads a new batch into the input buffers and the captured
@@ -1066,7 +1088,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         phase(f"timed: {steps} steps done (all-reduces so far {ar_calls[0]})")
-        if world > 1:
+        if dist_on:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -1127,7 +1149,7 @@ def main():
                     + ("(dc_graph_build_segmented: one launch per graph, the batch layout is host data)"
                        if args.segmented_build else "(dc_graph_build)")
                     + ", the first-layer hop slabs are computed, then fwd + bwd(synthetic "
-                    "upstream grad)" + (" + RCCL grad all-reduce" if world > 1 else "")
+                    "upstream grad)" + (" + RCCL grad all-reduce" if dist_on else "")
                     + ("" if args.no_optim else " + Adam") + "; all of it inside the timed region, one hipGraph",
             "value_cached_topology": "one fixed batch replayed, adjacency and first-layer hops built once "
                                      "outside the loop (round-1 headline definition)",
@@ -1139,7 +1161,7 @@ def main():
         },
     }
 
-    if world > 1:
+    if dist_on:
         torch.cuda.synchronize()
         us = sorted(a.elapsed_time(b) * 1e3 for a, b in ar_events[-max(args.steps, 1):])
         # which physical devices took part: every rank reports the device it ran on (UUID where the runtime exposes
@@ -1189,7 +1211,7 @@ def main():
                 fn()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture(g):
                 for _ in range(calls):
                     fn()
             g.replay()
@@ -1354,7 +1376,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     phase("result line printed" if rank == 0 else "waiting for rank 0's kernel-level measurements")
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     phase("done")

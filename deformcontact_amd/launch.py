@@ -88,6 +88,25 @@ def read_phases(log_dir: str, n: int) -> List[List[str]]:
     return out
 
 
+def read_phase_times(log_dir: str, n: int) -> List[List[tuple]]:
+    """Per rank, ``(seconds, phase name)`` of every marker it recorded, in order."""
+    out = []
+    for r in range(n):
+        rows = []
+        try:
+            with open(os.path.join(log_dir, f"rank{r}.phase")) as f:
+                for ln in f:
+                    t, _, name = ln.partition(" ")
+                    try:
+                        rows.append((float(t), name.strip()))
+                    except ValueError:
+                        pass
+        except OSError:
+            pass
+        out.append(rows)
+    return out
+
+
 class LaunchResult:
     def __init__(self, rc: int, rcs: List[Optional[int]], timed_out: bool, wall_s: float, log_dir: str, n: int):
         self.rc, self.rcs, self.timed_out, self.wall_s, self.log_dir, self.n = rc, rcs, timed_out, wall_s, log_dir, n

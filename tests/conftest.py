@@ -58,6 +58,7 @@ def pytest_collection_finish(session):
         for it in wanted:                                   # only the scenarios the selected tests read
             for name in ls.SCENARIOS:
                 tag = {"bench_two_rank_gloo": "direct_two_rank", "bench_torchrun_gloo": "torchrun_two_rank",
+                       "bench_rccl_single": "bench_over_rccl",
                        "rccl_single": "rccl",
                        "dp_graphed_serial": "graphed_train_step", "dp_graphed_two_streams": "graphed_train_step"}[name]
                 if tag in it.name and (not name.startswith("dp_graphed_") or name[len("dp_graphed_"):] in it.name):
@@ -69,7 +70,9 @@ def pytest_collection_finish(session):
         ls.run_all(names)
         if tr is not None:
             for k, v in ls.RESULTS.items():
-                tr.write_line(f"  {k}: rc={v['rc']} timed_out={v['timed_out']} {v['wall_s']:.0f}s")
+                tr.write_line(f"  {k}: rc={v['rc']} timed_out={v['timed_out']} {v['wall_s']:.0f}s"
+                              + (f" (attempt 2; the first: rc={v['first_attempt']['rc']} after "
+                                 f"{v['first_attempt']['wall_s']:.0f}s)" if v.get("attempts", 1) > 1 else ""))
 
 
 def pytest_sessionfinish(session, exitstatus):
