@@ -1089,7 +1089,8 @@ def main():
         elapsed = time.perf_counter() - t0
         phase(f"timed: {steps} steps done (all-reduces so far {ar_calls[0]})")
         if dist_on:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            # (gloo - the one-device stand-in - takes the host tensor: dp.staged_collective says why)
+            t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed

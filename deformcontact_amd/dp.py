@@ -37,13 +37,48 @@ def capture(graph: "torch.cuda.CUDAGraph", **kw):
     return torch.cuda.graph(graph, **kw)
 
 
+_HOST_STAGE = {}
+
+
+def _host_stage(t: torch.Tensor) -> torch.Tensor:
+    key = (t.numel(), t.dtype)
+    if key not in _HOST_STAGE:
+        if len(_HOST_STAGE) > 8:
+            _HOST_STAGE.clear()
+        _HOST_STAGE[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+    return _HOST_STAGE[key].view(t.shape)
+
+
+def staged_collective(fn, t: torch.Tensor, **kw) -> None:
+    """``fn(t, **kw)`` (``dist.all_reduce`` / ``dist.broadcast``) for a DEVICE tensor over a backend without device
+    support of its own worth using - gloo, the stand-in for RCCL on a one-GPU box and in the CPU tests: the tensor is
+    staged through pinned host memory on the CURRENT stream and the collective runs on the host copy.
+    ProcessGroupGloo's own path for device tensors copies on streams it takes from the high-priority pool; with two
+    processes time-sharing one device that is where round 5's (and round 4's) stalls sat - up to 15 s per 2.3 MB
+    all-reduce, once a 60 s timeout (``profiles/r05/t_launch_flakes.txt``)."""
+    if not t.is_cuda:
+        fn(t, **kw)
+        return
+    host = _host_stage(t)
+    host.copy_(t)                       # blocking: the current stream's work on `t` is done, the bytes are on the host
+    fn(host, **kw)
+    t.copy_(host)
+
+
+def _device_collectives(group=None) -> bool:
+    return dist.get_backend(group) == "nccl"
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every replica start from rank ``src``'s parameters and buffers."""
     if world_size(group) == 1:
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t, src=src, group=group)
+            if _device_collectives(group):
+                dist.broadcast(t, src=src, group=group)
+            else:
+                staged_collective(dist.broadcast, t.data, src=src, group=group)
 
 
 def flat_offsets(params, align: int = 4) -> List[int]:
@@ -148,8 +183,8 @@ class GradBucket:
             return
         if dist.get_backend(self.group) == "nccl":       # RCCL averages in the collective itself
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:                                            # gloo (CPU tests) has no AVG
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        else:                                            # gloo (one-GPU stand-in, CPU tests) has no AVG
+            staged_collective(dist.all_reduce, self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(ws)
 
 
