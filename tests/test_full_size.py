@@ -246,7 +246,7 @@ def _b16_oracles(monkeypatch):
         h.remove()
         monkeypatch.setattr(graphnet, "F", F)
         _B16.update(batches=(rest, deff, rig), state=state, masks32=shim.own, pos32=pos["pos"],
-                    loss32={k: float(v) for k, v in o32.items()},
+                    loss32={k: float(v.detach()) for k, v in o32.items()},
                     grad32={n: _np(p.grad) for n, p in ref.named_parameters()}, truth={})
 
     def float64_over(masks, tag):

@@ -1158,7 +1158,8 @@ def test_config4_radius100k_bf16_tagconv_forward_vs_float64():
     assert torch.equal(y, y_m), "node reordering must not change a single bit"
     ei_c = ei.cpu().numpy()
     deg = np.bincount(ei_c[1], minlength=n).astype(np.float64)
-    dis = np.where(deg > 0, deg ** -0.5, 0.0)
+    dis = np.zeros_like(deg)
+    dis[deg > 0] = deg[deg > 0] ** -0.5
     a = sp.csr_matrix((dis[ei_c[0]] * dis[ei_c[1]], (ei_c[1], ei_c[0])), shape=(n, n))
     xk = x.double().cpu().numpy()
     ref = np.zeros((n, f))
