@@ -53,7 +53,8 @@ def staged_collective(fn, t: torch.Tensor, **kw) -> None:
     """``fn(t, **kw)`` (``dist.all_reduce`` / ``dist.broadcast``) for a DEVICE tensor over a backend without device
     support of its own worth using - gloo, the stand-in for RCCL on a one-GPU box and in the CPU tests: the tensor is
     staged through pinned host memory on the CURRENT stream and the collective runs on the host copy.
-    ProcessGroupGloo's own path for device tensors copies on streams it takes from the high-priority pool; with two
+    ProcessGroupGloo's own path for device tensors copies on streams it takes from the high-priority pool (PyTorch 2.x
+    source: ``initializeStreamsEvents``); with two
     processes time-sharing one device that is where round 5's (and round 4's) stalls sat - up to 15 s per 2.3 MB
     all-reduce, once a 60 s timeout (``profiles/r05/t_launch_flakes.txt``)."""
     if not t.is_cuda:
