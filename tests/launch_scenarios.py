@@ -151,12 +151,22 @@ def run_all(names=None, outdir=None):
     attempt's logs stay where they are).  These are launches of whole processes on a shared box - two ranks time-sharing
     one device over gloo, RCCL bootstrapping over the box's network stack - and round 5 saw each of them stall once on
     boxes where they pass in 4 s a minute later (profiles/r05/t_launch_flakes.txt).  RESULTS[name] is the last attempt,
-    with `attempts` and, after a retry, `first_attempt` = the failed one's record."""
+    with `attempts` and, after a retry, `first_attempt` = the failed one's record.  All of it within DC_LAUNCH_BUDGET_S
+    (420 s): once that is spent nothing more is started or retried - the tests that read the missing results fail at the
+    END of the run, the parity tests in front of them are not kept waiting."""
     outdir = outdir or default_outdir()
+    t_all = time.time()
+    budget = float(os.environ.get("DC_LAUNCH_BUDGET_S", "420"))     # all scenarios together, retries included
     for name in (names or SCENARIOS):
+        if time.time() - t_all > budget:
+            # a box on which launches crawl must not keep the parity tests waiting (round 4: they never ran)
+            RESULTS[name] = {"rc": 126, "timed_out": False, "wall_s": 0.0, "dir": os.path.join(outdir, name), "stdout": "",
+                             "describe": f"not started: the launch scenarios before it used up their {budget:.0f} s",
+                             "phases": [], "attempts": 0}
+            continue
         res = _run_one(name, os.path.join(outdir, name))
         res["attempts"] = 1
-        if res["rc"] != 0 and os.environ.get("DC_LAUNCH_RETRY", "1") != "0":
+        if res["rc"] != 0 and os.environ.get("DC_LAUNCH_RETRY", "1") != "0" and time.time() - t_all <= budget:
             first = {k: v for k, v in res.items() if k != "stdout"}
             res = _run_one(name, os.path.join(outdir, name + ".attempt2"))
             res["attempts"], res["first_attempt"] = 2, first

@@ -219,3 +219,26 @@ def test_slow_launch_is_told_from_a_stuck_one(tmp_path):
     assert _slow_not_stuck(write(prog(9, 1.0) + [(300.0, "timed: warmup steps done")], prog(9, 1.0))) is None   # silent since
     assert _slow_not_stuck(write(prog(2, 15.0), prog(2, 15.0))) is None                     # too little evidence
     assert _slow_not_stuck(write([(100.0, "start")], [(100.0, "stalled (DC_TEST_STALL_RANK)")])) is None
+
+
+def test_scenarios_retry_once_and_stop_at_their_budget(tmp_path, monkeypatch):
+    """`launch_scenarios.run_all`: a failed scenario is run once more in a directory of its own; once the budget is spent
+    nothing else is started (the parity tests must not be kept waiting by a box on which launches crawl)."""
+    calls = []
+
+    def make(name, rcs, seconds=0.0):
+        def run(out):
+            calls.append((name, os.path.basename(out)))
+            time.sleep(seconds)
+            return {"rc": rcs.pop(0), "timed_out": False, "wall_s": seconds, "dir": out, "stdout": "", "describe": "", "phases": []}
+        return run
+    monkeypatch.setattr(ls, "SCENARIOS", {"a": make("a", [1, 0]), "b": make("b", [0]), "c": make("c", [1, 1], 0.3),
+                                          "d": make("d", [0])})
+    monkeypatch.setattr(ls, "RESULTS", {})
+    monkeypatch.setenv("DC_LAUNCH_BUDGET_S", "0.5")
+    r = ls.run_all(outdir=str(tmp_path))
+    assert calls == [("a", "a"), ("a", "a.attempt2"), ("b", "b"), ("c", "c"), ("c", "c.attempt2")]
+    assert r["a"]["rc"] == 0 and r["a"]["attempts"] == 2 and r["a"]["first_attempt"]["rc"] == 1
+    assert r["b"]["attempts"] == 1 and r["c"]["rc"] == 1 and r["c"]["attempts"] == 2
+    assert r["d"]["rc"] == 126 and r["d"]["attempts"] == 0 and "not started" in r["d"]["describe"]
+    assert json.load(open(tmp_path / "results.json"))["d"]["rc"] == 126
