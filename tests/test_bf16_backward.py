@@ -180,7 +180,8 @@ def test_config4_radius100k_bf16_tagconv_forward_backward_vs_float64():
     torch.cuda.synchronize()
     ei_c = ei.cpu().numpy()
     deg = np.bincount(ei_c[1], minlength=n).astype(np.float64)
-    dis = np.where(deg > 0, deg ** -0.5, 0.0)
+    dis = np.zeros_like(deg)
+    dis[deg > 0] = deg[deg > 0] ** -0.5
     a = sp.csr_matrix((dis[ei_c[0]] * dis[ei_c[1]], (ei_c[1], ei_c[0])), shape=(n, n))
     at = a.T.tocsr()
     ws = [lin.weight.detach().bfloat16().double().cpu().numpy() for lin in conv.lins]

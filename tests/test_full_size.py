@@ -266,7 +266,7 @@ def _b16_oracles(monkeypatch):
             o64["loss"].backward()
             h.remove()
             monkeypatch.setattr(graphnet, "F", F)
-            _B16["truth"][key] = dict(pos=pos["pos"], loss={k: float(v) for k, v in o64.items()}, pre=shim.pre,
+            _B16["truth"][key] = dict(pos=pos["pos"], loss={k: float(v.detach()) for k, v in o64.items()}, pre=shim.pre,
                                       grad={n: _np(p.grad) for n, p in m64.named_parameters()})
         return _B16["truth"][key]
     return _B16, float64_over

@@ -135,7 +135,8 @@ def test_c_csr_property_random_graphs():
         if ei.shape[1]:
             w = hop_c.gcn_norm(ei, n)
             deg = np.bincount(ei[1], minlength=n).astype(np.float64)
-            dis = np.where(deg > 0, deg ** -0.5, 0.0)
+            dis = np.zeros_like(deg)
+            dis[deg > 0] = deg[deg > 0] ** -0.5
             assert np.allclose(w, dis[ei[0]] * dis[ei[1]], rtol=1e-6)
 
     check()
