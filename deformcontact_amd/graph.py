@@ -118,7 +118,17 @@ class GraphIndex:
         #: (bench.py's cached-topology mode): lets ``graph_index`` reuse this entry under capture
         self._static_ok = False
         self._capture_id = capture_id(self.device)
-        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # the build's status word (a flag OR-ed in when an endpoint is out of range).  A private, cleared word costs a fill
+        # launch at the head of every new batch's build (5 us on each branch's critical path of the captured step); when
+        # nobody has asked for validation the one-launch segmented build (which only ORs) takes a word SHARED by all such
+        # graphs of the device, and `validate()` - should it be called after all - re-runs the build with a private one
+        self._status_shared = False
+        self._status = None
+        if (segments is not None and parts is None and not self_loops and not validate and not VALIDATE):
+            self._status = _shared_status(self.device)
+            self._status_shared = self._status is not None
+        if self._status is None:
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         dev, n, cap = self.device, self.num_nodes, max(self.capacity, 1)
 
         def side():
@@ -223,6 +233,12 @@ class GraphIndex:
 
     def validate(self) -> None:
         """Raise if any endpoint was outside ``[0, num_nodes)`` (synchronises)."""
+        if self._status_shared:
+            # built with the device's shared status word (nobody had asked for validation): build again, same buffers,
+            # same result, with a word of its own
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._status_shared = False
+            self.rebuild()
         if int(self._status.item()) != 0:
             self._status.zero_()
             raise IndexError(
@@ -307,6 +323,19 @@ def _layout_arrays(segments, num_nodes: int):
 
 #: DC_VALIDATE=1 graphs built under capture, waiting for their first replay (``validate_pending``)
 _PENDING_VALIDATION: list = []
+_SHARED_STATUS: dict = {}
+
+
+def _shared_status(device) -> Optional[torch.Tensor]:
+    """The device's shared status word for builds nobody validates (``GraphIndex.__init__``); allocated once, outside any
+    hipGraph capture (None while capturing before it exists: the caller then takes a private word, as before)."""
+    key = (device.type, device.index)
+    t = _SHARED_STATUS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = _SHARED_STATUS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
 
 
 def validate_pending() -> None:

@@ -131,3 +131,24 @@ def test_encoder_uses_the_segmented_build_and_matches_the_global_pipeline_bitwis
         outs.append([_np(hs), _np(hr)] + [_np(p.grad) for p in enc.parameters()])
     for a, c in zip(*outs):
         assert np.array_equal(a, c)
+
+
+def test_unvalidated_segmented_builds_share_one_status_word():
+    """A build nobody validates takes the device's shared status word (no fill launch at the head of every new batch's
+    build inside the captured step); `validate()` later on re-runs the build with a word of its own and still reports."""
+    b = _batch([(100, 500), (50, 200)])
+    n, seg = b.x.size(0), b.segments()
+    g1, g2 = GraphIndex(b.edge_index, n, segments=seg), GraphIndex(b.edge_index.clone(), n, segments=seg)
+    assert g1._status_shared and g2._status_shared and g1._status.data_ptr() == g2._status.data_ptr()
+    assert not GraphIndex(b.edge_index, n, segments=seg, validate=True)._status_shared
+    assert not GraphIndex(b.edge_index, n)._status_shared                      # the global pipeline keeps a private word
+    g1.validate()
+    assert not g1._status_shared and g1._status.data_ptr() != g2._status.data_ptr()
+    _same_arrays(g1, g2)
+    bad = b.edge_index.clone()
+    bad[1, 3] = 140
+    g3 = GraphIndex(bad, n, segments=seg)
+    assert g3._status_shared
+    g2.validate()                                                              # g3's flag sits in the shared word: not g2's
+    with pytest.raises(IndexError):
+        g3.validate()
