@@ -83,6 +83,7 @@ class ContactEncoder(nn.Module):
         key = (device.type, device.index)
         if key not in cls._side_streams:
             cls._side_streams[key] = torch.cuda.Stream(device=device)
+            ops.DW_LAST_STREAMS.add(cls._side_streams[key].cuda_stream)      # (ops.DW_LAST_STREAMS: why)
         return cls._side_streams[key]
 
     #: run both branches as ONE block-diagonal problem: one sorted adjacency over the

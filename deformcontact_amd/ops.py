@@ -471,6 +471,26 @@ def _h2_weight_prep(L, ws, k: int, fo: int, fi: int, want_t: bool, dev, st, zero
     return wmax, wimg, wt, wt_rowmax
 
 
+#: In the backward of a wide layer dW needs the masked gradient and the forward's slab only, not the transposed hop chain,
+#: so it can be issued in FRONT of chain + dX.  With both encoder branches running the same kernel sequence on two streams
+#: the two ``k_dw_h2w`` launches otherwise run side by side - two launches of one 512-thread workgroup per CU each - and take
+#: 151 us together where they take 49 + 66 us one after the other (``profiles/r05/w_step_timeline_headline_*.txt``).  Staggered:
+#: dW first everywhere EXCEPT on the streams listed here (``graphnet.ContactEncoder`` registers the side stream its rigid
+#: branch runs on).  Measured (``profiles/r05/x_dw_first.txt``): soft first 0.645 ms per step against 0.652 with both branches
+#: in the old order, 0.661 with the rigid branch first, 0.656 with both first.  Same kernels, same operands: same bits.
+DW_LAST_STREAMS: set = set()
+DW_FIRST_MODE = "unlisted"        # "unlisted" (default) | "none" | "all" | "listed" (the experiment's other arms)
+
+
+def _dw_first(dev) -> bool:
+    if DW_FIRST_MODE == "none":
+        return False
+    if DW_FIRST_MODE == "all":
+        return True
+    listed = current_stream_ptr(dev) in DW_LAST_STREAMS
+    return listed if DW_FIRST_MODE == "listed" else not listed
+
+
 class _TagConvFn(torch.autograd.Function):
     """Whole TAGConv layer (+ optional fused ReLU): K hops into one ``[N, (K+1)*Fi]`` slab, then
     ONE fp32-MFMA kernel for ``act(x W_0^T + sum_k (A^k x) W_k^T + b)`` - PyG ``tag_conv.py``
@@ -612,6 +632,41 @@ class _TagConvFn(torch.autograd.Function):
         gb = gx = None
         g_ptr, g_ld, g_rowmax = gout.data_ptr(), ldg, None
 
+        dw_done = not (need_w or need_b)
+
+        def weight_gradients():
+            nonlocal gws, gb
+            if need_w or need_b:
+                # one output block per lins[k].weight, in either layout of the dense block
+                sinks = [_grad_sink(p) for p in ctx.params] + \
+                    ([_grad_sink(ctx.bias_param)] if ctx.has_bias else [])
+                direct = (DIRECT_PARAM_GRAD and not torch.is_grad_enabled()
+                          and all(ctx.needs_input_grad[5:]) and (need_b or not ctx.has_bias)
+                          and sinks[0] is not None and all(b is sinks[0] for b in sinks))
+                if direct:
+                    outs = [p.grad for p in ctx.params]
+                    gb_out = ctx.bias_param.grad if ctx.has_bias else None
+                else:
+                    outs = [torch.empty((fo, fi), dtype=torch.float32, device=dev) for _ in range(k + 1)]
+                    gb_out = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
+                nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi_eff, fo, nseg)
+                scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                args = (g_ptr, g_ld, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
+                        _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
+                        int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo)
+                if g_rowmax is not None and n % 16 == 0:
+                    rc = L.dc_tag_linear_bwd_dw_h2(*args, g_rowmax.data_ptr(), xrowmax.data_ptr(), st)
+                elif DENSE_SPLIT_BF16:
+                    rc = L.dc_tag_linear_bwd_dw_split(*args, DENSE_PRODUCTS, st)
+                else:
+                    rc = L.dc_tag_linear_bwd_dw(*args, st)
+                _lib.check(rc, "dc_tag_linear_bwd_dw")
+                if direct:
+                    sinks[0].note_direct_write(torch.cuda.current_stream(dev))
+                else:
+                    gws = [outs[j] if ctx.needs_input_grad[5 + j] else None for j in range(k + 1)]
+                    gb = gb_out
+
         if h2 and fo % 16 == 0 and fo % 4 == 0:
             # fp16x2 path, backward in the forward's shape: gx = sum_j ((A^T)^j gm) W_j with
             # gm = g * relu' - K transposed hops on gm (which also record the row maxima), then
@@ -630,6 +685,12 @@ class _TagConvFn(torch.autograd.Function):
                                           hop_rowmax.data_ptr() if need_x else None, st),
                        "dc_tag_mask_grad")
             g_ptr, g_ld, mask_ptr = gslab.data_ptr(), gld, None
+            if need_x and _dw_first(dev):
+                # dW needs gm (block 0) and the forward's slab only - not the transposed chain: on one of the two encoder
+                # streams it goes in FRONT of chain + dX, so that the two branches' dW kernels do not run side by side
+                # (DW_LAST_STREAMS)
+                weight_gradients()
+                dw_done = True
             if need_x:
                 chained_hops(g, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
                              rowmax_has_block0=True)
@@ -657,36 +718,8 @@ class _TagConvFn(torch.autograd.Function):
                         DEBUG_TAP(f"bwd{fi}x{fo}.gslab", gslab)
                 need_x = False                               # done
 
-        if need_w or need_b:
-            # one output block per lins[k].weight, in either layout of the dense block
-            sinks = [_grad_sink(p) for p in ctx.params] + \
-                ([_grad_sink(ctx.bias_param)] if ctx.has_bias else [])
-            direct = (DIRECT_PARAM_GRAD and not torch.is_grad_enabled()
-                      and all(ctx.needs_input_grad[5:]) and (need_b or not ctx.has_bias)
-                      and sinks[0] is not None and all(b is sinks[0] for b in sinks))
-            if direct:
-                outs = [p.grad for p in ctx.params]
-                gb_out = ctx.bias_param.grad if ctx.has_bias else None
-            else:
-                outs = [torch.empty((fo, fi), dtype=torch.float32, device=dev) for _ in range(k + 1)]
-                gb_out = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
-            nbytes = L.dc_tag_linear_bwd_dw_workspace_bytes(n, fi_eff, fo, nseg)
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            args = (g_ptr, g_ld, mask_ptr, ldm, _ptr_array(xs), _i64_array(ldxs), nseg,
-                    _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
-                    int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo)
-            if g_rowmax is not None and n % 16 == 0:
-                rc = L.dc_tag_linear_bwd_dw_h2(*args, g_rowmax.data_ptr(), xrowmax.data_ptr(), st)
-            elif DENSE_SPLIT_BF16:
-                rc = L.dc_tag_linear_bwd_dw_split(*args, DENSE_PRODUCTS, st)
-            else:
-                rc = L.dc_tag_linear_bwd_dw(*args, st)
-            _lib.check(rc, "dc_tag_linear_bwd_dw")
-            if direct:
-                sinks[0].note_direct_write(torch.cuda.current_stream(dev))
-            else:
-                gws = [outs[j] if ctx.needs_input_grad[5 + j] else None for j in range(k + 1)]
-                gb = gb_out
+        if not dw_done:
+            weight_gradients()
 
         if need_x:
             gslab = _alloc_slab(n, wpad, dev)
