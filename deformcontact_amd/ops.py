@@ -471,24 +471,22 @@ def _h2_weight_prep(L, ws, k: int, fo: int, fi: int, want_t: bool, dev, st, zero
     return wmax, wimg, wt, wt_rowmax
 
 
-#: In the backward of a wide layer dW needs the masked gradient and the forward's slab only, not the transposed hop chain,
-#: so it can be issued in FRONT of chain + dX.  With both encoder branches running the same kernel sequence on two streams
-#: the two ``k_dw_h2w`` launches otherwise run side by side - two launches of one 512-thread workgroup per CU each - and take
-#: 151 us together where they take 49 + 66 us one after the other (``profiles/r05/w_step_timeline_headline_*.txt``).  Staggered:
-#: dW first everywhere EXCEPT on the streams listed here (``graphnet.ContactEncoder`` registers the side stream its rigid
-#: branch runs on).  Measured (``profiles/r05/x_dw_first.txt``): soft first 0.645 ms per step against 0.652 with both branches
-#: in the old order, 0.661 with the rigid branch first, 0.656 with both first.  Same kernels, same operands: same bits.
+#: In the backward of a wide layer dW needs the masked gradient and the forward's slab only - not the transposed hop chain,
+#: not dX - so its place in the sequence mask -> chain -> dX is free.  With both encoder branches running the same sequence
+#: on two streams the two ``k_dw_h2w`` launches run side by side - two launches of one 512-thread workgroup per CU each - and
+#: take 151 us together where they take 49 + 66 us one after the other (``profiles/r05/w_step_timeline_headline_*.txt``).
+#: Staggered: dW between chain and dX everywhere EXCEPT on the streams listed here (``graphnet.ContactEncoder`` registers the
+#: side stream its rigid branch runs on), where it stays behind dX.  Measured, three boxes (``profiles/r05/x_dw_first.txt``):
+#: 0.617 ms per step against 0.627 with both branches in the old order (dW in front of the chain on the soft branch: between
+#: -7 and +5 us depending on the box; any other combination: slower).  Same kernels, same operands: same bits.
 DW_LAST_STREAMS: set = set()
-DW_FIRST_MODE = "unlisted"        # "unlisted" (default) | "none" | "all" | "listed" (the experiment's other arms)
+#: where dW goes in a wide layer's backward, by class of the current stream ("listed" = in DW_LAST_STREAMS): "first" (in front
+#: of the transposed chain), "mid" (between chain and dX) or "last" (behind dX: the order of rounds 1 - 4 on both streams)
+DW_POSITION = {"unlisted": "mid", "listed": "last"}
 
 
-def _dw_first(dev) -> bool:
-    if DW_FIRST_MODE == "none":
-        return False
-    if DW_FIRST_MODE == "all":
-        return True
-    listed = current_stream_ptr(dev) in DW_LAST_STREAMS
-    return listed if DW_FIRST_MODE == "listed" else not listed
+def _dw_position(dev) -> str:
+    return DW_POSITION["listed" if current_stream_ptr(dev) in DW_LAST_STREAMS else "unlisted"]
 
 
 class _TagConvFn(torch.autograd.Function):
@@ -685,7 +683,8 @@ class _TagConvFn(torch.autograd.Function):
                                           hop_rowmax.data_ptr() if need_x else None, st),
                        "dc_tag_mask_grad")
             g_ptr, g_ld, mask_ptr = gslab.data_ptr(), gld, None
-            if need_x and _dw_first(dev):
+            dw_pos = _dw_position(dev)
+            if need_x and dw_pos == "first":
                 # dW needs gm (block 0) and the forward's slab only - not the transposed chain: on one of the two encoder
                 # streams it goes in FRONT of chain + dX, so that the two branches' dW kernels do not run side by side
                 # (DW_LAST_STREAMS)
@@ -694,6 +693,9 @@ class _TagConvFn(torch.autograd.Function):
             if need_x:
                 chained_hops(g, gslab, fo, k, backward=False, rowmax=hop_rowmax, transposed=True,
                              rowmax_has_block0=True)
+                if dw_pos == "mid" and not dw_done:
+                    weight_gradients()
+                    dw_done = True
                 if wt is None:                       # forward ran without needs_input_grad
                     wt = torch.empty((fi, gwid), dtype=torch.float32, device=dev)
                     wt_rowmax = torch.empty(fi, dtype=torch.float32, device=dev)

@@ -1,5 +1,5 @@
-"""`ops.DW_FIRST_MODE`: in a wide layer's backward dW is issued in front of the transposed chain + dX on every stream but the
-encoder's side stream (the two branches' dW kernels then do not run side by side).  Same kernels, same operands - every mode
+"""`ops.DW_POSITION`: in a wide layer's backward dW is issued between the transposed chain and dX on every stream but the
+encoder's side stream, where it stays behind dX (the two branches' dW kernels then do not run side by side).  Same kernels, same operands - every mode
 must give the same bits, eagerly and replayed from a hipGraph.  Reference: the encoder loops of
 /root/reference/models/model.py:69-78 (autograd orders nothing between a layer's weight and input gradients)."""
 import pytest
@@ -9,11 +9,11 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def _steps(mode: str, overlap: bool, graphed: bool, steps: int = 3):
+def _steps(mode: dict, overlap: bool, graphed: bool, steps: int = 3):
     from deformcontact_amd import dp, ops, synth
     from deformcontact_amd.graphnet import ContactEncoder
-    keep = ops.DW_FIRST_MODE
-    ops.DW_FIRST_MODE = mode
+    keep = dict(ops.DW_POSITION)
+    ops.DW_POSITION.update(mode)
     try:
         rest, _, rig = (b.to(DEV) for b in synth.make_batch(3, soft_vertices=300, sphere_resolution=8))
         gen = torch.Generator(device=DEV).manual_seed(5)
@@ -50,14 +50,15 @@ def _steps(mode: str, overlap: bool, graphed: bool, steps: int = 3):
         torch.cuda.synchronize()
         return [a.clone(), b.clone(), opt.flat_param.clone()]
     finally:
-        ops.DW_FIRST_MODE = keep
+        ops.DW_POSITION.update(keep)
 
 
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("graphed", [False, True])
 def test_config1_weight_gradient_first_or_last_is_bit_identical(overlap, graphed):
-    ref = _steps("none", overlap, graphed)
-    for mode in ("unlisted", "all"):
+    ref = _steps({"unlisted": "last", "listed": "last"}, overlap, graphed)           # the order of rounds 1 - 4
+    for mode in ({"unlisted": "mid", "listed": "last"}, {"unlisted": "first", "listed": "first"},
+                 {"unlisted": "first", "listed": "mid"}):
         for r, g in zip(ref, _steps(mode, overlap, graphed)):
             assert torch.equal(r, g), mode
 
@@ -66,7 +67,7 @@ def test_side_stream_is_registered_and_keeps_the_old_order():
     from deformcontact_amd import ops
     from deformcontact_amd.graphnet import ContactEncoder
     side = ContactEncoder._side_stream(DEV)
-    assert side.cuda_stream in ops.DW_LAST_STREAMS and ops.DW_FIRST_MODE == "unlisted"
+    assert side.cuda_stream in ops.DW_LAST_STREAMS and ops.DW_POSITION == {"unlisted": "mid", "listed": "last"}
     with torch.cuda.stream(side):
-        assert not ops._dw_first(DEV)
-    assert ops._dw_first(DEV)
+        assert ops._dw_position(DEV) == "last"
+    assert ops._dw_position(DEV) == "mid"
