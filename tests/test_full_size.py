@@ -356,7 +356,7 @@ def test_full_model_b16_through_the_flash_attention_vs_oracle(variant, monkeypat
     three_way(rel_err(pos["pos"], ctx["pos32"]), lambda: rel_err(pos["pos"], t_h["pos"]),
               lambda: rel_err(ctx["pos32"], t_o["pos"]), TOL, f"{variant}: pred.pos")
     for key in ("loss", "l1", "consistency"):
-        g, r = float(out[key]), ctx["loss32"][key]
+        g, r = float(out[key].detach()), ctx["loss32"][key]
         three_way(abs(g - r) / abs(r), lambda: abs(g - t_h["loss"][key]) / abs(t_h["loss"][key]),
                   lambda: abs(r - t_o["loss"][key]) / abs(t_o["loss"][key]), TOL, f"{variant}: {key}")
     # (2) + (3) every parameter gradient

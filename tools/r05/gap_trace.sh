@@ -8,7 +8,7 @@ mkdir -p "$R/$O"
 export TMPDIR=/tmp
 cd /tmp
 Q="--no-cpu-baseline --no-full-step --no-strict-fp32 --no-radius100k --no-pmc --no-merged --no-backbones --windows 0 --steps 100 --warmup 10"
-for m in default serial; do
+for m in ${MODES:-default serial}; do
   X=""; [ $m = serial ] && X="--serial-branches"
   timeout -s KILL 400 rocprofv3 --kernel-trace --output-format csv -d "$R/$O/trace_$m" -- python3 "$R/bench.py" $Q $X > "$R/$O/trace_$m.log" 2>&1
   f=$(ls $R/$O/trace_$m/*/*_kernel_trace.csv 2>/dev/null | head -1)
