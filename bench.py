@@ -82,6 +82,8 @@ def parse():
                     help="radius100k: only the bf16 100k-point radius-graph stress (BASELINE.json configs[4])")
     ap.add_argument("--no-merged", action="store_true",
                     help="skip the extra line with both branches merged into one block-diagonal launch set")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the extra line with the reference's own encoder wiring (plain conv(x, edge_index) calls)")
     ap.add_argument("--global-build", dest="segmented_build", action="store_false",
                     help="build the adjacencies with the 5-launch global pipeline even though the batch layout is known")
     ap.add_argument("--no-backbones", action="store_true",
@@ -955,21 +957,26 @@ def main():
     bucket.zero()
     k_hops = enc.conv_layers_resting[0].K
 
+    model_box = [enc]                                  # the module a step runs (the drop-in leg swaps the wiring, same parameters)
+
     def fwd_bwd(slot=0):
         if opt is None:
             bucket.zero()
-        a, b = enc(*slots[slot])
+        a, b = model_box[0](*slots[slot])
         torch.autograd.backward([a, b], [g_rest, g_rig])
 
     ar_events = []                                     # HIP events around the gradient all-reduce (N > 1)
 
-    ar_calls = [0]                                     # all-reduces this rank has issued (phase markers carry it)
+    ar_calls = [0, 0.0]                                # all-reduces this rank has issued (phase markers carry it), time of the last marker
 
     def tail():
         ar_calls[0] += 1
-        if dist_on:
-            phase(f"collective {ar_calls[0]}")      # (a file append when DC_RANK_LOG_DIR is set, else nothing: progress markers
-                                                    # that let a slow launch be told from a stuck one)
+        if dist_on and (ar_calls[0] <= 4 or time.monotonic() - ar_calls[1] >= 1.0):
+            # progress markers that let a slow launch be told from a stuck one (a file append when DC_RANK_LOG_DIR is set):
+            # at most one per second - on a healthy box a step takes a millisecond and a marker per step put a file open /
+            # append / close inside every timed step; on a crawling box every step still leaves one
+            ar_calls[1] = time.monotonic()
+            phase(f"collective {ar_calls[0]}")
         if dist_on and len(ar_events) < 4096:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1325,6 +1332,40 @@ def main():
                                       "dense_arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32), DC_DENSE_SPLIT=0"}
             finally:
                 ops.DENSE_SPLIT_BF16 = keep
+        if world == 1 and not args.no_dropin:
+            # the drop-in surface north_star names.  The SAME step (new batch copy + adjacency build +
+            # fwd + bwd + Adam, one hipGraph) with the encoder wired the way the reference wires it - plain
+            # `F.relu(conv(x, graph.edge_index))` + `F.dropout` calls, branch after branch on one stream
+            # (graphnet.ReferenceWiring = models/model.py:69-78), batches from `Batch.from_data_list(...).to(dev)`
+            # (train.py:36-46), same parameters - beside the headline's ContactEncoder (two streams) and the same
+            # ContactEncoder held to one stream.
+            from deformcontact_amd.graphnet import ReferenceWiring
+            wiring = ReferenceWiring([21, 25], 256)
+            wiring.conv_layers_resting, wiring.conv_layers_rigid = enc.conv_layers_resting, enc.conv_layers_rigid
+            k = max(5, args.steps)
+            try:
+                model_box[0] = wiring
+                el_w = timed(make_mode("serial"), k, 3)
+                model_box[0] = enc
+                enc.overlap_branches = False
+                el_1 = timed(make_mode("serial"), k, 3)
+            finally:
+                model_box[0] = enc
+                enc.overlap_branches = not args.serial_branches
+            out["dropin_reference_wiring"] = {
+                "value": round(edges_per_rank * k / el_w / 1e6, 3), "unit": "M edges/s",
+                "ms_per_step": round(el_w / k * 1e3, 4), "steps": k,
+                "ratio_to_headline": round((el_w / k * 1e3) / ms_per_step, 4),
+                "contact_encoder_one_stream": {"value": round(edges_per_rank * k / el_1 / 1e6, 3),
+                                               "ms_per_step": round(el_1 / k * 1e3, 4)},
+                "ratio_to_contact_encoder_one_stream": round(el_w / el_1, 4),
+                "wiring": "graphnet.ReferenceWiring: the encoder loops as /root/reference/models/model.py:69-78 writes "
+                          "them (F.relu(conv(x, graph.edge_index)), F.dropout; resting branch, then rigid branch, caller's "
+                          "stream) on Batch.from_data_list(...).to(dev) batches; the batch layout travels on the "
+                          "edge_index tensor, the ReLU is fused by nn.deferred, layer 1's output lands in layer 2's hop slab "
+                          "(TAGConv._note_consumer): the launch set of ContactEncoder (tests/test_dropin.py asserts it, and "
+                          "bit-identity); what the headline has on top is the second stream",
+            }
         if world == 1 and not args.no_merged and not merged and ops.DENSE_SPLIT_BF16 and ops.DENSE_F16X2:
             # the OTHER encoder path, same step definition: both branches as one block-diagonal problem (one merged
             # adjacency, 6 instead of 12 F=256 hop launches, grouped dense launches; DC_MERGE_BRANCHES=1).  Same bits

@@ -395,11 +395,29 @@ k_hop_chain_gcn(ChainParams p) {
 #pragma unroll
         for (int s = 0; s < 2 * STEPS; ++s) {
             const int r0 = (wid - 8) * 16 * STEPS + 8 * s;      // the rows of waves 2 (wid - 8) and 2 (wid - 8) + 1
+#ifdef DC_CHAIN_REGSTAGE
+            // diagnostic build (tools/r06/chain_variants.sh): the same bytes through registers (global_load_dwordx4 +
+            // ds_write_b128) instead of LDS-DMA - does the rare difference need the DMA path?
+            if (r0 + grp < nn)
+                *reinterpret_cast<float4 *>(smem + r0 * 128 + 16 * lane) =
+                    *reinterpret_cast<const float4 *>(src + (int64_t)(r0 + grp) * p.ld);
+#else
             if (r0 + grp < nn && !(DC_CHAIN_ABL & 8))
                 __builtin_amdgcn_global_load_lds(
                     (const void __attribute__((address_space(1))) *)(src + (int64_t)(r0 + grp) * p.ld),
                     (void __attribute__((address_space(3))) *)(smem + r0 * 128), 16, 0, 0);
+#endif
         }
+#ifdef DC_CHAIN_DMA_READBACK
+        // diagnostic build: behind its own vmcnt(0) every DMA wave reads back the last piece it brought in, before the
+        // barrier releases the other waves' reads
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        {
+            const int r_last = (wid - 8) * 16 * STEPS + 8 * (2 * STEPS - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(smem + r_last * 128 + 16 * lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
+        }
+#endif
     } else {
         if (threadIdx.x < 8)
             *reinterpret_cast<float4 *>(smem + R * 128 + 16 * threadIdx.x) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -586,7 +604,6 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
     DC_REQUIRE(src_block >= 0 && src_block + K * dir >= 0 && (int64_t)(src_block + 1) * F <= ld &&
                    (int64_t)(src_block + K * dir + 1) * F <= ld,
                "dc_hop_chain_f32: column blocks outside the slab");
-    DC_REQUIRE(ld < ((int64_t)1 << 20), "dc_hop_chain_f32: leading dimension %lld exceeds the 32-bit row offsets", (long long)ld);
     DC_REQUIRE(cap >= 0 && cap < (int64_t)1 << 29 && N < (int64_t)1 << 24,
                "dc_hop_chain_f32: adjacency of %lld edges / %lld nodes exceeds the 32-bit LDS / buffer offsets",
                (long long)cap, (long long)N);
@@ -614,6 +631,11 @@ extern "C" int dc_hop_chain_f32(const int32_t *ptr, const int32_t *other, const 
             big = dn > big ? dn : big;
         }
         if (big == 0) continue;
+        // a graph's rows are addressed through one buffer resource with 32-bit byte offsets (row * ld * 4 + column): the
+        // resource size and every store offset must stay below 2^31, or the bounds-checked stores are dropped silently
+        DC_REQUIRE(big * ld * 4 < ((int64_t)1 << 31),
+                   "dc_hop_chain_f32: a graph of %lld nodes with leading dimension %lld exceeds the 32-bit buffer offsets "
+                   "(nodes * ld * 4 must stay below 2^31)", (long long)big, (long long)ld);
         p.nseg = cnt;
         // slice width by the largest graph of the launch: 32 columns up to 1,024 nodes, 16 up to 2,048, 8 up to 4,096
         const int lpr = big <= 128 * kChainSteps ? 8 : big <= 2 * 128 * kChainSteps ? 4 : 2;

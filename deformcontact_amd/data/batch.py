@@ -38,7 +38,19 @@ class Data:
         for k, v in self.__dict__.items():
             if isinstance(v, Tensor):
                 self.__dict__[k] = fn(v)
+        self._tag_edge_layout()
         return self
+
+    def _tag_edge_layout(self, sticky: bool = False) -> None:
+        """Attach the batch layout (``Batch.segments()``) to the ``edge_index`` TENSOR: the reference hands the conv only
+        ``graph.edge_index`` (``models/model.py:71,77``: ``conv(x, graph.edge_index)``), so that is where
+        ``graph.graph_index`` looks for it (``graph.edge_layout``) when no ``segments`` are passed - the one-launch
+        segmented adjacency build and ``dc_hop_chain_f32`` are then reached by the unchanged reference wiring.  The tag
+        carries the tensor's version counter and is ignored once the tensor has been written in place (``sticky``:
+        the caller vouches for every later content, ``Batch.assume_segments``)."""
+        seg, ei = self.__dict__.get("_segments"), self.__dict__.get("edge_index")
+        if seg is not None and isinstance(ei, Tensor):
+            ei._dc_segments = (seg, None if sticky else ei._version)
 
     def clone(self):
         out = self.__class__.__new__(self.__class__)
@@ -49,6 +61,7 @@ class Data:
             # provenance of the copy's edge set (tensor it was cloned from + its version): lets train.losses
             # know, without reading device memory, that a prediction shares the rest batch's edges
             out.__dict__["_dc_cloned_edges"] = (self.edge_index, self.edge_index._version)
+        out._tag_edge_layout()
         return out
 
     def to(self, device, non_blocking: bool = False):
@@ -126,6 +139,7 @@ class Batch(Data):
         out._kinds = kinds
         # host-side layout (node / edge offsets of the graphs): survives to() / clone() as plain tuples
         out.__dict__["_segments"] = (tuple(offs), tuple(eptr.tolist()))
+        out._tag_edge_layout()
         return out
 
     def __setattr__(self, name, value):
@@ -140,6 +154,7 @@ class Batch(Data):
         """Declare that the CURRENT ``edge_index`` (e.g. a view into a static buffer that receives batches of one
         fixed layout) follows ``segments`` = an earlier ``segments()`` value."""
         self.__dict__["_segments"] = (tuple(int(v) for v in segments[0]), tuple(int(v) for v in segments[1]))
+        self._tag_edge_layout(sticky=True)
 
     def segments(self):
         """``(node offsets, edge offsets)`` of the graphs in this batch as host tuples - graph ``i`` owns nodes

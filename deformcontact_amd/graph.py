@@ -431,9 +431,24 @@ def graph_index(edge_index: torch.Tensor, num_nodes: int, *, self_loops: bool = 
     g = _cache_get(key, edge_index.device if edge_index.is_cuda else None)
     if g is not None:
         return g
+    if segments is None:
+        segments = edge_layout(edge_index)       # the layout travels on the tensor (data.Batch._tag_edge_layout)
     g = GraphIndex(edge_index, num_nodes, self_loops=self_loops, normalize=normalize, segments=segments)
     _cache_put(key, g, (edge_index,))
     return g
+
+
+def edge_layout(edge_index: torch.Tensor):
+    """The batch layout ``data.Batch`` attached to this ``edge_index`` tensor (``Batch.from_data_list`` / ``.to()`` /
+    ``.clone()`` / ``assume_segments``), or None: no tag, or the tensor has been written in place since it was tagged
+    (version counter; a tag set by ``assume_segments`` holds for whatever the buffer receives - the caller's promise)."""
+    tag = getattr(edge_index, "_dc_segments", None)
+    if tag is None:
+        return None
+    seg, version = tag
+    if version is not None and version != edge_index._version:
+        return None
+    return seg
 
 
 def _cache_get(key, device):
@@ -508,7 +523,11 @@ class NodeOrder:
             # kernels index with it unchecked (index_select / indexed assignment used to raise on a bad one)
             n = self.perm.numel()
             p64 = self.perm.long()
-            if n and (int(p64.min()) < 0 or int(p64.max()) >= n or int(torch.bincount(p64, minlength=n).max()) != 1):
+            # (the check reads three scalars back on the host: under hipGraph capture - where a read-back would invalidate
+            # the capture - a caller's permutation is taken on trust, as `morton`'s own always is)
+            capturing = self.perm.is_cuda and torch.cuda.is_current_stream_capturing()
+            if n and not capturing and (int(p64.min()) < 0 or int(p64.max()) >= n
+                                        or int(torch.bincount(p64, minlength=n).max()) != 1):
                 raise IndexError(f"NodeOrder: perm is not a permutation of 0..{n - 1}")
             inv = torch.empty_like(self.perm)
             inv[p64] = torch.arange(n, device=self.perm.device, dtype=torch.int32)

@@ -187,6 +187,28 @@ class ContactEncoder(nn.Module):
         return self.encode(graph_resting, graph_rigid)
 
 
+class ReferenceWiring(ContactEncoder):
+    """The two encoder loops written the way the reference writes them (``/root/reference/models/model.py:69-78``):
+    plain ``conv(x, graph.edge_index)`` calls, ``F.relu`` and ``F.dropout`` outside the conv, one branch after the other
+    on the caller's stream, nothing passed along but the ``edge_index`` tensor of a ``Batch.from_data_list(...).to(dev)``
+    batch (``train.py:36-46``).  Same parameters as ``ContactEncoder``.  This is what the reference's own ``GraphNet`` does
+    through ``install_as_torch_geometric()``; it exists so that ``bench.py`` and the GPU tests can run that wiring where
+    ``/root/reference`` is absent.  The layout travels on the ``edge_index`` tensor (``data.Batch._tag_edge_layout``), the
+    ReLU is fused by ``nn.deferred``, the next layer's slab is found by ``TAGConv._note_consumer``: the launches are those
+    of ``ContactEncoder`` on one stream."""
+
+    def encode(self, graph_resting, graph_rigid):
+        x_resting = graph_resting.x
+        for conv in self.conv_layers_resting:
+            x_resting = F.relu(conv(x_resting, graph_resting.edge_index))
+            x_resting = F.dropout(x_resting, p=self.dropout_rate, training=self.training)
+        x_rigid = graph_rigid.x
+        for conv in self.conv_layers_rigid:
+            x_rigid = F.relu(conv(x_rigid, graph_rigid.edge_index))
+            x_rigid = F.dropout(x_rigid, p=self.dropout_rate, training=self.training)
+        return x_resting, x_rigid
+
+
 class CrossAttention(nn.Module):
     """The reference's ``MultiHeadAttention``: per head one ``Linear(d, d)`` shared by
     queries and keys, raw rigid features as values, no 1/sqrt(d), no per-graph mask."""

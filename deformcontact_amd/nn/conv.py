@@ -16,6 +16,8 @@ No CPU path: calling a conv with CPU tensors raises.
 from __future__ import annotations
 
 import math
+import os
+import weakref
 from typing import Optional
 
 import torch
@@ -24,6 +26,17 @@ from torch import Tensor
 
 from .. import ops
 from ..graph import GraphIndex, _require_cuda, graph_index
+from .deferred import deferred
+
+#: a plain ``conv(x, edge_index)`` call returns a ``deferred.DeferredActivation``: the ``F.relu`` the reference applies
+#: right behind it (``models/model.py:71,77``) then runs fused in the layer's epilogue, and the output lands in the hop
+#: slab of the TAGConv layer that consumed it last time (``TAGConv._consumer_geom``) - the unchanged reference wiring on
+#: the same launches as ``graphnet.ContactEncoder``.  False / ``DC_DEFER_ACT=0``: the conv returns its output directly.
+DEFER_ACTIVATION = os.environ.get("DC_DEFER_ACT", "1") != "0"
+
+
+def _grad_wanted(x: Tensor, module: nn.Module) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
 
 class _Lin(nn.Module):
@@ -74,6 +87,8 @@ class TAGConv(nn.Module):
             self.bias = nn.Parameter(torch.zeros(out_channels))
         else:
             self.register_parameter("bias", None)
+        #: {activation fused?: (width, padded width) of the hop slab of the layer that consumed the last output}
+        self._consumer_geom = {}
 
     def reset_parameters(self):
         for lin in self.lins:
@@ -115,13 +130,40 @@ class TAGConv(nn.Module):
                                      out_dtype=self.bf16_out, next_k=nk)
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
+        self._note_consumer(x)
+        if DEFER_ACTIVATION and not relu and next_conv is None and out_into is None:
+            # the PyG call as the reference makes it: what follows decides (deferred.py) - F.relu runs fused
+            def run(act: bool) -> Tensor:
+                return self._mark(ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=act,
+                                               next_geom=self._consumer_geom.get(act)), act)
+            return deferred(run, x.size(0), self.out_channels, x, _grad_wanted(x, self))
         nxt = None
         if out_into is not None:
             nxt = ops.OutInto(out_into)
         elif isinstance(next_conv, TAGConv) and next_conv.in_channels == self.out_channels:
             nxt = ops.tag_slab_geometry(next_conv.in_channels, next_conv.K)[1:]
-        return ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu,
-                            next_geom=nxt)
+        return self._mark(ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu,
+                                       next_geom=nxt), relu)
+
+    # ---- the consumer of a layer's output, discovered at call time ------------------------------------------------
+    # ``models/model.py:69-78`` calls the layers one by one; nothing tells a conv who reads its output.  Every output
+    # carries a weak reference to the layer that produced it; a TAGConv that is handed such a tensor and does NOT find
+    # it sitting in block 0 of a hop slab of its own geometry tells the producer, which from its next call on
+    # allocates its output as block 0 of that slab (one step of a training loop runs with the packing copy, every later
+    # one without).  A wrong guess costs memory, never correctness: the output is a view either way.
+    def _mark(self, out: Tensor, act: bool) -> Tensor:
+        out._dc_producer = (weakref.ref(self), bool(act))
+        return out
+
+    def _note_consumer(self, x: Tensor) -> None:
+        tag = getattr(x, "_dc_producer", None)
+        if tag is None:
+            return
+        prod, act = tag[0](), tag[1]
+        if isinstance(prod, TAGConv) and prod is not self and prod.out_channels == self.in_channels:
+            geom = ops.tag_slab_geometry(self.in_channels, self.K)[1:]
+            if prod._consumer_geom.get(act) != geom:
+                prod._consumer_geom[act] = geom
 
     def extra_repr(self) -> str:
         return f"{self.in_channels}, {self.out_channels}, K={self.K}"
@@ -155,6 +197,11 @@ class GCNConv(nn.Module):
         (``models/model.py:71,77``) - with the bias - into the aggregation launch (``ops.gcn_aggregate``)."""
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
+        if DEFER_ACTIVATION and not relu and next_conv is None:
+            return deferred(lambda act: self._layer(g, x, act), x.size(0), self.out_channels, x, _grad_wanted(x, self))
+        return self._layer(g, x, relu)
+
+    def _layer(self, g: GraphIndex, x: Tensor, relu: bool) -> Tensor:
         h = self.lin(x)
         if ops.fused_gnn_ok(h):
             return ops.gcn_aggregate(g, h, self.bias, relu)
@@ -204,6 +251,12 @@ class GATConv(nn.Module):
         (``ops.gat_conv``); ``relu=True`` also fuses the encoder's ReLU (``models/model.py:71,77``)."""
         _check_inputs(x, edge_index, self.in_channels)
         g = self.graph(edge_index, x.size(0))
+        if DEFER_ACTIVATION and not relu and next_conv is None:
+            return deferred(lambda act: self._layer(g, x, act), x.size(0), self.heads * self.out_channels, x,
+                            _grad_wanted(x, self))
+        return self._layer(g, x, relu)
+
+    def _layer(self, g: GraphIndex, x: Tensor, relu: bool) -> Tensor:
         h = self.lin(x)
         if ops.fused_gnn_ok(h):
             return ops.gat_conv(g, h, self.att_src, self.att_dst, self.bias, self.negative_slope, relu)

@@ -390,3 +390,75 @@ def test_chain_workgroups_request_the_whole_lds():
     from deformcontact_amd import _lib
     assert _lib.lib().dc_hop_chain_lds_request() == 160 * 1024
     assert _lib.lib().dc_hop_chain_max_nodes() == 4096
+
+
+def test_batch_layout_travels_on_the_edge_index_tensor():
+    """The reference hands a conv nothing but `graph.edge_index` (models/model.py:71,77): the batch layout that selects
+    the one-launch adjacency build and the chain kernel is attached to that tensor by `Batch.from_data_list`, follows
+    `.to()` / `.clone()`, dies with an in-place write (version counter) or a replaced tensor, and is sticky after
+    `assume_segments` (static input buffers of a captured step)."""
+    from deformcontact_amd.graph import edge_layout
+    ds = [Data(x=torch.zeros(n, 3), edge_index=torch.tensor([[0, 1], [1, 0]]), pos=torch.zeros(n, 3)) for n in (2, 3, 4)]
+    b = Batch.from_data_list(ds)
+    seg = ((0, 2, 5, 9), (0, 2, 4, 6))
+    assert b.segments() == seg and edge_layout(b.edge_index) == seg
+    moved = b.to("cpu")
+    assert edge_layout(moved.edge_index) == seg
+    c = b.clone()
+    assert c.edge_index is not b.edge_index and edge_layout(c.edge_index) == seg
+    c.edge_index.add_(0)                                       # written in place: the tag no longer describes it
+    assert edge_layout(c.edge_index) is None and edge_layout(b.edge_index) == seg
+    c.assume_segments(seg)                                     # the caller's promise for every later content
+    c.edge_index.add_(0)
+    assert edge_layout(c.edge_index) == seg
+    b.edge_index = torch.tensor([[0, 4], [4, 0]])              # replaced (radius graph, re-meshing): no layout
+    assert b.segments() is None and edge_layout(b.edge_index) is None
+    assert edge_layout(torch.zeros(2, 3, dtype=torch.long)) is None
+
+
+def test_deferred_activation_semantics_cpu():
+    """`nn.deferred.DeferredActivation` (what a plain `conv(x, edge_index)` call returns): F.relu / torch.relu / .relu()
+    run the layer once with the activation fused and return that plain tensor; anything else runs it without and applies
+    the operation; metadata costs nothing; the value is an ordinary autograd tensor."""
+    import torch.nn.functional as F
+    from deformcontact_amd.nn.deferred import DeferredActivation, deferred
+    w = torch.randn(4, 3, requires_grad=True)
+    x = torch.randn(5, 3)
+    calls = []
+
+    def run(relu):
+        calls.append(relu)
+        y = x @ w.t()
+        return torch.relu(y) if relu else y
+    d = deferred(run, 5, 4, x, True)
+    assert isinstance(d, torch.Tensor) and isinstance(d, DeferredActivation)
+    assert (tuple(d.shape), d.size(0), d.dim(), d.dtype, d.device, d.requires_grad, len(d), d.numel()) == \
+        ((5, 4), 5, 2, torch.float32, x.device, True, 5, 20) and calls == []
+    r = F.relu(d)
+    assert type(r) is torch.Tensor and calls == [True] and torch.equal(r, torch.relu(x @ w.t()))
+    assert F.dropout(r, p=0.0, training=True) is r             # models/model.py:72: the same tensor object goes on
+    assert F.relu(d) is r and calls == [True]                  # computed once
+    for use in (lambda t: t.sum(), lambda t: t + 1, lambda t: torch.cat([t, t], -1), lambda t: t.detach(),
+                lambda t: t.data_ptr(), lambda t: t.is_contiguous(), lambda t: t[1:3], lambda t: repr(t)):
+        calls.clear()
+        use(deferred(run, 5, 4, x, True))
+        assert calls == [False], use
+    for act in (torch.relu, lambda t: t.relu(), lambda t: F.relu(t, inplace=True), lambda t: t.relu_()):
+        calls.clear()
+        assert type(act(deferred(run, 5, 4, x, True))) is torch.Tensor and calls == [True]
+    deferred(run, 5, 4, x, True).relu().sum().backward()
+    assert w.grad is not None and float(w.grad.abs().sum()) > 0
+    with pytest.raises(RuntimeError):                          # the two autograd entry points that do not dispatch
+        torch.autograd.backward([deferred(run, 5, 4, x, True)], [torch.ones(5, 4)])
+    deferred(run, 5, 4, x, True).backward(torch.ones(5, 4))    # Tensor.backward does
+
+
+def test_plain_conv_call_checks_its_inputs_at_the_call_site():
+    """Deferral postpones the launches, not the errors: CPU tensors / wrong shapes raise from `conv(x, edge_index)` itself."""
+    conv = dc.nn.TAGConv(3, 8)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(RuntimeError, match="HIP device"):
+        conv(torch.zeros(2, 3), ei)
+    for cls in (dc.nn.GCNConv, dc.nn.GATConv):
+        with pytest.raises(RuntimeError, match="HIP device"):
+            cls(3, 8)(torch.zeros(2, 3), ei)

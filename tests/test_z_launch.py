@@ -48,9 +48,20 @@ def _result(name):
         # loopback, two processes on one GPU): a launch (both attempts) that was progressing in step when its DEADLINE came is a slow box,
         # not a failure of the N > 1 code - anything else (a dead rank, a stuck rank, ranks out of step) still fails
         slow = _slow_not_stuck(r)
-        if slow is not None:
-            pytest.skip(f"{name}: box too slow for the two-ranks-on-one-device smoke - {slow}")
+        if slow is not None and os.environ.get("DC_ALLOW_SLOW_LAUNCH", "1") != "0":
+            # reported as an expected FAILURE (xfailed in the summary), never as a pass or a plain skip;
+            # DC_ALLOW_SLOW_LAUNCH=0 makes it a hard failure
+            pytest.xfail(f"{name}: box too slow for the two-ranks-on-one-device smoke - {slow}")
     assert r["rc"] == 0, f"{name}: rc={r['rc']} timed_out={r['timed_out']} after {r['wall_s']:.0f}s\n{r['describe'][-6000:]}"
+    if r.get("attempts", 1) > 1:
+        # a launch that only passed on its second attempt is not silently green: a warning in the session
+        # summary with the first attempt's record, a hard failure under DC_LAUNCH_STRICT=1
+        first = r.get("first_attempt", {})
+        msg = (f"{name}: passed only on attempt {r['attempts']}; first attempt rc={first.get('rc')} "
+               f"timed_out={first.get('timed_out')} after {first.get('wall_s', 0):.0f}s - {str(first.get('describe'))[-600:]}")
+        assert os.environ.get("DC_LAUNCH_STRICT", "0") != "1", msg
+        import warnings
+        warnings.warn(msg)
     return r
 
 

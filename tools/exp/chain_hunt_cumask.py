@@ -70,7 +70,7 @@ def main():
     torch.manual_seed(100)
     init = {k: v.detach().clone() for k, v in load_model(EVERYDAY_NETWORK).to(dev).state_dict().items()}
     torch.cuda.synchronize()
-    bad = 0
+    bad = nans = 0
     with torch.cuda.stream(main_s):
         base = run(init, dev)
         for rep in range(reps):
@@ -78,9 +78,16 @@ def main():
             for s in range(STEPS):
                 if not torch.equal(cur[s], base[s]):
                     bad += 1
-                    print(f"rep {rep} step {s}: gradient bucket differs", flush=True)
+                    # (round 6: with a -DDC_CHAIN_POISON build a NaN here = LDS read before its data had landed)
+                    n_nan = int(torch.isnan(cur[s]).sum())
+                    nans += n_nan > 0
+                    d = (cur[s] - base[s]).abs()
+                    print(f"rep {rep} step {s}: gradient bucket differs ({int((d > 0).sum())} elements, max |d| "
+                          f"{float(d[~torch.isnan(d)].max()) if (~torch.isnan(d)).any() else float('nan'):.3e}, NaNs {n_nan})",
+                          flush=True)
                     break
-    print(f"HUNT_CUMASK={MODE}: {bad} of {reps} repetitions differ from the first", flush=True)
+    print(f"HUNT_CUMASK={MODE}: {bad} of {reps} repetitions differ from the first ({nans} of them with NaNs; "
+          f"base has NaNs: {any(bool(torch.isnan(b).any()) for b in base)})", flush=True)
 
 
 if __name__ == "__main__":
