@@ -82,6 +82,10 @@ def parse():
                     help="radius100k: only the bf16 100k-point radius-graph stress (BASELINE.json configs[4])")
     ap.add_argument("--no-merged", action="store_true",
                     help="skip the extra line with both branches merged into one block-diagonal launch set")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="time the headline loop, print its line and stop (the child pass of roofline.kernel_only_us)")
+    ap.add_argument("--no-kernel-trace", action="store_true",
+                    help="skip the rocprofv3 --kernel-trace child pass that measures roofline.kernel_only_us")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the extra line with the reference's own encoder wiring (plain conv(x, edge_index) calls)")
     ap.add_argument("--global-build", dest="segmented_build", action="store_false",
@@ -802,6 +806,51 @@ def measure_traffic(timeout_s: float = 300.0):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def measure_kernel_only(batch: int, timeout_s: float = 300.0):
+    """`roofline.kernel_only_us`: per-kernel average durations of the headline step from a `rocprofv3 --kernel-trace
+    --stats` child pass over THIS file (`--headline-only --serial-branches`: both encoder branches on one stream, so that
+    no kernel shares the chip with another one - the regime a per-kernel roofline fraction is defined in), started before
+    this process initialises the GPU.  -> ({kernel name: {"calls", "avg_us"}} | None, note).  The stats table is kept as
+    `gpurun_out/bench_kernel_stats.csv` when that directory exists (copy it to profiles/)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_ROOT") \
+            or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "skipped: this process is itself being profiled"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="dc_kt_", dir="/tmp")
+    try:
+        cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.abspath(__file__), "--headline-only", "--serial-branches", "--batch", str(batch), "--settle", "20",
+               "--steps", "30", "--warmup", "3", "--windows", "0", "--no-pmc", "--no-kernel-trace"]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=timeout_s)
+        if r.returncode != 0:
+            return None, f"rocprofv3 --kernel-trace failed (rc {r.returncode}): " + r.stderr.decode(errors="replace")[-300:]
+        files = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
+        if not files:
+            return None, "no kernel_stats.csv in the child pass's output"
+        res = {}
+        for row in csv.DictReader(open(files[0])):
+            name = row["Name"].replace("void ", "").split("(")[0]
+            if name.startswith("dc::"):
+                res[name] = {"calls": int(row["Calls"]), "avg_us": round(float(row["AverageNs"]) / 1e3, 2)}
+        keep = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(keep):
+            shutil.copy(files[0], os.path.join(keep, "bench_kernel_stats.csv"))
+        return res, ("rocprofv3 --kernel-trace --stats child pass of `bench.py --headline-only --serial-branches` (one "
+                     "stream: no kernel shares the chip with another), graph-replayed headline steps, kernel-only averages")
+    except Exception as e:  # pragma: no cover
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def _capture(g):
     """Every hipGraph capture of this file: `dp.capture` - thread-local capture checks once a process group exists (RCCL's
     watchdog thread queries events while this thread captures; in the default mode that aborts the process)."""
@@ -859,8 +908,11 @@ def main():
         time.sleep(3600)
     phase("start")
     traffic, traffic_note = None, "not measured at N > 1"
+    kernel_only, kernel_only_note = None, "not measured"
     if world == 1:
         traffic, traffic_note = (None, "--no-pmc") if args.no_pmc else measure_traffic()
+        if not (args.no_kernel_trace or args.headline_only or args.workload != "everyday"):
+            kernel_only, kernel_only_note = measure_kernel_only(args.batch)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in deformcontact_amd)")
     if args.workload == "radius100k":
@@ -1119,6 +1171,16 @@ def main():
     window_ms = [round(ms_per_step, 4)]
     for _ in range(max(args.windows, 0)):
         window_ms.append(round(timed(serial_step, args.steps, 0) / args.steps * 1e3, 4))
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps({"metric": "M edges/sec fwd+bwd, everyday-deform batch=32 per GPU (encoder hot path)",
+                              "value": round(value, 3), "unit": "M edges/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": warmup, "ms_per_step": round(ms_per_step, 4), "headline_only": True,
+                              "two_stream_branches": not args.serial_branches}), flush=True)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # ---- secondary: the per-batch topology work left out of the loop (round-1 headline definition) ----
     elapsed_c = timed(make_mode("cached"), args.steps, warmup)
     graph_used = len(captured) >= 2             # both modes really replay a captured graph
@@ -1261,6 +1323,32 @@ def main():
         achieved = comp_bytes / tot_ms / 1e6                     # GB/s of per-hop compulsory bytes
         # what a fused 3-hop launch itself has to move: the source block in once, three blocks out, the adjacency once
         fused_min = sum(2 * (e_ * 8 + n_ * (4 * 4 * f + 4)) for n_, e_ in ((n_s, e_s), (n_r, e_r)))
+        # ---- what `frac` is: the bytes a launch MOVES - the PMC counters' traffic when this run
+        # measured it, else the fused launch's minimum (source block in once, three blocks out, adjacency once) - over the
+        # kernel-only average duration of a rocprofv3 --kernel-trace pass, over 8 TB/s.  The per-hop-compulsory figure of
+        # rounds 2 - 5 (bytes the three hop units WOULD move hop by hop / graph-replay time) is kept under its own name.
+        work_equiv = achieved
+        hop_ko = {k: v for k, v in (kernel_only or {}).items() if "k_hop_chain" in k or "k_spmm_wave" in k}
+        ko_calls = sum(v["calls"] for v in hop_ko.values())
+        ko_avg_us = sum(v["calls"] * v["avg_us"] for v in hop_ko.values()) / ko_calls if ko_calls else None
+        if chained:
+            moved = float(traffic) if traffic is not None else fused_min / nlaunch
+            moved_src = ("PMC counters of this run (FETCH_SIZE x 2 + WRITE_SIZE, per launch)" if traffic is not None else
+                         "fused launch's minimum: source block in once, 3 blocks out, adjacency once")
+        else:
+            moved = float(traffic) if traffic is not None else comp_bytes / nlaunch
+            moved_src = "PMC counters of this run" if traffic is not None else "per-hop compulsory bytes"
+        t_us = ko_avg_us if ko_avg_us is not None else tot_ms / nlaunch * 1e3
+        achieved = moved / t_us / 1e3                               # GB/s
+        per_kernel = {}
+        if chained and hop_ko:
+            for tag, n_, e_ in (("soft", n_s, e_s), ("rigid", n_r, e_r)):
+                steps_ = (n_ // args.batch + 127) // 128
+                hit = [(k, v) for k, v in hop_ko.items() if k.endswith(f"k_hop_chain_gcn<{steps_}>")]
+                if hit:
+                    mb = e_ * 8 + n_ * (4 * 4 * f + 4)
+                    per_kernel[hit[0][0]] = {"branch": tag, "kernel_only_us": hit[0][1]["avg_us"], "min_bytes_per_launch": mb,
+                                             "frac_of_min_bytes": round(mb / hit[0][1]["avg_us"] / 1e3 / HBM_PEAK_GBS, 4)}
         out["roofline"] = {
             "bound": "hbm",
             "kernel": ("dc::k_hop_chain_gcn<8> / <6> (dc_hop_chain_f32: the 3 F=256 hops of a chain + row maxima as ONE "
@@ -1271,38 +1359,39 @@ def main():
              (": ONE launch for both branches over the merged adjacency)" if merged else ")")),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
-            "bytes_model": "compulsory bytes PER HOP, E*8 + N*(2*4F + 4) (each index / weight once, each feature row in "
-                           "once and out once; SURVEY.md 8(d) strict lower bound; N, E = real nodes / edges of the "
-                           "batch), times the hops a launch performs" +
-                           (" (3 per dc_hop_chain_f32 launch: the unit SURVEY.md 8(d) prices is the edge-hop)" if chained else ""),
+            "frac_definition": "frac = bytes a launch MOVES (moved_bytes_per_launch: " + moved_src + ") / kernel-only average "
+                               "duration (" + ("kernel_only_avg_launch_us" if ko_avg_us is not None else
+                                               "NOT measured in this run - avg_launch_us, HIP events with launch gaps, used instead") +
+                               ") / 8 TB/s; frac_work_equivalent_per_hop_compulsory = per-hop compulsory bytes of the hop units "
+                               "a launch performs (SURVEY.md 8(d) strict lower bound x 3 hops) / avg_launch_us / 8 TB/s - the "
+                               "`frac` of rounds 2 - 5: it credits the fused launch with bytes it never moves",
+            "moved_bytes_per_launch": int(moved), "moved_bytes_source": moved_src,
+            "kernel_only_avg_launch_us": round(ko_avg_us, 2) if ko_avg_us is not None else None,
+            "kernel_only_us": hop_ko or None, "kernel_only_source": kernel_only_note,
+            "per_kernel": per_kernel or None,
             "launches_per_step": nlaunch, "hops_per_launch": nhops // nlaunch,
-            "compulsory_bytes_per_launch": int(comp_bytes / nlaunch),
             "avg_launch_us": round(tot_ms / nlaunch * 1e3, 2),
             "avg_us_per_hop": round(tot_ms / nhops * 1e3, 2),
+            "frac_live_hip_events": round(moved / (tot_ms / nlaunch * 1e3) / 1e3 / HBM_PEAK_GBS, 4),
+            "frac_work_equivalent_per_hop_compulsory": round(work_equiv / HBM_PEAK_GBS, 4),
+            "work_equivalent_GBps": round(work_equiv, 1),
+            "compulsory_bytes_per_launch": int(comp_bytes / nlaunch),
+            "bytes_model_work_equivalent": "compulsory bytes PER HOP, E*8 + N*(2*4F + 4) (each index / weight once, each feature "
+                                           "row in once and out once; SURVEY.md 8(d) strict lower bound), times the hops a launch performs",
             "frac_of_measured_copy_peak_6290GBps": round(achieved / 6290.0, 4),
-            "l2_served_algorithmic_GBps": round(gath_bytes / tot_ms / 1e6, 1),
-            "l2_served_algorithmic_bytes_per_launch": int(gath_bytes / nlaunch),
-            "l2_served_note": "SURVEY.md 8(d) gather model (every neighbour row counted per edge); the chain kernel serves "
-                              "these reads from LDS, the per-hop kernel from L2 - NOT an HBM fraction either way",
-            "measured": f"the {nlaunch} launches that perform the {nhops} F=256 hops of a step, in step order on step-shaped "
-                        "slabs (forward chain and transposed chain" + (" over the merged adjacency" if merged else "s of both branches") +
+            "l2_lds_served": {"GBps": round(gath_bytes / tot_ms / 1e6, 1), "bytes_per_launch": int(gath_bytes / nlaunch),
+                              "note": "SURVEY.md 8(d) gather model (every neighbour row counted per edge) / avg_launch_us; the "
+                                      "chain kernel serves these reads from LDS, the per-hop kernel from L2 - NOT an HBM fraction"},
+            "measured": f"avg_launch_us: the {nlaunch} launches that perform the {nhops} F=256 hops of a step, in step order on "
+                        "step-shaped slabs (forward chain and transposed chain" + (" over the merged adjacency" if merged else "s of both branches") +
                         "), replayed from a hipGraph as the step is (no host launch cost), HIP events on the launch "
-                        "stream, launch gaps included",
+                        "stream, launch gaps included; kernel_only_*: see kernel_only_source",
             "cases_isolated": per_case,
             "cases_isolated_kernel": "dc::k_spmm_wave<4,8,true>, ONE hop per launch (ops.hop), the same launch back to back",
         }
         if chained:
-            # the fused launch against what IT must move (1 block in + 3 out per chain): the honest HBM fraction of the
-            # kernel that ships; `frac` above stays on the per-hop model so that rounds compare
             out["roofline"]["fused_chain_min_bytes_per_launch"] = int(fused_min / nlaunch)
-            out["roofline"]["fused_chain_min_GBps"] = round(fused_min / tot_ms / 1e6, 1)
-            out["roofline"]["fused_chain_min_frac"] = round(fused_min / tot_ms / 1e6 / HBM_PEAK_GBS, 4)
-            # `frac` credits a fused launch with the per-hop bytes it AVOIDS (algorithmic bytes of the 3 hop units
-            # it performs / its time): a figure of merit against the roofline, not the HBM utilisation - that one is here
-            out["roofline"]["frac_of_moved_bytes"] = out["roofline"]["fused_chain_min_frac"]
-            out["roofline"]["frac_definition"] = ("frac = algorithmic (per-hop compulsory) bytes of the hop units a launch "
-                                                  "performs / launch time / 8 TB/s; frac_of_moved_bytes = the bytes the fused "
-                                                  "launch itself must move (1 block in, 3 out, adjacency once) / time / 8 TB/s")
+            out["roofline"]["counter_over_min_traffic_ratio"] = round(traffic / (fused_min / nlaunch), 3) if traffic else None
             # and the same hops hop by hop (the r01-r03 kernel), same slabs, same method
             keep_chain = ops.HOP_CHAIN
             ops.HOP_CHAIN = False
@@ -1319,6 +1408,19 @@ def main():
             out["roofline_mfma"] = dense_roofline_grouped(dev, parts, args.kernel_reps // 4 or 1)
         else:
             out["roofline_mfma"] = dense_roofline(dev, n_s, n_r, args.kernel_reps // 4 or 1, graphs=(gs, gr))
+        if kernel_only:
+            ko = {k: v for k, v in kernel_only.items() if "k_fwd_h2d" in k or "k_dw_h2w" in k or "k_fwd_h2w" in k}
+            # the six layer-2 launches of a (one-stream) step: forward + dX of each branch on k_fwd_h2d, dW on k_dw_h2w
+            calls = sum(v["calls"] for v in ko.values())
+            if ko and calls:
+                per_step = calls / 6.0                     # steps the child pass traced (6 such launches per step)
+                t6 = sum(v["calls"] * v["avg_us"] for v in ko.values()) / per_step
+                fl = out["roofline_mfma"].get("algorithmic_flop_per_step_l2")
+                out["roofline_mfma"]["kernel_only_us"] = ko
+                out["roofline_mfma"]["kernel_only_us_per_6_launches"] = round(t6, 1)
+                if fl:
+                    out["roofline_mfma"]["frac_kernel_only"] = round(3 * fl / t6 / 1e6 / 2500.0, 4)
+                out["roofline_mfma"]["kernel_only_source"] = kernel_only_note
         if world == 1 and not args.no_strict_fp32:
             # auditable line: the headline step with every dense block on the fp32 matrix cores
             # (v_mfma_f32_32x32x2_f32, exact fp32 products) instead of the split fp16 / bf16 forms
@@ -1343,9 +1445,18 @@ def main():
             wiring = ReferenceWiring([21, 25], 256)
             wiring.conv_layers_resting, wiring.conv_layers_rigid = enc.conv_layers_resting, enc.conv_layers_rigid
             k = max(5, args.steps)
+            from deformcontact_amd.nn import conv as conv_mod
+            el_w2 = None
             try:
                 model_box[0] = wiring
                 el_w = timed(make_mode("serial"), k, 3)
+                if not args.serial_branches:
+                    # opt-in nn.conv.BRANCH_STREAMS: the wiring's two loops on two HIP streams (contract: conv.py)
+                    conv_mod.BRANCH_STREAMS = True
+                    try:
+                        el_w2 = timed(make_mode("serial"), k, 3)
+                    finally:
+                        conv_mod.BRANCH_STREAMS = False
                 model_box[0] = enc
                 enc.overlap_branches = False
                 el_1 = timed(make_mode("serial"), k, 3)
@@ -1359,6 +1470,13 @@ def main():
                 "contact_encoder_one_stream": {"value": round(edges_per_rank * k / el_1 / 1e6, 3),
                                                "ms_per_step": round(el_1 / k * 1e3, 4)},
                 "ratio_to_contact_encoder_one_stream": round(el_w / el_1, 4),
+                "branch_streams_opt_in": None if el_w2 is None else {
+                    "value": round(edges_per_rank * k / el_w2 / 1e6, 3), "ms_per_step": round(el_w2 / k * 1e3, 4),
+                    "ratio_to_headline": round((el_w2 / k * 1e3) / ms_per_step, 4),
+                    "note": "nn.conv.BRANCH_STREAMS = True (DC_BRANCH_STREAMS=1; off by default): the same wiring, the rigid "
+                            "loop's launches on a side stream that waits for the start of the pass - needs every branch's "
+                            "inputs complete when the pass's first conv is called (true of a model whose forward receives its "
+                            "graphs as arguments)"},
                 "wiring": "graphnet.ReferenceWiring: the encoder loops as /root/reference/models/model.py:69-78 writes "
                           "them (F.relu(conv(x, graph.edge_index)), F.dropout; resting branch, then rigid branch, caller's "
                           "stream) on Batch.from_data_list(...).to(dev) batches; the batch layout travels on the "

@@ -35,6 +35,58 @@ from .deferred import deferred
 DEFER_ACTIVATION = os.environ.get("DC_DEFER_ACT", "1") != "0"
 
 
+#: OPT-IN (``DC_BRANCH_STREAMS=1`` or ``nn.conv.BRANCH_STREAMS = True``; default off): run the independent branches of a
+#: forward pass written with plain conv calls - the resting loop and the rigid loop of ``models/model.py:69-78`` - on two HIP
+#: streams, as ``graphnet.ContactEncoder`` does.  A conv whose input carries no producer tag starts a branch: the first
+#: branch of a pass stays on the caller's stream, every further one runs on a side stream that waits only for the point at
+#: which the pass began (an event recorded at the pass's first conv call), and the caller's stream waits for the side stream
+#: behind every layer launched there, so whatever the caller enqueues later (the cross-attention) sees the results; autograd
+#: replays the structure in backward.  CONTRACT, which is why this is opt-in: the inputs of EVERY branch (features and
+#: ``edge_index`` of both graphs) must be complete on the caller's stream when the first conv of the pass is called - true of
+#: a model whose ``forward`` receives its graphs as arguments, as the reference's does.  A pass ends when a branch's first
+#: layer is called again.
+BRANCH_STREAMS = os.environ.get("DC_BRANCH_STREAMS", "0") == "1"
+_PASS = {}            # device index -> {"roots": set of module ids, "event", "main": stream handle, "count"}
+
+
+def _branch_stream(module: nn.Module, x: Tensor):
+    """The side stream this plain conv call's layer runs on, or None (the caller's stream).  See ``BRANCH_STREAMS``."""
+    if not BRANCH_STREAMS:
+        return None
+    side = getattr(x, "_dc_branch", None)
+    if side is not None:
+        return side                                            # a later layer of a side branch follows its input
+    if getattr(x, "_dc_producer", None) is not None or x.grad_fn is not None:
+        return None                                            # not a graph input: ordinary stream semantics
+    from ..graphnet import ContactEncoder
+    dev = x.device
+    main = torch.cuda.current_stream(dev)
+    st = _PASS.get(dev.index)
+    if st is None or id(module) in st["roots"] or st["main"] != main.cuda_stream:
+        st = _PASS[dev.index] = {"roots": set(), "event": torch.cuda.Event(), "main": main.cuda_stream, "count": 0}
+        st["event"].record(main)                               # the pass begins: every branch's inputs exist (contract)
+    st["roots"].add(id(module))
+    st["count"] += 1
+    if st["count"] == 1:
+        return None
+    side = ContactEncoder._side_stream(dev)
+    side.wait_event(st["event"])
+    return side
+
+
+def _on_branch(side, fn):
+    """``fn()`` on ``side`` (None: here); the caller's stream then waits for it and the result remembers its stream."""
+    if side is None:
+        return fn()
+    main = torch.cuda.current_stream(side.device)
+    with torch.cuda.stream(side):
+        out = fn()
+    main.wait_stream(side)
+    out.record_stream(main)
+    out._dc_branch = side
+    return out
+
+
 def _grad_wanted(x: Tensor, module: nn.Module) -> bool:
     return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
@@ -129,14 +181,22 @@ class TAGConv(nn.Module):
             return ops.tag_conv_bf16(g, x, [lin.weight for lin in self.lins], self.bias, relu=relu,
                                      out_dtype=self.bf16_out, next_k=nk)
         _check_inputs(x, edge_index, self.in_channels)
-        g = self.graph(edge_index, x.size(0))
         self._note_consumer(x)
         if DEFER_ACTIVATION and not relu and next_conv is None and out_into is None:
             # the PyG call as the reference makes it: what follows decides (deferred.py) - F.relu runs fused
+            side = _branch_stream(self, x)
+
             def run(act: bool) -> Tensor:
-                return self._mark(ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=act,
-                                               next_geom=self._consumer_geom.get(act)), act)
-            return deferred(run, x.size(0), self.out_channels, x, _grad_wanted(x, self))
+                def layer():
+                    g = self.graph(edge_index, x.size(0))
+                    return self._mark(ops.tag_conv(g, x, [lin.weight for lin in self.lins], self.bias, relu=act,
+                                                   next_geom=self._consumer_geom.get(act)), act)
+                return _on_branch(side, layer)
+            if side is None:
+                self.graph(edge_index, x.size(0))        # the adjacency build starts at the call, as without deferral
+            return deferred(run, x.size(0), self.out_channels, x, _grad_wanted(x, self)).guard(
+                x, edge_index, *self.parameters())
+        g = self.graph(edge_index, x.size(0))
         nxt = None
         if out_into is not None:
             nxt = ops.OutInto(out_into)
@@ -196,9 +256,11 @@ class GCNConv(nn.Module):
         """``conv(x, edge_index)`` as PyG; ``relu=True`` fuses the ReLU the reference applies right after
         (``models/model.py:71,77``) - with the bias - into the aggregation launch (``ops.gcn_aggregate``)."""
         _check_inputs(x, edge_index, self.in_channels)
-        g = self.graph(edge_index, x.size(0))
         if DEFER_ACTIVATION and not relu and next_conv is None:
-            return deferred(lambda act: self._layer(g, x, act), x.size(0), self.out_channels, x, _grad_wanted(x, self))
+            side = _branch_stream(self, x)
+            return deferred(lambda act: _on_branch(side, lambda: self._layer(self.graph(edge_index, x.size(0)), x, act)),
+                            x.size(0), self.out_channels, x, _grad_wanted(x, self)).guard(x, edge_index, *self.parameters())
+        g = self.graph(edge_index, x.size(0))
         return self._layer(g, x, relu)
 
     def _layer(self, g: GraphIndex, x: Tensor, relu: bool) -> Tensor:
@@ -250,10 +312,12 @@ class GATConv(nn.Module):
         """``conv(x, edge_index)`` as PyG; everything behind ``lin`` is one autograd node on fused kernels
         (``ops.gat_conv``); ``relu=True`` also fuses the encoder's ReLU (``models/model.py:71,77``)."""
         _check_inputs(x, edge_index, self.in_channels)
-        g = self.graph(edge_index, x.size(0))
         if DEFER_ACTIVATION and not relu and next_conv is None:
-            return deferred(lambda act: self._layer(g, x, act), x.size(0), self.heads * self.out_channels, x,
-                            _grad_wanted(x, self))
+            side = _branch_stream(self, x)
+            return deferred(lambda act: _on_branch(side, lambda: self._layer(self.graph(edge_index, x.size(0)), x, act)),
+                            x.size(0), self.heads * self.out_channels, x, _grad_wanted(x, self)).guard(
+                                x, edge_index, *self.parameters())
+        g = self.graph(edge_index, x.size(0))
         return self._layer(g, x, relu)
 
     def _layer(self, g: GraphIndex, x: Tensor, relu: bool) -> Tensor:

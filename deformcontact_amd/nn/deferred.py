@@ -49,11 +49,26 @@ class DeferredActivation(torch.Tensor):
         self._dc_run = run
         self._dc_values = {}
         self._dc_requires_grad = bool(requires_grad)
+        self._dc_inputs = ()
+
+    def guard(self, *tensors) -> "DeferredActivation":
+        """Remember the version counters of the layer's inputs (features, ``edge_index``, parameters): an in-place write to
+        one of them between the conv call and the first use of its result would silently change what an eager conv had
+        already computed - ``value`` raises instead."""
+        self._dc_inputs = tuple((t, t._version) for t in tensors if isinstance(t, torch.Tensor))
+        return self
 
     def value(self, relu: bool = False) -> torch.Tensor:
         """The conv's output (``relu``: with the activation fused), computed on first request."""
         v = self._dc_values.get(relu)
         if v is None:
+            for t, ver in self._dc_inputs:
+                if t._version != ver:
+                    raise RuntimeError(
+                        "deformcontact_amd: an input of conv(x, edge_index) (features, edge_index or a parameter) was "
+                        "modified in place between the call and the first use of its result; the call is deferred by one "
+                        "use so that a following F.relu runs fused (nn/deferred.py) - use the result before modifying its "
+                        "inputs, or set deformcontact_amd.nn.conv.DEFER_ACTIVATION = False")
             v = self._dc_values[relu] = self._dc_run(relu)
         return v
 

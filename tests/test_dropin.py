@@ -36,8 +36,12 @@ def _step(enc, rest, rig, ga, gb, bucket):
     return a.detach().clone(), b.detach().clone(), bucket.flat.clone()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_config1_b32_reference_wiring_is_bit_identical_to_contact_encoder_and_launches_the_same_kernels(overlap):
+@pytest.mark.parametrize("overlap,branch_streams", [(False, False), (True, False), (True, True)])
+def test_config1_b32_reference_wiring_is_bit_identical_to_contact_encoder_and_launches_the_same_kernels(
+        overlap, branch_streams, monkeypatch):
+    """`branch_streams`: the opt-in `nn.conv.BRANCH_STREAMS` (the wiring's two loops on two HIP streams)."""
+    from deformcontact_amd.nn import conv as conv_mod
+    monkeypatch.setattr(conv_mod, "BRANCH_STREAMS", branch_streams)
     rest, rig = _batches(32)
     torch.manual_seed(0)
     enc = ContactEncoder([21, 25], 256).to(DEV)
@@ -50,16 +54,23 @@ def test_config1_b32_reference_wiring_is_bit_identical_to_contact_encoder_and_la
     clear_cache()
     want = _step(enc, rest, rig, ga, gb, bucket)
     got = None
-    for it in range(3):            # step 0 of the wiring still packs layer 1's output (consumer not yet known)
+    for it in range(8 if branch_streams else 3):   # step 0 of the wiring still packs layer 1's output (consumer not yet known)
         clear_cache()
         if it == 2:
             torch.cuda.synchronize()
             _lib.kernel_trace(True)
+        elif it == 3:
+            _lib.kernel_trace(False)
         got = _step(ref, rest, rig, ga, gb, bucket)
         for w, g, name in zip(want, got, ("out_rest", "out_rigid", "gradient bucket")):
             assert torch.equal(w, g), f"step {it}: {name} differs from ContactEncoder"
     _lib.kernel_trace(False)
     tr = _lib.kernel_trace_counts()
+    if branch_streams:
+        assert rig.x is not None and getattr(got[1], "_dc_branch", None) is None      # (clones carry no stream tag)
+        a, b = ref(rest, rig)
+        assert getattr(b, "_dc_branch", None) is not None and getattr(a, "_dc_branch", None) is None
+        torch.cuda.synchronize()
     names = {k.split("<")[0] for k in tr}
     for k, v in {"k_build_segment": 2, "k_hop_chain_gcn<8>": 2, "k_hop_chain_gcn<6>": 2, "k_fwd_h2d<true>": 2,
                  "k_fwd_h2d<false>": 2, "k_dw_h2w<false>": 2}.items():

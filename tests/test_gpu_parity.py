@@ -822,29 +822,29 @@ def test_input_hop_slab_cache_hits_and_invalidates():
     real = ops._build_input_slab
     ops._build_input_slab = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     try:
-        y0 = conv(x, ei)
-        y1 = conv(x, ei)
+        y0 = conv(x, ei).clone()         # (.clone(): a plain conv call is deferred until its first use, nn/deferred.py)
+        y1 = conv(x, ei).clone()
         assert len(calls) == 1 and torch.equal(y0, y1)
         old, ops.HOP_CACHE = ops.HOP_CACHE, False
-        y_nc = conv(x, ei)
+        y_nc = conv(x, ei).clone()
         ops.HOP_CACHE = old
         assert len(calls) == 2 and torch.equal(y_nc, y0)
         x[3, 2] += 1.0                                        # in-place edit bumps the version
-        y2 = conv(x, ei)
+        y2 = conv(x, ei).clone()
         assert len(calls) == 3 and not torch.equal(y2, y0)
         ei2 = ei.clone()
         ei2[0, 5] = (ei2[0, 5] + 1) % n
-        y3 = conv(x, ei2)
+        y3 = conv(x, ei2).clone()
         assert len(calls) == 4
         xg = x.clone().requires_grad_(True)
         conv(xg, ei).sum().backward()                         # needs grad: no cache, grads flow
-        conv(xg, ei)
+        conv(xg, ei).clone()
         assert len(calls) == 6 and xg.grad is not None
         # ahead-of-time (what the loader does): the layer then builds nothing
         x4 = x.clone()
         ops.precompute_input_hops(graph_index(ei, n), x4, 3)
         assert len(calls) == 7
-        y4 = conv(x4, ei)
+        y4 = conv(x4, ei).clone()
         assert len(calls) == 7 and torch.equal(y4, y2)
     finally:
         ops._build_input_slab = real

@@ -451,6 +451,11 @@ def test_deferred_activation_semantics_cpu():
     with pytest.raises(RuntimeError):                          # the two autograd entry points that do not dispatch
         torch.autograd.backward([deferred(run, 5, 4, x, True)], [torch.ones(5, 4)])
     deferred(run, 5, 4, x, True).backward(torch.ones(5, 4))    # Tensor.backward does
+    # an input written in place between the call and the first use: an eager conv would have used the old content
+    late = deferred(run, 5, 4, x, True).guard(x, w)
+    x.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        late.sum()
 
 
 def test_plain_conv_call_checks_its_inputs_at_the_call_site():
