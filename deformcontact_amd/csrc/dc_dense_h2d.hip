@@ -229,6 +229,28 @@ k_fwd_h2d(FwdParams p) {
     };
     // the 6 MFMAs of one 32-column block of a k-step: products h2*h1, h1*h2, h1*h1 (smallest terms first, as k_fwd_h2),
     // each on both row blocks - every accumulator sees its terms in k_fwd_h2w's order
+#ifdef DC_H2D_ABL_MFMA16
+    // timing-only ablation (wrong results by construction; tools/r06/mfma16_abl.sh): every 32x32x16 MFMA replaced by two
+    // 16x16x32 ones on the same operand registers and two quarters of the same accumulator - same FLOPs, same LDS reads, same
+    // VALU: does the chip hold a higher clock on the smaller MFMA shape inside THIS loop (MI355X_MICROARCH.md, DVFS item 7)?
+    hd_f32x4 acc4[2][4][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc4[mb][nb][q] = hd_f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma_nb = [&](const hd_f16x8 (&fa)[2][2], int nb) {
+        constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                acc4[mb][nb][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mb][pa[t]], fb[nb][pb[t]], acc4[mb][nb][t], 0, 0, 0);
+                acc4[mb][nb][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mb][pb[t]], fb[nb][pa[t]], acc4[mb][nb][3], 0, 0, 0);
+            }
+    };
+#else
     auto mma_nb = [&](const hd_f16x8 (&fa)[2][2], int nb) {
         constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};
 #pragma unroll
@@ -237,6 +259,7 @@ k_fwd_h2d(FwdParams p) {
             for (int mb = 0; mb < 2; ++mb)
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mb][pa[t]], fb[nb][pb[t]], acc[mb][nb], 0, 0, 0);
     };
+#endif
     __syncthreads();                                   // P: stages 0 and 1 of both operands have landed
     rawA(0, 0);
 #pragma unroll
@@ -304,7 +327,11 @@ k_fwd_h2d(FwdParams p) {
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
+#ifdef DC_H2D_ABL_MFMA16
+                so[(wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + wn * 128 + nb * 32 + c] = acc4[mb][nb][r >> 2][r & 3];
+#else
                 so[(wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + wn * 128 + nb * 32 + c] = acc[mb][nb][r];
+#endif
     store_rows();
 }
 
