@@ -1480,7 +1480,7 @@ def main():
                 "wiring": "graphnet.ReferenceWiring: the encoder loops as /root/reference/models/model.py:69-78 writes "
                           "them (F.relu(conv(x, graph.edge_index)), F.dropout; resting branch, then rigid branch, caller's "
                           "stream) on Batch.from_data_list(...).to(dev) batches; the batch layout travels on the "
-                          "edge_index tensor, the ReLU is fused by nn.deferred, layer 1's output lands in layer 2's hop slab "
+                          "edge_index tensor, the ReLU is fused by deferred, layer 1's output lands in layer 2's hop slab "
                           "(TAGConv._note_consumer): the launch set of ContactEncoder (tests/test_dropin.py asserts it, and "
                           "bit-identity); what the headline has on top is the second stream",
             }

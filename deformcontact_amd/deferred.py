@@ -67,9 +67,24 @@ class DeferredActivation(torch.Tensor):
                     raise RuntimeError(
                         "deformcontact_amd: an input of conv(x, edge_index) (features, edge_index or a parameter) was "
                         "modified in place between the call and the first use of its result; the call is deferred by one "
-                        "use so that a following F.relu runs fused (nn/deferred.py) - use the result before modifying its "
+                        "use so that a following F.relu runs fused (deferred.py) - use the result before modifying its "
                         "inputs, or set deformcontact_amd.nn.conv.DEFER_ACTIVATION = False")
-            v = self._dc_values[relu] = self._dc_run(relu)
+            if self._dc_requires_grad and not torch.is_grad_enabled():
+                # The call was made with gradients wanted, its first use is not recording.  Inside the forward of a custom
+                # autograd Function (`Function.apply` does not dispatch on its arguments, so it took the wrapper for a
+                # tensor that needs no gradient) the graph would be cut silently: raise.  Under a plain `torch.no_grad()`
+                # block the layer runs WITH recording, as the eager call would have done at the call site.
+                if _inside_function_apply():
+                    raise RuntimeError(
+                        "deformcontact_amd: the result of conv(x, edge_index) was passed straight to a custom "
+                        "torch.autograd.Function; the call is deferred by one use (deferred.py) and Function.apply does not "
+                        "dispatch on its arguments, so the gradient would not reach the conv - pass `y.value()` (or any "
+                        "tensor computed from y), or set deformcontact_amd.nn.conv.DEFER_ACTIVATION = False")
+                with torch.enable_grad():
+                    v = self._dc_run(relu)
+            else:
+                v = self._dc_run(relu)
+            self._dc_values[relu] = v
         return v
 
     @classmethod
@@ -92,6 +107,24 @@ class DeferredActivation(torch.Tensor):
 
     def __repr__(self):                                          # (printing a tensor is a use of its value)
         return repr(self.value(False))
+
+
+def _inside_function_apply() -> bool:
+    import sys
+    f = sys._getframe(2)
+    while f is not None:
+        code = f.f_code
+        if code.co_name == "apply" and code.co_filename.replace("\\", "/").endswith("torch/autograd/function.py"):
+            return True
+        f = f.f_back
+    return False
+
+
+def resolve(x):
+    """``x`` itself, or - for the deferred result of a plain conv call - its value without activation: what every entry
+    point of this package that hands tensors to a custom autograd Function calls first (``Function.apply`` does not
+    dispatch on its arguments)."""
+    return x.value(False) if isinstance(x, DeferredActivation) else x
 
 
 def _unwrap(a):

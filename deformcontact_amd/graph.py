@@ -575,6 +575,8 @@ class NodeOrder:
         """``x[idx]``; differentiable: ``idx`` and ``idx_back`` are inverse permutations, so the gradient of a row
         gather is the row gather of the gradient by the opposite permutation (``index_select``'s backward,
         without its ``index_add_`` atomics)."""
+        from .deferred import resolve
+        x = resolve(x)                     # (a plain conv call's deferred result: Function.apply does not dispatch)
         if torch.is_grad_enabled() and x.requires_grad:
             return _PermuteRows.apply(x, idx, idx_back)
         return self._gather_raw(x, idx)

@@ -194,7 +194,7 @@ class ReferenceWiring(ContactEncoder):
     batch (``train.py:36-46``).  Same parameters as ``ContactEncoder``.  This is what the reference's own ``GraphNet`` does
     through ``install_as_torch_geometric()``; it exists so that ``bench.py`` and the GPU tests can run that wiring where
     ``/root/reference`` is absent.  The layout travels on the ``edge_index`` tensor (``data.Batch._tag_edge_layout``), the
-    ReLU is fused by ``nn.deferred``, the next layer's slab is found by ``TAGConv._note_consumer``: the launches are those
+    ReLU is fused by ``deferred``, the next layer's slab is found by ``TAGConv._note_consumer``: the launches are those
     of ``ContactEncoder`` on one stream."""
 
     def encode(self, graph_resting, graph_rigid):

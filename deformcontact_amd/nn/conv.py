@@ -26,7 +26,7 @@ from torch import Tensor
 
 from .. import ops
 from ..graph import GraphIndex, _require_cuda, graph_index
-from .deferred import deferred
+from ..deferred import deferred, resolve
 
 #: a plain ``conv(x, edge_index)`` call returns a ``deferred.DeferredActivation``: the ``F.relu`` the reference applies
 #: right behind it (``models/model.py:71,77``) then runs fused in the layer's epilogue, and the output lands in the hop
@@ -112,6 +112,7 @@ class _Lin(nn.Module):
             self.weight.uniform_(-a, a)
 
     def forward(self, x: Tensor) -> Tensor:
+        x = resolve(x)
         if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
             return ops.dense_linear(x, self.weight, six_products=self.six_products)      # the library's MFMA dense block
         return torch.nn.functional.linear(x, self.weight)
@@ -168,6 +169,7 @@ class TAGConv(nn.Module):
         TAGConv that consumes this output) lets the output be written straight into that
         layer's hop slab; ``out_into`` (a ``[N, out]`` row-major view the caller owns, e.g. this
         branch's rows of a merged slab - ``ops.merged_slab_part``) receives the output instead."""
+        x = resolve(x)                 # (the deferred result of another plain conv call: its value, see deferred.py)
         if x.dtype == torch.bfloat16:
             # bf16-STORED features (BASELINE.json configs[4]): bf16 hops with fp32 accumulation + the
             # bf16 MFMA dense block; forward only.  ``out_dtype`` of the last layer: self.bf16_out
@@ -255,6 +257,7 @@ class GCNConv(nn.Module):
     def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False, next_conv=None) -> Tensor:
         """``conv(x, edge_index)`` as PyG; ``relu=True`` fuses the ReLU the reference applies right after
         (``models/model.py:71,77``) - with the bias - into the aggregation launch (``ops.gcn_aggregate``)."""
+        x = resolve(x)
         _check_inputs(x, edge_index, self.in_channels)
         if DEFER_ACTIVATION and not relu and next_conv is None:
             side = _branch_stream(self, x)
@@ -311,6 +314,7 @@ class GATConv(nn.Module):
     def forward(self, x: Tensor, edge_index: Tensor, relu: bool = False, next_conv=None) -> Tensor:
         """``conv(x, edge_index)`` as PyG; everything behind ``lin`` is one autograd node on fused kernels
         (``ops.gat_conv``); ``relu=True`` also fuses the encoder's ReLU (``models/model.py:71,77``)."""
+        x = resolve(x)
         _check_inputs(x, edge_index, self.in_channels)
         if DEFER_ACTIVATION and not relu and next_conv is None:
             side = _branch_stream(self, x)

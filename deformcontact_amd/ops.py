@@ -15,6 +15,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
+from .deferred import resolve
 from .graph import GraphIndex, SortedAdjacency, _require_cuda, current_stream_ptr
 
 
@@ -162,7 +163,7 @@ class _HopFn(torch.autograd.Function):
 
 def propagate(g: GraphIndex, x: torch.Tensor, weighted: bool = True) -> torch.Tensor:
     """Autograd-aware hop (PyG ``propagate(edge_index, x=x, edge_weight=w)``)."""
-    return _HopFn.apply(g, x, weighted)
+    return _HopFn.apply(g, resolve(x), weighted)
 
 
 def _ptr_array(tensors):
@@ -964,6 +965,7 @@ def tag_conv_grouped(mg: GraphIndex, xs, weights, biases, relu: bool = False, ne
     branch.  ``next_k``: K of a grouped layer that consumes the outputs - they are then written as the part
     views of block 0 of that layer's merged slab."""
     flat = []
+    xs = [resolve(x) for x in xs]
     for b, ws in zip(biases, weights):
         flat += [b] + list(ws)
     return _TagConvGroupedFn.apply(mg, bool(relu), (int(next_k),) if next_k is not None else None, len(xs),
@@ -984,14 +986,14 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     ``six_products``: stay on the exact three-way bf16 split (24 bits) where the three-product fp16 split (22 bits)
     would apply - GATConv's ``lin``: the gradient of its attention vectors is a sum of terms that cancel to 1 % of
     their size and sits at the parity bar already."""
-    return _TagConvFn.apply(None, x, bias, bool(relu), SIX_PRODUCTS if six_products else None, weight)
+    return _TagConvFn.apply(None, resolve(x), bias, bool(relu), SIX_PRODUCTS if six_products else None, weight)
 
 
 def tag_conv(g: GraphIndex, x: torch.Tensor, weights, bias, relu: bool = False,
              next_geom=None) -> torch.Tensor:
     """``next_geom``: ``(width, padded width)`` of the hop slab of the TAGConv layer that consumes
     this output (None = none): the output is then allocated as column block 0 of that slab."""
-    return _TagConvFn.apply(g, x, bias, bool(relu), next_geom, *weights)
+    return _TagConvFn.apply(g, resolve(x), bias, bool(relu), next_geom, *weights)
 
 
 # --------------------------------------------------------------------------- #
@@ -1274,7 +1276,7 @@ class _GcnAggFn(torch.autograd.Function):
 
 
 def gcn_aggregate(g: GraphIndex, h: torch.Tensor, bias, relu: bool = False) -> torch.Tensor:
-    return _GcnAggFn.apply(g, h, bias, bool(relu))
+    return _GcnAggFn.apply(g, resolve(h), bias, bool(relu))
 
 
 class _GatConvFn(torch.autograd.Function):
@@ -1358,7 +1360,7 @@ class _GatConvFn(torch.autograd.Function):
 
 
 def gat_conv(g: GraphIndex, h, att_src, att_dst, bias, slope: float, relu: bool = False) -> torch.Tensor:
-    return _GatConvFn.apply(g, h, att_src, att_dst, bias, float(slope), bool(relu))
+    return _GatConvFn.apply(g, resolve(h), att_src, att_dst, bias, float(slope), bool(relu))
 
 # --------------------------------------------------------------------------- #
 # the two training losses in one pass (train.py:51-53, models/losses.py:7-19)
@@ -1393,6 +1395,7 @@ class _ContactLossFn(torch.autograd.Function):
 def contact_losses(g: GraphIndex, pred_pos: torch.Tensor, target_pos: torch.Tensor):
     """``(L1Loss(pred, target), GradientConsistencyLoss(pred, target))`` over the edge set of ``g``
     (``train.py:51-53``) in one node pass, differentiable w.r.t. ``pred_pos`` (the target is data)."""
+    pred_pos, target_pos = resolve(pred_pos), resolve(target_pos)
     _require_cuda(pred_pos, "pred_pos")
     for name, t in (("pred_pos", pred_pos), ("target_pos", target_pos)):
         if t.dim() != 2 or t.size(1) != 3 or t.dtype != torch.float32:

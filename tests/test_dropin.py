@@ -13,7 +13,7 @@ from deformcontact_amd import nn as dc_nn
 from deformcontact_amd.data import Batch
 from deformcontact_amd.graph import clear_cache
 from deformcontact_amd.graphnet import ContactEncoder, ReferenceWiring
-from deformcontact_amd.nn.deferred import DeferredActivation
+from deformcontact_amd.deferred import DeferredActivation
 from oracle import pyg_ref
 from tests.helpers import assert_parity
 
@@ -155,3 +155,41 @@ def test_plain_call_uses_follow_the_first_use(backbone):
             assert torch.equal(a, b)
     with torch.no_grad():
         assert not conv(x, ei).requires_grad
+
+
+def test_deferred_result_into_this_packages_own_autograd_functions_and_a_foreign_one():
+    """`Function.apply` does not dispatch on its arguments: the package's own entry points resolve a deferred conv result
+    before handing it on (conv of conv without activation, `NodeOrder.undo`, `ops.dense_linear`); a foreign custom Function
+    that is handed the wrapper raises instead of silently cutting the graph."""
+    from deformcontact_amd import ops
+    rest, _ = _batches(2, soft_vertices=128, sphere_resolution=5)
+    torch.manual_seed(2)
+    c1, c2 = dc_nn.TAGConv(21, 64).to(DEV), dc_nn.TAGConv(64, 32).to(DEV)
+    x, ei = rest.x, rest.edge_index
+    y = c2(c1(x, ei), ei)                                        # no activation in between
+    want = c2(c1(x, ei, relu=False, next_conv=None, out_into=None).clone(), ei).clone()
+    assert torch.equal(y.clone(), want)
+    (y * 1.0).sum().backward()
+    assert all(p_.grad is not None and float(p_.grad.abs().sum()) > 0 for p_ in list(c1.parameters()) + list(c2.parameters()))
+    lin = torch.nn.Linear(64, 16).to(DEV)
+    c1.zero_grad(set_to_none=True)
+    ops.dense_linear(c1(x, ei), lin.weight, lin.bias).sum().backward()
+    assert c1.lins[0].weight.grad is not None
+
+    class Twice(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+    with pytest.raises(RuntimeError, match="custom"):
+        Twice.apply(c1(x, ei))
+    assert Twice.apply(c1(x, ei).value()).grad_fn is not None
+    with torch.no_grad():                                        # first use under no_grad: recorded as the eager call would have
+        late = c1(x, ei)
+    y2 = c1(x, ei)
+    with torch.no_grad():
+        float(y2.norm())
+    assert y2.value().grad_fn is not None and not late.requires_grad

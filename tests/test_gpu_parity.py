@@ -822,7 +822,7 @@ def test_input_hop_slab_cache_hits_and_invalidates():
     real = ops._build_input_slab
     ops._build_input_slab = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     try:
-        y0 = conv(x, ei).clone()         # (.clone(): a plain conv call is deferred until its first use, nn/deferred.py)
+        y0 = conv(x, ei).clone()         # (.clone(): a plain conv call is deferred until its first use, deferred.py)
         y1 = conv(x, ei).clone()
         assert len(calls) == 1 and torch.equal(y0, y1)
         old, ops.HOP_CACHE = ops.HOP_CACHE, False

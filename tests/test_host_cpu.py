@@ -417,11 +417,11 @@ def test_batch_layout_travels_on_the_edge_index_tensor():
 
 
 def test_deferred_activation_semantics_cpu():
-    """`nn.deferred.DeferredActivation` (what a plain `conv(x, edge_index)` call returns): F.relu / torch.relu / .relu()
+    """`deferred.DeferredActivation` (what a plain `conv(x, edge_index)` call returns): F.relu / torch.relu / .relu()
     run the layer once with the activation fused and return that plain tensor; anything else runs it without and applies
     the operation; metadata costs nothing; the value is an ordinary autograd tensor."""
     import torch.nn.functional as F
-    from deformcontact_amd.nn.deferred import DeferredActivation, deferred
+    from deformcontact_amd.deferred import DeferredActivation, deferred
     w = torch.randn(4, 3, requires_grad=True)
     x = torch.randn(5, 3)
     calls = []
