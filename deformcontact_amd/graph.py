@@ -152,9 +152,26 @@ class GraphIndex:
         if segments is not None and parts is None and not self_loops:
             self._segments = _segment_arrays(segments, self.num_nodes, self.num_input_edges, self.device)
             self._layout = _layout_arrays(segments, self.num_nodes)
-            if self._layout is not None:
-                nodes = self._layout[0]
-                self._seg_max_nodes = max(nodes[i + 1] - nodes[i] for i in range(self._layout[1]))
+        elif parts is not None and not self_loops:
+            # merged node space: when every part's edge_index carries its batch layout (data.Batch._tag_edge_layout), the
+            # merged space is a union of those graphs plus the isolated padding rows between the parts, which enter as graphs
+            # without edges - dc_hop_chain_f32 then runs the merged hops as one launch too (round 6; until then the merged
+            # encoder path hopped one launch per hop: 6 x 35 us against 2 chain launches)
+            nodes = [0]
+            for g, (ei, n) in enumerate(self.parts):
+                lay = edge_layout(ei)
+                if lay is None or int(lay[0][-1]) != n or int(lay[1][-1]) != int(ei.size(1)):
+                    nodes = None
+                    break
+                nodes += [self.row_beg[g] + int(v) for v in lay[0][1:]]
+                end = self.row_beg[g + 1] if g + 1 < len(self.parts) else self.num_nodes
+                if nodes[-1] < end:
+                    nodes.append(end)                       # the part's padding rows: a graph of isolated nodes
+            if nodes is not None:
+                self._layout = _layout_arrays((nodes,), self.num_nodes)
+        if self._layout is not None:
+            nodes = self._layout[0]
+            self._seg_max_nodes = max(nodes[i + 1] - nodes[i] for i in range(self._layout[1]))
         self.rebuild()
         if validate:
             self.validate()
