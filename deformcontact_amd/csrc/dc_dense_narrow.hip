@@ -1,0 +1,241 @@
+// dc_dense_narrow.hip -- the dense block of a TAGConv layer with a SHORT reduction: the first layer of each encoder branch
+// (/root/reference/models/model.py:44-50: TAGConv(21, 256) / TAGConv(25, 256), K = 3 -> reduction (K + 1) * F_in = 84 / 100,
+// zero-padded to 96 / 112 in the hop slab).
+//
+//   out[N, 256] = act(slab[N, Kp] . Wcat[256, Kp]^T + b),   Wcat = [W_0 | W_1 | W_2 | W_3 | 0]  (lins[k].weight of PyG tag_conv.py)
+//
+// Round 6 measured what these layers cost the two-stream headline step by making them free (tools/r06/skip_probe.py): forward
+// blocks 53 us, weight-gradient blocks 64 us, hops 36 us of a 617 us step - all of it on the critical path, none hidden by the
+// second stream.  The generic split kernel (dc_dense_split.hip: k_fwd_split, 128 x 128 tiles, both operands split per tile and
+// stage, 4-byte epilogue stores) took 25.7 / 20.7 us for 46 / 35 MB of compulsory traffic (0.22 of the HBM roofline) and
+// needed a packing launch for Wcat in front of it.
+//
+// This kernel is built for the shape: the whole reduction is ONE stage.
+//   * persistent 256-thread workgroups, one per CU; wave w owns output columns [64 w, 64 w + 64) and keeps ITS slice of the
+//     weights - gathered straight from the K + 1 lins[k].weight matrices (no packing launch), split into the three bf16 planes
+//     once per launch - in registers for all row tiles (24 * Kp / 16 VGPRs; one wave per SIMD, 512 registers each);
+//   * per row tile (64 or 32 rows): fp32 rows global -> registers (issued one tile ahead) -> three bf16 planes -> LDS (rows
+//     padded to Kp * 6 + 16 bytes: conflict-free ds_read_b128 fragment reads), one barrier, 6 products x Kp / 16 k-steps of
+//     v_mfma_f32_32x32x16_bf16 per accumulator IN THE ORDER of k_fwd_split<., 6> (k-steps ascending, products smallest terms
+//     first) - the outputs are bit-identical to it (tests/test_narrow_dense.py);
+//   * epilogue through LDS: bias + ReLU in registers, accumulators into a [rows][256] fp32 image, one barrier, one 1-KiB row per
+//     global_store_dwordx4 wave-instruction (the 4-byte stores of the accumulator layout cost 7.6 us per 33.5 MB).
+// Bytes per launch (B = 32): 12.6 + 33.5 MB soft, 10.9 + 25.0 MB rigid; MFMA work 9.7 / 8.4 GFLOP: HBM-bound.
+#include "dc_dense.h"
+
+namespace dc {
+
+using nb_bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using nb_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using nb_f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct NarrowParams {
+    const float *x;                 // hop slab [N, ld], Kp valid (zero-padded) columns
+    int64_t ld;
+    const float *w[kMaxSeg];        // lins[k].weight [Fo, fi]
+    int nseg, fi;
+    const float *bias;
+    float *out;
+    int64_t ldo, N;
+    int relu, ntiles;
+};
+
+__device__ __forceinline__ void nb_split1(float x, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+    hi = (__bf16)x;
+    const float r = x - (float)hi;        // exact
+    mid = (__bf16)r;
+    const float r2 = r - (float)mid;      // exact
+    lo = (__bf16)r2;
+}
+
+constexpr int kNarrowFo = 256;
+
+// KS: k-steps of 16 (Kp = 16 KS); MB: 32-row blocks per tile
+template <int KS, int MB>
+__global__ void __launch_bounds__(256)
+k_fwd_narrow(NarrowParams p) {
+    constexpr int TR = 32 * MB;                         // rows per tile
+    constexpr int SROWA = KS * 96 + 16;                 // bytes per row of the plane image: [ks][plane][half][8 bf16] + pad
+    constexpr int PPR = 4 * KS;                         // float4 pieces per row
+    constexpr int TP = TR * PPR, NV = (TP + 255) / 256;
+    constexpr int kOffStage = ((TR * SROWA + 1023) / 1024) * 1024;
+    __shared__ __attribute__((aligned(1024))) char lds[kOffStage + TR * 1024];
+    char *const sA = lds;
+    float *const so = reinterpret_cast<float *>(lds + kOffStage);
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+
+    // ---- this wave's slice of the weights: fragments of all k-steps, three planes, in registers for the whole launch ----
+    // B fragment of (nb, ks): column 64 wid + 32 nb + c, k = 16 ks + 8 h .. + 7 of Wcat; k -> (segment k / fi, column k % fi)
+    nb_bf16x8 fb[2][KS][3];
+    const int width = p.nseg * p.fi;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int64_t col = 64 * wid + 32 * nb + c;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            int k = 16 * ks + 8 * h;
+            int s = k / p.fi, f = k - s * p.fi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = 0.f;
+                if (k + j < width) v = p.w[s][col * p.fi + f];
+                __bf16 hi, mid, lo;
+                nb_split1(v, hi, mid, lo);
+                fb[nb][ks][0][j] = hi, fb[nb][ks][1][j] = mid, fb[nb][ks][2][j] = lo;
+                if (++f == p.fi) f = 0, ++s;
+                if (s >= p.nseg) s = p.nseg - 1;                 // (past the last segment: the value is not used)
+            }
+        }
+    }
+    float bcol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[64 * wid + 32 * nb + c] : 0.f;
+    const bool relu = p.relu != 0;
+
+    // ---- x tile staging: piece q = threadIdx.x + 256 j of the tile = float4 c4 of row r ----
+    nb_f32x4 xv[NV];
+    auto load_tile = [&](int t) {
+        const int64_t row0 = (int64_t)t * TR;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = (int)threadIdx.x + 256 * j;
+            if (TP % 256 != 0 && q >= TP) continue;
+            const int r = q / PPR, c4 = q - r * PPR;
+            int64_t row = row0 + r;
+            row = row < p.N ? row : p.N - 1;
+            xv[j] = *reinterpret_cast<const nb_f32x4 *>(p.x + row * p.ld + 4 * c4);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = (int)threadIdx.x + 256 * j;
+            if (TP % 256 != 0 && q >= TP) continue;
+            const int r = q / PPR, c4 = q - r * PPR;
+            nb_bf16x4 hi, mid, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __bf16 a, b, d;
+                nb_split1(xv[j][i], a, b, d);
+                hi[i] = a, mid[i] = b, lo[i] = d;
+            }
+            // k = 4 c4 .. + 3: k-step c4 / 4, half (c4 & 3) / 2, position 4 (c4 & 1) inside the half's 8
+            char *dst = sA + r * SROWA + (c4 >> 2) * 96 + ((c4 >> 1) & 1) * 16 + (c4 & 1) * 8;
+            *reinterpret_cast<nb_bf16x4 *>(dst) = hi;
+            *reinterpret_cast<nb_bf16x4 *>(dst + 32) = mid;
+            *reinterpret_cast<nb_bf16x4 *>(dst + 64) = lo;
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < p.ntiles) load_tile(t);
+    for (; t < p.ntiles; t += gridDim.x) {
+        const int64_t row0 = (int64_t)t * TR;
+        store_tile();                                   // (every wave is past the MFMAs of the previous tile: barrier B)
+        if (t + (int)gridDim.x < p.ntiles) load_tile(t + gridDim.x);      // in flight under this tile's MFMAs
+        __syncthreads();                                // A: the plane image is complete; the staging image is free
+        f32x16 acc[MB][2];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+        constexpr int HI = 0, MID = 1, LO = 2;
+        constexpr int pa6[6] = {LO, HI, MID, MID, HI, HI}, pb6[6] = {HI, LO, MID, HI, MID, HI};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            nb_bf16x8 fa[MB][3];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fa[mb][pl] = *reinterpret_cast<const nb_bf16x8 *>(sA + (mb * 32 + c) * SROWA + ks * 96 + pl * 32 + h * 16);
+#pragma unroll
+            for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb][pa6[tt]], fb[nb][ks][pb6[tt]], acc[mb][nb], 0, 0, 0);
+        }
+        // epilogue: bias + ReLU, accumulators -> [TR][256] image (C/D layout: row (reg & 3) + 8 (reg >> 2) + 4 h, column c)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mb][nb][r] + bcol[nb];
+                    if (relu) v = fmaxf(v, 0.f);
+                    so[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 64 * wid + 32 * nb + c] = v;
+                }
+        __syncthreads();                                // B: image complete; every wave has read its plane fragments
+        // one 1-KiB row per store instruction: wave w stores rows w, w + 4, ...
+#pragma unroll 4
+        for (int r = wid; r < TR; r += 4) {
+            const int64_t row = row0 + r;
+            const nb_f32x4 v = *reinterpret_cast<const nb_f32x4 *>(so + r * 256 + 4 * lane);
+            if (row < p.N) *reinterpret_cast<nb_f32x4 *>(p.out + row * p.ldo + 4 * lane) = v;
+        }
+    }
+}
+
+template <int KS>
+static void narrow_launch(const NarrowParams &p0, int mb, hipStream_t hs) {
+    NarrowParams p = p0;
+    const int tr = 32 * mb;
+    p.ntiles = (int)((p.N + tr - 1) / tr);
+    const unsigned grid = (unsigned)(p.ntiles < 256 ? p.ntiles : 256);
+    if (mb == 2)
+        DC_LAUNCH((k_fwd_narrow<KS, 2>), dim3(grid), dim3(256), 0, hs, p);
+    else
+        DC_LAUNCH((k_fwd_narrow<KS, 1>), dim3(grid), dim3(256), 0, hs, p);
+}
+
+}  // namespace dc
+
+using namespace dc;
+
+// Whether dc_tag_linear_fwd_narrow takes this shape (host-side query; the entry itself returns DC_EINVAL otherwise)
+extern "C" int dc_tag_linear_fwd_narrow_ok(int64_t fi, int nseg, int64_t wpad, int64_t Fo) {
+    return (Fo == kNarrowFo && nseg >= 1 && nseg <= kMaxSeg && fi >= 1 && nseg * fi <= wpad &&
+            (wpad == 96 || wpad == 112 || wpad == 128)) ? 1 : 0;
+}
+
+extern "C" int dc_tag_linear_fwd_narrow(const float *slab, int64_t ld, const float *const *ws, int nseg, int64_t fi,
+                                        const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t wpad,
+                                        int64_t Fo, dc_stream_t stream) {
+    DC_REQUIRE(dc_tag_linear_fwd_narrow_ok(fi, nseg, wpad, Fo),
+               "dc_tag_linear_fwd_narrow: needs Fo = 256, a padded reduction of 96 / 112 / 128 >= nseg * fi (got Fo=%lld wpad=%lld "
+               "nseg=%d fi=%lld)", (long long)Fo, (long long)wpad, nseg, (long long)fi);
+    DC_REQUIRE(N >= 0, "dc_tag_linear_fwd_narrow: negative N");
+    if (N == 0) return DC_OK;
+    DC_REQUIRE(slab && ws && out && ld >= wpad && ldo >= Fo, "dc_tag_linear_fwd_narrow: null pointer / short leading dimension");
+    DC_REQUIRE(ld % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((uintptr_t)out & 15) == 0,
+               "dc_tag_linear_fwd_narrow: rows of the slab and of the output must be 16-byte aligned");
+    DC_REQUIRE(N < ((int64_t)1 << 31) - 64, "dc_tag_linear_fwd_narrow: too many rows");
+    NarrowParams p{};
+    p.x = slab, p.ld = ld, p.nseg = nseg, p.fi = (int)fi, p.bias = bias, p.out = out, p.ldo = ldo, p.N = N, p.relu = relu;
+    for (int s = 0; s < nseg; ++s) {
+        DC_REQUIRE(ws[s], "dc_tag_linear_fwd_narrow: null weight segment %d", s);
+        p.w[s] = ws[s];
+    }
+    // 64-row tiles unless 32-row ones balance the 256 persistent workgroups better (rigid B = 32: 381 x 64 rows = 2 rounds of
+    // which the second is half empty; 762 x 32 rows = 3 rounds of 32)
+    const int64_t t64 = (N + 63) / 64, t32 = (N + 31) / 32;
+    const int64_t r64 = (t64 + 255) / 256 * 2, r32 = (t32 + 255) / 256;
+    static const int force_mb = [] {
+        const char *v = getenv("DC_NARROW_MB");
+        return (v && *v) ? atoi(v) : 0;
+    }();
+    const int mb = force_mb ? force_mb : (r32 < r64 ? 1 : 2);
+    hipStream_t hs = (hipStream_t)stream;
+    switch (wpad) {
+    case 96: narrow_launch<6>(p, mb, hs); break;
+    case 112: narrow_launch<7>(p, mb, hs); break;
+    default: narrow_launch<8>(p, mb, hs); break;
+    }
+    return check_launch("dc_tag_linear_fwd_narrow");
+}

@@ -200,6 +200,11 @@ DENSE_SPLIT_BF16 = os.environ.get("DC_DENSE_SPLIT", "1") != "0"
 DENSE_PRODUCTS = 6
 
 
+#: the short-reduction forward kernel for the first layers (``dc_tag_linear_fwd_narrow``: persistent, weights resident in
+#: registers, no packing launch; bit-identical to the six-product split kernel); ``DC_NARROW_FWD=0``: ``dc_tag_pack_weights`` +
+#: ``dc_tag_linear_fwd_split`` as up to round 5
+NARROW_FWD = os.environ.get("DC_NARROW_FWD", "1") != "0"
+
 #: fp16x2 mode of the wide (Fi % 16 == 0, unconcatenated) dense blocks: two power-of-two-scaled
 #: fp16 planes per operand and THREE MFMA products instead of the six of the bf16 split - still
 #: fp32-accurate (error below that of fp32 accumulation), half the matrix work.  The row maxima
@@ -550,7 +555,13 @@ class _TagConvFn(torch.autograd.Function):
             rowmax = torch.empty(n, dtype=torch.float32, device=dev)
             _lib.check(L.dc_rowabsmax_f32(slab.data_ptr(), slab.stride(0), n, fi, rowmax.data_ptr(), st), "dc_rowabsmax_f32")
         blocks = [slab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
-        if concat:
+        narrow = (concat and NARROW_FWD and DENSE_SPLIT_BF16 and DENSE_PRODUCTS == 6
+                  and bool(L.dc_tag_linear_fwd_narrow_ok(fi, k + 1, wpad, fo)))
+        if concat and narrow:
+            # the short-reduction kernel gathers its weight fragments from the lins[k].weight matrices themselves
+            ws = [w.contiguous() for w in weights]
+            xs, ldxs, fi_eff = [slab], [slab.stride(0)], wpad
+        elif concat:
             wc = [w.contiguous() for w in weights]
             wcat = torch.empty((fo, wpad), dtype=torch.float32, device=dev)
             _lib.check(L.dc_tag_pack_weights(_ptr_array(wc), k + 1, wcat.data_ptr(), fo, fi, wpad,
@@ -592,6 +603,10 @@ class _TagConvFn(torch.autograd.Function):
                                          b.data_ptr() if b is not None else None, int(relu),
                                          out.data_ptr(), ldo, n, width, fo,
                                          rowmax.data_ptr(), wmax.data_ptr(), None, 0, st)
+        elif narrow:
+            rc = L.dc_tag_linear_fwd_narrow(slab.data_ptr(), slab.stride(0), _ptr_array(ws), k + 1, fi,
+                                            b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n,
+                                            wpad, fo, st)
         elif DENSE_SPLIT_BF16:
             rc = L.dc_tag_linear_fwd_split(*args, DENSE_PRODUCTS, st)
         else:
@@ -599,6 +614,7 @@ class _TagConvFn(torch.autograd.Function):
         _lib.check(rc, "dc_tag_linear_fwd")
         ctx.g, ctx.k, ctx.fi, ctx.fo, ctx.has_bias, ctx.relu, ctx.concat = \
             g, k, fi, fo, bias is not None, relu, concat
+        ctx.narrow = narrow
         ctx.params, ctx.bias_param = weights, bias       # the Parameter objects themselves
         ctx.h2 = h2
         ctx.save_for_backward(slab, out if relu else None, rowmax, wt, wt_rowmax, *ws)
@@ -725,6 +741,12 @@ class _TagConvFn(torch.autograd.Function):
             weight_gradients()
 
         if need_x:
+            if concat and ctx.narrow:
+                # the forward read the lins[k].weight matrices directly; the one-segment dX block wants them concatenated
+                wcat = torch.empty((fo, wpad), dtype=torch.float32, device=dev)
+                _lib.check(L.dc_tag_pack_weights(_ptr_array(ws), k + 1, wcat.data_ptr(), fo, fi, wpad, st),
+                           "dc_tag_pack_weights")
+                ws = [wcat]
             gslab = _alloc_slab(n, wpad, dev)
             gblocks = [gslab[:, j * fi:(j + 1) * fi] for j in range(k + 1)]
             gxs = [gslab] if concat else gblocks

@@ -447,7 +447,8 @@ def test_default_b32_step_launches_exactly_the_tuned_kernels(everyday_b32):
     # first layers: fused pack + first hop, two more narrow hops, six-product split blocks
     narrow_hops = sum(v for k, v in got.items() if k.startswith("k_spmm_sub"))
     assert narrow_hops == 6, got
-    assert sum(v for k, v in got.items() if k.startswith("k_fwd_split")) == 2
+    assert sum(v for k, v in got.items() if k.startswith("k_fwd_narrow")) == 2       # (round 6: the short-reduction kernel;
+    assert not any(k.startswith("k_fwd_split") or "k_pack_weights" in k for k in got)  # no packing launch in front of it)
     assert sum(v for k, v in got.items() if k.startswith("k_dw_split")) == 2
     assert "k_dw_reduce" in names
     banned = {"k_spmm_wave", "k_tag_linear_fwd", "k_tag_linear_bwd_dx", "k_tag_linear_bwd_dw", "k_fwd_h2", "k_fwd_fast",
