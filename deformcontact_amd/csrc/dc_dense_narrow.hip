@@ -12,8 +12,9 @@
 //
 // This kernel is built for the shape: the whole reduction is ONE stage.
 //   * persistent 256-thread workgroups, one per CU; wave w owns output columns [64 w, 64 w + 64) and keeps ITS slice of the
-//     weights - gathered straight from the K + 1 lins[k].weight matrices (no packing launch), split into the three bf16 planes
-//     once per launch - in registers for all row tiles (24 * Kp / 16 VGPRs; one wave per SIMD, 512 registers each);
+//     weights - read from the K + 1 lins[k].weight matrices themselves (no packing launch: coalesced reads into an fp32 LDS
+//     image, fragments picked out of it), split into the three bf16 planes once per launch - in registers for all row tiles
+//     (24 * Kp / 16 VGPRs; one wave per SIMD, 512 registers each);
 //   * per row tile (64 or 32 rows): fp32 rows global -> registers (issued one tile ahead) -> three bf16 planes -> LDS (rows
 //     padded to Kp * 6 + 16 bytes: conflict-free ds_read_b128 fragment reads), one barrier, 6 products x Kp / 16 k-steps of
 //     v_mfma_f32_32x32x16_bf16 per accumulator IN THE ORDER of k_fwd_split<., 6> (k-steps ascending, products smallest terms
@@ -40,6 +41,8 @@ struct NarrowParams {
     int relu, ntiles;
 };
 
+constexpr int kNarrowFo = 256;
+
 __device__ __forceinline__ void nb_split1(float x, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
     hi = (__bf16)x;
     const float r = x - (float)hi;        // exact
@@ -47,8 +50,6 @@ __device__ __forceinline__ void nb_split1(float x, __bf16 &hi, __bf16 &mid, __bf
     const float r2 = r - (float)mid;      // exact
     lo = (__bf16)r2;
 }
-
-constexpr int kNarrowFo = 256;
 
 // KS: k-steps of 16 (Kp = 16 KS); MB: 32-row blocks per tile
 template <int KS, int MB>
@@ -58,40 +59,14 @@ k_fwd_narrow(NarrowParams p) {
     constexpr int SROWA = KS * 96 + 16;                 // bytes per row of the plane image: [ks][plane][half][8 bf16] + pad
     constexpr int PPR = 4 * KS;                         // float4 pieces per row
     constexpr int TP = TR * PPR, NV = (TP + 255) / 256;
+    constexpr int KP = 16 * KS;                         // padded reduction
     constexpr int kOffStage = ((TR * SROWA + 1023) / 1024) * 1024;
-    __shared__ __attribute__((aligned(1024))) char lds[kOffStage + TR * 1024];
+    constexpr int kLdsTiles = kOffStage + TR * 1024, kLdsW = kNarrowFo * KP * 4;      // tile images / prologue weight image
+    __shared__ __attribute__((aligned(1024))) char lds[kLdsTiles > kLdsW ? kLdsTiles : kLdsW];
     char *const sA = lds;
     float *const so = reinterpret_cast<float *>(lds + kOffStage);
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int c = lane & 31, h = lane >> 5;
-
-    // ---- this wave's slice of the weights: fragments of all k-steps, three planes, in registers for the whole launch ----
-    // B fragment of (nb, ks): column 64 wid + 32 nb + c, k = 16 ks + 8 h .. + 7 of Wcat; k -> (segment k / fi, column k % fi)
-    nb_bf16x8 fb[2][KS][3];
-    const int width = p.nseg * p.fi;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int64_t col = 64 * wid + 32 * nb + c;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            int k = 16 * ks + 8 * h;
-            int s = k / p.fi, f = k - s * p.fi;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = 0.f;
-                if (k + j < width) v = p.w[s][col * p.fi + f];
-                __bf16 hi, mid, lo;
-                nb_split1(v, hi, mid, lo);
-                fb[nb][ks][0][j] = hi, fb[nb][ks][1][j] = mid, fb[nb][ks][2][j] = lo;
-                if (++f == p.fi) f = 0, ++s;
-                if (s >= p.nseg) s = p.nseg - 1;                 // (past the last segment: the value is not used)
-            }
-        }
-    }
-    float bcol[2];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[64 * wid + 32 * nb + c] : 0.f;
-    const bool relu = p.relu != 0;
 
     // ---- x tile staging: piece q = threadIdx.x + 256 j of the tile = float4 c4 of row r ----
     nb_f32x4 xv[NV];
@@ -107,6 +82,51 @@ k_fwd_narrow(NarrowParams p) {
             xv[j] = *reinterpret_cast<const nb_f32x4 *>(p.x + row * p.ld + 4 * c4);
         }
     };
+    int t = blockIdx.x;
+    if (t < p.ntiles) load_tile(t);                     // the first tile's rows travel while the weights are prepared
+
+    // ---- this wave's slice of the weights: fragments of all k-steps, three planes, in registers for the whole launch ----
+    // First Wcat = [W_0 | ... | W_{nseg-1} | 0] as an fp32 image [256][Kp] in LDS, gathered with COALESCED reads of the
+    // lins[k].weight matrices (element e of segment s = row e / fi, column e % fi; a per-lane gather of the fragments straight
+    // from memory - 8 strided 4-byte loads per fragment - cost 20 us per launch: every workgroup made 7 M cache-line requests);
+    // then every lane picks its fragments out of the image: column 64 wid + 32 nb + c, k = 16 ks + 8 h .. + 7.
+    {
+        float *wi = reinterpret_cast<float *>(lds);
+        const int width = p.nseg * p.fi, per = kNarrowFo * p.fi;
+        for (int s = 0; s < p.nseg; ++s)
+            for (int e = threadIdx.x; e < per; e += 256) {
+                const int o = e / p.fi, f = e - o * p.fi;
+                wi[o * KP + s * p.fi + f] = p.w[s][e];
+            }
+        const int padw = KP - width;
+        for (int e = threadIdx.x; e < kNarrowFo * padw; e += 256) {
+            const int o = e / padw, f = e - o * padw;
+            wi[o * KP + width + f] = 0.f;
+        }
+    }
+    __syncthreads();
+    nb_bf16x8 fb[2][KS][3];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const float *wr = reinterpret_cast<const float *>(lds) + (64 * wid + 32 * nb + c) * KP + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const nb_f32x4 v0 = *reinterpret_cast<const nb_f32x4 *>(wr + 16 * ks);
+            const nb_f32x4 v1 = *reinterpret_cast<const nb_f32x4 *>(wr + 16 * ks + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 hi, mid, lo;
+                nb_split1(j < 4 ? v0[j] : v1[j - 4], hi, mid, lo);
+                fb[nb][ks][0][j] = hi, fb[nb][ks][1][j] = mid, fb[nb][ks][2][j] = lo;
+            }
+        }
+    }
+    __syncthreads();                                    // the image's LDS becomes the plane / staging images
+    float bcol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[64 * wid + 32 * nb + c] : 0.f;
+    const bool relu = p.relu != 0;
+
     auto store_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -128,8 +148,6 @@ k_fwd_narrow(NarrowParams p) {
         }
     };
 
-    int t = blockIdx.x;
-    if (t < p.ntiles) load_tile(t);
     for (; t < p.ntiles; t += gridDim.x) {
         const int64_t row0 = (int64_t)t * TR;
         store_tile();                                   // (every wave is past the MFMAs of the previous tile: barrier B)
