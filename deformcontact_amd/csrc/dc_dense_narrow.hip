@@ -98,13 +98,31 @@ k_fwd_narrow(NarrowParams p) {
     // from memory - 8 strided 4-byte loads per fragment - cost 20 us per launch: every workgroup made 7 M cache-line requests);
     // then every lane picks its fragments out of the image: column 64 wid + 32 nb + c, k = 16 ks + 8 h .. + 7.
     {
+        // all loads of a segment are issued before the first is used (a load per loop trip waited for each one in turn:
+        // 84 round trips to L2, 25 us per launch)
         float *wi = reinterpret_cast<float *>(lds);
-        const int width = p.nseg * p.fi, per = kNarrowFo * p.fi;
-        for (int s = 0; s < p.nseg; ++s)
-            for (int e = threadIdx.x; e < per; e += 256) {
-                const int o = e / p.fi, f = e - o * p.fi;
-                wi[o * KP + s * p.fi + f] = p.w[s][e];
+        const int width = p.nseg * p.fi, per4 = kNarrowFo * p.fi / 4;         // float4 pieces per segment (256 fi / 4)
+        constexpr int MAXQ = 8;                                              // fi <= 32
+        for (int s = 0; s < p.nseg; ++s) {
+            nb_f32x4 wv[MAXQ];
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) {
+                const int q = (int)threadIdx.x + 256 * j;
+                if (q < per4) wv[j] = *reinterpret_cast<const nb_f32x4 *>(p.w[s] + 4 * q);
             }
+#pragma unroll
+            for (int j = 0; j < MAXQ; ++j) {
+                const int q = (int)threadIdx.x + 256 * j;
+                if (q < per4) {
+                    int o = (4 * q) / p.fi, f = 4 * q - o * p.fi;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        wi[o * KP + s * p.fi + f] = wv[j][i];
+                        if (++f == p.fi) f = 0, ++o;
+                    }
+                }
+            }
+        }
         const int padw = KP - width;
         for (int e = threadIdx.x; e < kNarrowFo * padw; e += 256) {
             const int o = e / padw, f = e - o * padw;
@@ -235,7 +253,7 @@ using namespace dc;
 
 // Whether dc_tag_linear_fwd_narrow takes this shape (host-side query; the entry itself returns DC_EINVAL otherwise)
 extern "C" int dc_tag_linear_fwd_narrow_ok(int64_t fi, int nseg, int64_t wpad, int64_t Fo) {
-    return (Fo == kNarrowFo && nseg >= 1 && nseg <= kMaxSeg && fi >= 1 && nseg * fi <= wpad &&
+    return (Fo == kNarrowFo && nseg >= 1 && nseg <= kMaxSeg && fi >= 1 && fi <= 32 && nseg * fi <= wpad &&
             (wpad == 96 || wpad == 112 || wpad == 128)) ? 1 : 0;
 }
 
