@@ -24,6 +24,13 @@
 // Bytes per launch (B = 32): 12.6 + 33.5 MB soft, 10.9 + 25.0 MB rigid; MFMA work 9.7 / 8.4 GFLOP: HBM-bound.
 #include "dc_dense.h"
 
+// timing-only ablations (tools/r06/narrow_abl.sh builds this file with -DDC_NARROW_ABL=<bits>; results are wrong by
+// construction): 1 no MFMAs, 2 no weight image (fragments made up), 4 no row stores, 8 no row loads / plane image, 16 no
+// accumulator staging
+#ifndef DC_NARROW_ABL
+#define DC_NARROW_ABL 0
+#endif
+
 namespace dc {
 
 using nb_bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
@@ -86,7 +93,8 @@ k_fwd_narrow(NarrowParams p) {
             const int r = q / PPR, c4 = q - r * PPR;
             int64_t row = row0 + r;
             row = row < p.N ? row : p.N - 1;
-            xv[j] = *reinterpret_cast<const nb_f32x4 *>(p.x + row * p.ld + 4 * c4);
+            if (DC_NARROW_ABL & 8) xv[j] = nb_f32x4{(float)row, 1.f, 2.f, 3.f};
+            else xv[j] = *reinterpret_cast<const nb_f32x4 *>(p.x + row * p.ld + 4 * c4);
         }
     };
     int t = blockIdx.x;
@@ -103,7 +111,7 @@ k_fwd_narrow(NarrowParams p) {
         float *wi = reinterpret_cast<float *>(lds);
         const int width = p.nseg * p.fi, per4 = kNarrowFo * p.fi / 4;         // float4 pieces per segment (256 fi / 4)
         constexpr int MAXQ = 8;                                              // fi <= 32
-        for (int s = 0; s < p.nseg; ++s) {
+        for (int s = 0; s < ((DC_NARROW_ABL & 2) ? 0 : p.nseg); ++s) {
             nb_f32x4 wv[MAXQ];
 #pragma unroll
             for (int j = 0; j < MAXQ; ++j) {
@@ -179,7 +187,7 @@ k_fwd_narrow(NarrowParams p) {
         for (int r = wid; r < TR; r += 4) {
             const int64_t row = row0 + r;
             const nb_f32x4 v = *reinterpret_cast<const nb_f32x4 *>(so + r * 256 + 4 * lane);
-            if (row < p.N) *reinterpret_cast<nb_f32x4 *>(p.out + row * p.ldo + 4 * lane) = v;
+            if (row < p.N && (!(DC_NARROW_ABL & 4) || v[0] == 12345.678f)) *reinterpret_cast<nb_f32x4 *>(p.out + row * p.ldo + 4 * lane) = v;
         }
     };
     // Order inside an iteration (vector-memory operations retire in order, and hipcc's wait before the first use of the staged
@@ -189,7 +197,7 @@ k_fwd_narrow(NarrowParams p) {
     int64_t prev_row0 = -1;
     for (; t < p.ntiles; t += gridDim.x) {
         const int64_t row0 = (int64_t)t * TR;
-        store_tile();                                   // (every wave is past the MFMAs of the previous tile: barrier B)
+        if (!(DC_NARROW_ABL & 8)) store_tile();         // (every wave is past the MFMAs of the previous tile: barrier B)
         if (prev_row0 >= 0) store_rows(prev_row0);
         if (t + (int)gridDim.x < p.ntiles) load_tile(t + gridDim.x);
         nb_lds_barrier();                               // A: the plane image is complete; the staging image has been read
@@ -216,7 +224,10 @@ k_fwd_narrow(NarrowParams p) {
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb][pa6[tt]], fb[nb][ks][pb6[tt]], acc[mb][nb], 0, 0, 0);
+                        if (!(DC_NARROW_ABL & 1))
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb][pa6[tt]], fb[nb][ks][pb6[tt]], acc[mb][nb], 0, 0, 0);
+                        else
+                            acc[mb][nb][tt] += (float)fa[mb][pa6[tt]][0] * (float)fb[nb][ks][pb6[tt]][0];
         }
         // epilogue: bias + ReLU, accumulators -> [TR][256] image (C/D layout: row (reg & 3) + 8 (reg >> 2) + 4 h, column c)
 #pragma unroll
@@ -227,7 +238,8 @@ k_fwd_narrow(NarrowParams p) {
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[mb][nb][r] + bcol[nb];
                     if (relu) v = fmaxf(v, 0.f);
-                    so[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 64 * wid + 32 * nb + c] = v;
+                    if (!(DC_NARROW_ABL & 16) || r == 0)
+                        so[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 256 + 64 * wid + 32 * nb + c] = v;
                 }
         nb_lds_barrier();                               // B: image complete; every wave has read its plane fragments
         prev_row0 = row0;
