@@ -75,7 +75,7 @@ k_fwd_narrow(NarrowParams p) {
     constexpr int TP = TR * PPR, NV = (TP + 255) / 256;
     constexpr int KP = 16 * KS;                         // padded reduction
     constexpr int kOffStage = ((TR * SROWA + 1023) / 1024) * 1024;
-    constexpr int kLdsTiles = kOffStage + TR * 1024, kLdsW = kNarrowFo * KP * 4;      // tile images / prologue weight image
+    constexpr int kLdsTiles = kOffStage + TR * 1024, kLdsW = kNarrowFo * (KP + 4) * 4;      // tile images / prologue weight image
     __shared__ __attribute__((aligned(1024))) char lds[kLdsTiles > kLdsW ? kLdsTiles : kLdsW];
     char *const sA = lds;
     float *const so = reinterpret_cast<float *>(lds + kOffStage);
@@ -105,43 +105,46 @@ k_fwd_narrow(NarrowParams p) {
     // lins[k].weight matrices (element e of segment s = row e / fi, column e % fi; a per-lane gather of the fragments straight
     // from memory - 8 strided 4-byte loads per fragment - cost 20 us per launch: every workgroup made 7 M cache-line requests);
     // then every lane picks its fragments out of the image: column 64 wid + 32 nb + c, k = 16 ks + 8 h .. + 7.
+    constexpr int WROW = KP + 4;                        // image row in floats: +16 B keeps the fragment picks conflict-free
     {
-        // all loads of a segment are issued before the first is used (a load per loop trip waited for each one in turn:
-        // 84 round trips to L2, 25 us per launch)
+        // ALL loads (every segment) are issued before the first is used: a load per loop trip waited for each one in turn
+        // (84 round trips to L2, 25 us per launch); a batch per segment still made four round trips
         float *wi = reinterpret_cast<float *>(lds);
         const int width = p.nseg * p.fi, per4 = kNarrowFo * p.fi / 4;         // float4 pieces per segment (256 fi / 4)
         constexpr int MAXQ = 8;                                              // fi <= 32
-        for (int s = 0; s < ((DC_NARROW_ABL & 2) ? 0 : p.nseg); ++s) {
-            nb_f32x4 wv[MAXQ];
+        nb_f32x4 wv[kMaxSeg][MAXQ];
+#pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s)
 #pragma unroll
             for (int j = 0; j < MAXQ; ++j) {
                 const int q = (int)threadIdx.x + 256 * j;
-                if (q < per4) wv[j] = *reinterpret_cast<const nb_f32x4 *>(p.w[s] + 4 * q);
+                if (!(DC_NARROW_ABL & 2) && s < p.nseg && q < per4) wv[s][j] = *reinterpret_cast<const nb_f32x4 *>(p.w[s] + 4 * q);
             }
 #pragma unroll
+        for (int s = 0; s < kMaxSeg; ++s)
+#pragma unroll
             for (int j = 0; j < MAXQ; ++j) {
                 const int q = (int)threadIdx.x + 256 * j;
-                if (q < per4) {
+                if (!(DC_NARROW_ABL & 2) && s < p.nseg && q < per4) {
                     int o = (4 * q) / p.fi, f = 4 * q - o * p.fi;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        wi[o * KP + s * p.fi + f] = wv[j][i];
+                        wi[o * WROW + s * p.fi + f] = wv[s][j][i];
                         if (++f == p.fi) f = 0, ++o;
                     }
                 }
             }
-        }
         const int padw = KP - width;
         for (int e = threadIdx.x; e < kNarrowFo * padw; e += 256) {
             const int o = e / padw, f = e - o * padw;
-            wi[o * KP + width + f] = 0.f;
+            wi[o * WROW + width + f] = 0.f;
         }
     }
     __syncthreads();
     nb_bf16x8 fb[2][KS][3];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        const float *wr = reinterpret_cast<const float *>(lds) + (64 * wid + 32 * nb + c) * KP + 8 * h;
+        const float *wr = reinterpret_cast<const float *>(lds) + (64 * wid + 32 * nb + c) * WROW + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const nb_f32x4 v0 = *reinterpret_cast<const nb_f32x4 *>(wr + 16 * ks);
@@ -287,15 +290,13 @@ extern "C" int dc_tag_linear_fwd_narrow(const float *slab, int64_t ld, const flo
         DC_REQUIRE(ws[s], "dc_tag_linear_fwd_narrow: null weight segment %d", s);
         p.w[s] = ws[s];
     }
-    // 64-row tiles unless 32-row ones balance the 256 persistent workgroups better (rigid B = 32: 381 x 64 rows = 2 rounds of
-    // which the second is half empty; 762 x 32 rows = 3 rounds of 32)
-    const int64_t t64 = (N + 63) / 64, t32 = (N + 31) / 32;
-    const int64_t r64 = (t64 + 255) / 256 * 2, r32 = (t32 + 255) / 256;
+    // 32-row tiles: four (soft) / three (rigid) per persistent workgroup at B = 32 - measured 23.1 / 20.8 us against 25.1 / 22.6 us
+    // with 64-row tiles (two / one and a half per workgroup); DC_NARROW_MB=2 forces the tall tile
     static const int force_mb = [] {
         const char *v = getenv("DC_NARROW_MB");
         return (v && *v) ? atoi(v) : 0;
     }();
-    const int mb = force_mb ? force_mb : (r32 < r64 ? 1 : 2);
+    const int mb = force_mb == 2 ? 2 : 1;
     hipStream_t hs = (hipStream_t)stream;
     switch (wpad) {
     case 96: narrow_launch<6>(p, mb, hs); break;
