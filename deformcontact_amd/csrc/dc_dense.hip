@@ -452,8 +452,7 @@ static void dw_plan(int64_t N, int64_t Fi, int64_t Fo, int nseg, int64_t *chunk_
                     int *nchunks) {
     const int64_t BM = 64 * dw_mb(Fo);
     const int64_t tiles = ((Fo + BM - 1) / BM) * ((Fi + BN - 1) / BN) * nseg;
-    // (DC_DW_TARGET / DC_DW_MAXCHUNKS: A/B switches of tools/r06/dw_narrow_probe.sh)
-    static const int target = env_int("DC_DW_TARGET", 512), maxchunks = env_int("DC_DW_MAXCHUNKS", 128);
+    constexpr int target = 512, maxchunks = 128;
     int64_t want = target / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
     if (want > maxchunks) want = maxchunks;   // keeps the slab-reduce pass short
