@@ -139,7 +139,7 @@ _SIGNATURES = {
     "dc_tag_pack_weights": (c_int, [POINTER(_vp), c_int, _vp, c_int64, c_int64, c_int64, _vp]),
     "dc_tag_linear_fwd_narrow_ok": (c_int, [c_int64, c_int, c_int64, c_int64]),
     "dc_tag_linear_fwd_narrow": (c_int, [_vp, c_int64, POINTER(_vp), c_int, c_int64, _vp, c_int, _vp, c_int64, c_int64,
-                                         c_int64, c_int64, c_int, _vp]),
+                                         c_int64, c_int64, _vp]),
     "dc_attn_softmax_rows": (c_int, [_vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp]),
     "dc_attn_exp_rows": (c_int, [_vp, c_int64, c_int64, c_int64, c_int64, _vp, _vp]),
     "dc_attn_ds_rows": (c_int, [_vp, _vp, c_int64, c_int64, c_int64, _vp, _vp, _vp]),

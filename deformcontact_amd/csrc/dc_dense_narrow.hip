@@ -250,228 +250,6 @@ k_fwd_narrow(NarrowParams p) {
     if (prev_row0 >= 0) store_rows(prev_row0);
 }
 
-// ---- the same block on the fp16 matrix cores: two power-of-two-scaled fp16 planes, three products (dc_dense.h: H2Scales) ----
-// Why a second form.  The six-product kernel above keeps 24 * KS VGPRs of weight fragments (316 VGPRs in all): one workgroup per
-// CU, and its phases - row loads, MFMAs, row stores - add up instead of overlapping (profiles/r06/e_narrow_abl.txt).  Two
-// fp16 planes need 16 * KS: the kernel fits 256 VGPRs, TWO workgroups share a CU (and the soft and the rigid branch's launches
-// can share CUs), one's memory phases run under the other's MFMAs, and the MFMA work halves.  The scales cost nothing here:
-// a tile row is the whole reduction, so its maximum is formed by the eight lanes that load it (three xor-shuffles), and a
-// weight column's maximum by the two lanes that hold its fragments.  Accuracy: that of the wide layers' blocks (< 2e-6 per row
-// against float64, tests/test_narrow_dense.py); NOT bit-identical to the six-product form.
-using nb_f16x4 = __attribute__((ext_vector_type(4))) _Float16;
-using nb_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-
-template <int KS>
-__global__ void __launch_bounds__(256, 2)
-k_fwd_narrow_h2(NarrowParams p) {
-    constexpr int TR = 32;                              // rows per tile
-    constexpr int SROWA = KS * 64 + 16;                 // plane image row: [ks][plane][half][8 fp16] + pad (conflict-free b128)
-    constexpr int PPR = 4 * KS, NV = (PPR + 7) / 8;     // float4 pieces per row; per lane (8 lanes per row)
-    constexpr int KP = 16 * KS, WROW = KP + 4;
-    constexpr int kOffInv = ((TR * SROWA + 127) / 128) * 128;               // row unscale factors [TR]
-    constexpr int kOffStage = ((kOffInv + TR * 4 + 1023) / 1024) * 1024;
-    constexpr int kLdsTiles = kOffStage + TR * 1024, kLdsW = (kNarrowFo / 2) * WROW * 4;   // weight image: 128 columns at a time
-    __shared__ __attribute__((aligned(1024))) char lds[kLdsTiles > kLdsW ? kLdsTiles : kLdsW];
-    char *const sA = lds;
-    float *const sinv = reinterpret_cast<float *>(lds + kOffInv);
-    float *const so = reinterpret_cast<float *>(lds + kOffStage);
-    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int c = lane & 31, h = lane >> 5;
-    const int xr = threadIdx.x >> 3, xc = threadIdx.x & 7;       // staging: row xr of the tile, pieces xc, xc + 8, ...
-
-    nb_f32x4 xv[NV];
-    auto load_tile = [&](int t) {
-        int64_t row = (int64_t)t * TR + xr;
-        row = row < p.N ? row : p.N - 1;
-        const float *src = p.x + row * p.ld + 4 * xc;
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            if (PPR % 8 == 0 || xc + 8 * j < PPR) xv[j] = *reinterpret_cast<const nb_f32x4 *>(src + 32 * j);
-    };
-    int t = blockIdx.x;
-    if (t < p.ntiles) load_tile(t);                     // the first tile's rows travel while the weights are prepared
-
-    // ---- weights: fp32 image of 128 columns at a time (coalesced float4 reads of the lins[k].weight matrices, all in flight
-    // together), fragments picked by the two waves that own those columns, column maxima -> scales -> two fp16 planes ----
-    nb_f16x8 fb[2][KS][2];
-    float icol[2];
-    {
-        float *wi = reinterpret_cast<float *>(lds);
-        const int width = p.nseg * p.fi, half4 = (kNarrowFo / 2) * p.fi / 4;     // float4 pieces per segment and column half
-        constexpr int MAXQ = 4;                                                 // fi <= 32: 128 * 32 / 4 / 256
-        auto image_half = [&](int hh) {                                         // columns 128 hh .. + 127 -> wi[128][WROW]
-            nb_f32x4 wv[kMaxSeg][MAXQ];
-#pragma unroll
-            for (int s = 0; s < kMaxSeg; ++s)
-#pragma unroll
-                for (int j = 0; j < MAXQ; ++j) {
-                    const int q = (int)threadIdx.x + 256 * j;
-                    if (s < p.nseg && q < half4)
-                        wv[s][j] = *reinterpret_cast<const nb_f32x4 *>(p.w[s] + (int64_t)hh * 128 * p.fi + 4 * q);
-                }
-#pragma unroll
-            for (int s = 0; s < kMaxSeg; ++s)
-#pragma unroll
-                for (int j = 0; j < MAXQ; ++j) {
-                    const int q = (int)threadIdx.x + 256 * j;
-                    if (s < p.nseg && q < half4) {
-                        int o = (4 * q) / p.fi, f = 4 * q - o * p.fi;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            wi[o * WROW + s * p.fi + f] = wv[s][j][i];
-                            if (++f == p.fi) f = 0, ++o;
-                        }
-                    }
-                }
-            const int padw = KP - width;
-            for (int e = threadIdx.x; e < (kNarrowFo / 2) * padw; e += 256) {
-                const int o = e / padw, f = e - o * padw;
-                wi[o * WROW + width + f] = 0.f;
-            }
-        };
-        auto pick = [&]() {                                                     // this wave's 64 columns out of the image
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const float *wr = wi + (64 * (wid & 1) + 32 * nb + c) * WROW + 8 * h;
-                float m = 0.f;                           // (two passes over the LDS image: no register copy of the column)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const nb_f32x4 v = *reinterpret_cast<const nb_f32x4 *>(wr + 16 * ks + 4 * e);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(v[i]));
-                    }
-                m = fmaxf(m, __shfl_xor(m, 32));         // the column's other eight-k halves
-                const float sc = h2_scale(m);
-                icol[nb] = h2_unscale(m);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const nb_f32x4 v = *reinterpret_cast<const nb_f32x4 *>(wr + 16 * ks + 4 * e);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float x = v[i] * sc;
-                            const _Float16 a = (_Float16)x;
-                            fb[nb][ks][0][4 * e + i] = a;
-                            fb[nb][ks][1][4 * e + i] = (_Float16)(x - (float)a);
-                        }
-                    }
-            }
-        };
-        // the wave pair that owns a half waits at the barriers of the other half's pass; every wave runs pick() exactly once
-        if (wid < 2) {
-            image_half(0);
-            __syncthreads();
-            pick();
-            __syncthreads();
-            image_half(1);
-            __syncthreads();
-        } else {
-            image_half(0);
-            __syncthreads();
-            __syncthreads();
-            image_half(1);
-            __syncthreads();
-            pick();
-        }
-    }
-    __syncthreads();                                    // the image's LDS becomes the plane / staging images
-    float bcol[2];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) bcol[nb] = p.bias ? p.bias[64 * wid + 32 * nb + c] : 0.f;
-    const bool relu = p.relu != 0;
-
-    // rows of the tile -> row maximum (8 lanes) -> scaled fp16 planes in LDS; the row's unscale factor beside them
-    auto store_tile = [&]() {
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-            if (PPR % 8 == 0 || xc + 8 * j < PPR)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) m = fmaxf(m, fabsf(xv[j][i]));
-        m = fmaxf(m, __shfl_xor(m, 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
-        m = fmaxf(m, __shfl_xor(m, 4));
-        const float sc = h2_scale(m);
-        if (xc == 0) sinv[xr] = h2_unscale(m);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int c4 = xc + 8 * j;
-            if (PPR % 8 != 0 && c4 >= PPR) continue;
-            nb_f16x4 hi, lo;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float x = xv[j][i] * sc;
-                const _Float16 a = (_Float16)x;
-                hi[i] = a;
-                lo[i] = (_Float16)(x - (float)a);
-            }
-            char *dst = sA + xr * SROWA + (c4 >> 2) * 64 + ((c4 >> 1) & 1) * 16 + (c4 & 1) * 8;
-            *reinterpret_cast<nb_f16x4 *>(dst) = hi;
-            *reinterpret_cast<nb_f16x4 *>(dst + 32) = lo;
-        }
-    };
-    auto store_rows = [&](int64_t row0) {
-#pragma unroll 4
-        for (int r = wid; r < TR; r += 4) {
-            const int64_t row = row0 + r;
-            const nb_f32x4 v = *reinterpret_cast<const nb_f32x4 *>(so + r * 256 + 4 * lane);
-            if (row < p.N) *reinterpret_cast<nb_f32x4 *>(p.out + row * p.ldo + 4 * lane) = v;
-        }
-    };
-    int64_t prev_row0 = -1;
-    for (; t < p.ntiles; t += gridDim.x) {              // (iteration order: see k_fwd_narrow)
-        const int64_t row0 = (int64_t)t * TR;
-        store_tile();
-        if (prev_row0 >= 0) store_rows(prev_row0);
-        if (t + (int)gridDim.x < p.ntiles) load_tile(t + gridDim.x);
-        nb_lds_barrier();                               // A
-        f32x16 acc[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-        constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};          // h2 * h1, h1 * h2, h1 * h1: smallest terms first
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            nb_f16x8 fa[2];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                fa[pl] = *reinterpret_cast<const nb_f16x8 *>(sA + c * SROWA + ks * 64 + pl * 32 + h * 16);
-#pragma unroll
-            for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa[tt]], fb[nb][ks][pb[tt]], acc[nb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float sv = sinv[rl];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                float v = (acc[nb][r] * sv) * icol[nb];
-                v += bcol[nb];
-                if (relu) v = fmaxf(v, 0.f);
-                so[rl * 256 + 64 * wid + 32 * nb + c] = v;
-            }
-        }
-        nb_lds_barrier();                               // B
-        prev_row0 = row0;
-    }
-    if (prev_row0 >= 0) store_rows(prev_row0);
-}
-
-template <int KS>
-static void narrow_h2_launch(const NarrowParams &p0, hipStream_t hs) {
-    NarrowParams p = p0;
-    p.ntiles = (int)((p.N + 31) / 32);
-    const unsigned grid = (unsigned)(p.ntiles < 512 ? p.ntiles : 512);          // two persistent workgroups per CU
-    DC_LAUNCH((k_fwd_narrow_h2<KS>), dim3(grid), dim3(256), 0, hs, p);
-}
-
 template <int KS>
 static void narrow_launch(const NarrowParams &p0, int mb, hipStream_t hs) {
     NarrowParams p = p0;
@@ -496,8 +274,7 @@ extern "C" int dc_tag_linear_fwd_narrow_ok(int64_t fi, int nseg, int64_t wpad, i
 
 extern "C" int dc_tag_linear_fwd_narrow(const float *slab, int64_t ld, const float *const *ws, int nseg, int64_t fi,
                                         const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t wpad,
-                                        int64_t Fo, int products, dc_stream_t stream) {
-    DC_REQUIRE(products == 6 || products == 2, "dc_tag_linear_fwd_narrow: products must be 6 (bf16 x 3) or 2 (fp16 x 2)");
+                                        int64_t Fo, dc_stream_t stream) {
     DC_REQUIRE(dc_tag_linear_fwd_narrow_ok(fi, nseg, wpad, Fo),
                "dc_tag_linear_fwd_narrow: needs Fo = 256, a padded reduction of 96 / 112 / 128 >= nseg * fi (got Fo=%lld wpad=%lld "
                "nseg=%d fi=%lld)", (long long)Fo, (long long)wpad, nseg, (long long)fi);
@@ -521,14 +298,6 @@ extern "C" int dc_tag_linear_fwd_narrow(const float *slab, int64_t ld, const flo
     }();
     const int mb = force_mb == 2 ? 2 : 1;
     hipStream_t hs = (hipStream_t)stream;
-    if (products == 2) {
-        switch (wpad) {
-        case 96: narrow_h2_launch<6>(p, hs); break;
-        case 112: narrow_h2_launch<7>(p, hs); break;
-        default: narrow_h2_launch<8>(p, hs); break;
-        }
-        return check_launch("dc_tag_linear_fwd_narrow (fp16x2)");
-    }
     switch (wpad) {
     case 96: narrow_launch<6>(p, mb, hs); break;
     case 112: narrow_launch<7>(p, mb, hs); break;

@@ -204,9 +204,6 @@ DENSE_PRODUCTS = 6
 #: registers, no packing launch; bit-identical to the six-product split kernel); ``DC_NARROW_FWD=0``: ``dc_tag_pack_weights`` +
 #: ``dc_tag_linear_fwd_split`` as up to round 5
 NARROW_FWD = os.environ.get("DC_NARROW_FWD", "1") != "0"
-#: its arithmetic: 6 = exact three-way bf16 split (bit-identical to the split kernel), 2 = two scaled fp16 planes, three
-#: products (the wide layers' arithmetic; two workgroups per CU)
-NARROW_PRODUCTS = int(os.environ.get("DC_NARROW_PRODUCTS", "6"))
 
 #: fp16x2 mode of the wide (Fi % 16 == 0, unconcatenated) dense blocks: two power-of-two-scaled
 #: fp16 planes per operand and THREE MFMA products instead of the six of the bf16 split - still
@@ -609,7 +606,7 @@ class _TagConvFn(torch.autograd.Function):
         elif narrow:
             rc = L.dc_tag_linear_fwd_narrow(slab.data_ptr(), slab.stride(0), _ptr_array(ws), k + 1, fi,
                                             b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n,
-                                            wpad, fo, NARROW_PRODUCTS, st)
+                                            wpad, fo, st)
         elif DENSE_SPLIT_BF16:
             rc = L.dc_tag_linear_fwd_split(*args, DENSE_PRODUCTS, st)
         else:

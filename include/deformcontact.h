@@ -352,15 +352,13 @@ int dc_tag_linear_fwd_split(const float *const *xs, const int64_t *ldxs, const f
  * followed by the F.relu of models/model.py:71,77):
  *     out[N, 256] = act(slab[N, wpad] . [W_0 | ... | W_{nseg-1} | 0]^T + bias)
  * slab = the layer's hop slab, (nseg * fi) data columns zero-padded to wpad = 96 / 112 / 128; ws[k] = lins[k].weight
- * [256, fi], read as they are (no packing launch).  products = 6: exact three-way bf16 split, six MFMA products,
- * bit-identical to dc_tag_linear_fwd_split (products = 6) on the packed weights; products = 2: two power-of-two-scaled fp16
- * planes, three products (row / column maxima formed inside the kernel), fp32-accurate like the wide layers' blocks, two
- * workgroups per compute unit.  One persistent launch, weights resident in registers, whole reduction in one stage,
- * 1-KiB row stores (dc_dense_narrow.hip).  _ok: host-side query whether the entry takes a shape. */
+ * [256, fi], read as they are (no packing launch).  Six-product bf16 arithmetic, bit-identical to dc_tag_linear_fwd_split
+ * (products = 6) on the packed weights.  One persistent launch, weights resident in registers, whole reduction in one
+ * stage, 1-KiB row stores (dc_dense_narrow.hip).  _ok: host-side query whether the entry takes a shape. */
 int dc_tag_linear_fwd_narrow_ok(int64_t fi, int nseg, int64_t wpad, int64_t Fo);
 int dc_tag_linear_fwd_narrow(const float *slab, int64_t ld, const float *const *ws, int nseg, int64_t fi,
                              const float *bias, int relu, float *out, int64_t ldo, int64_t N, int64_t wpad,
-                             int64_t Fo, int products, dc_stream_t stream);
+                             int64_t Fo, dc_stream_t stream);
 int64_t dc_tag_linear_bwd_dx_split_workspace_bytes(int64_t Fi, int64_t Fo, int nseg);
 int dc_tag_linear_bwd_dx_split(const float *g, int64_t ldg, const float *out_for_mask,
                                int64_t ldo, const float *const *ws, int nseg, float *const *gxs,

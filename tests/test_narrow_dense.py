@@ -35,7 +35,7 @@ def test_narrow_forward_block_bit_identical_to_split_kernel_and_fp32_accurate(n,
     out = base[:, :fo]
     _lib.check(L.dc_tag_linear_fwd_narrow(slab.data_ptr(), slab.stride(0), _ptr_array(ws), nseg, fi,
                                           bias.data_ptr() if bias_on else None, int(relu), out.data_ptr(), out.stride(0), n,
-                                          wpad, fo, 6, st), "narrow")
+                                          wpad, fo, st), "narrow")
     wcat = torch.empty(fo, wpad, device=dev)
     _lib.check(L.dc_tag_pack_weights(_ptr_array(ws), nseg, wcat.data_ptr(), fo, fi, wpad, st), "pack")
     ref = torch.empty(n, fo, device=dev)
@@ -53,16 +53,6 @@ def test_narrow_forward_block_bit_identical_to_split_kernel_and_fp32_accurate(n,
         t = t.clamp_min(0)
     den = t.abs().amax(1, keepdim=True).clamp_min(1e-300)
     assert float(((out.double().cpu() - t).abs() / den).max()) < 2e-6
-    # the fp16x2 form (two scaled fp16 planes, three products, two workgroups per CU): fp32-accurate, not bit-identical
-    base2 = torch.full((n, fo + ldo_pad), float("nan"), device=dev)
-    out2 = base2[:, :fo]
-    _lib.check(L.dc_tag_linear_fwd_narrow(slab.data_ptr(), slab.stride(0), _ptr_array(ws), nseg, fi,
-                                          bias.data_ptr() if bias_on else None, int(relu), out2.data_ptr(), out2.stride(0), n,
-                                          wpad, fo, 2, st), "narrow fp16x2")
-    torch.cuda.synchronize()
-    assert float(((out2.double().cpu() - t).abs() / den).max()) < 2e-6
-    if ldo_pad:
-        assert torch.isnan(base2[:, fo:]).all()
 
 
 def test_first_layer_of_a_tagconv_uses_the_narrow_kernel_and_no_packing_launch():

@@ -29,7 +29,7 @@ for name, n, fi, wpad in (("soft", 32768, 21, 96), ("rigid", 24384, 25, 112)):
     bias = torch.randn(fo, device=dev)
     def new(k):
         s, o = slabs[k % 6], outs[k % 6]
-        L.dc_tag_linear_fwd_narrow(s.data_ptr(), s.stride(0), _ptr_array(ws), 4, fi, bias.data_ptr(), 1, o.data_ptr(), o.stride(0), n, wpad, fo, int(os.environ.get("NP", "6")), st)
+        L.dc_tag_linear_fwd_narrow(s.data_ptr(), s.stride(0), _ptr_array(ws), 4, fi, bias.data_ptr(), 1, o.data_ptr(), o.stride(0), n, wpad, fo, st)
     for k in range(5): new(k)
     ts = []
     for _ in range(3):

@@ -2,7 +2,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r06_narrow
 mkdir -p $O
-timeout 600 python -m pytest tests/test_narrow_dense.py -x -q -m gpu 2>&1 | tail -n 6
+timeout 600 python -m pytest tests/test_narrow_dense.py tests/test_full_size.py -x -q -m gpu 2>&1 | tail -n 6
 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_narrow/narrow_time.txt
 import torch, os
 from deformcontact_amd import _lib, ops
@@ -28,7 +28,7 @@ for name, n, fi, wpad in (("soft", 32768, 21, 96), ("rigid", 24384, 25, 112)):
     i = [0]
     def new():
         i[0] += 1; s, o = slabs[i[0] % 6], outs[i[0] % 6]
-        L.dc_tag_linear_fwd_narrow(s.data_ptr(), s.stride(0), _ptr_array(ws), 4, fi, bias.data_ptr(), 1, o.data_ptr(), o.stride(0), n, wpad, fo, int(os.environ.get("NP", "6")), st)
+        L.dc_tag_linear_fwd_narrow(s.data_ptr(), s.stride(0), _ptr_array(ws), 4, fi, bias.data_ptr(), 1, o.data_ptr(), o.stride(0), n, wpad, fo, st)
     def old():
         i[0] += 1; s, o = slabs[i[0] % 6], outs[i[0] % 6]
         L.dc_tag_pack_weights(_ptr_array(ws), 4, wcat.data_ptr(), fo, fi, wpad, st)
@@ -38,8 +38,8 @@ for name, n, fi, wpad in (("soft", 32768, 21, 96), ("rigid", 24384, 25, 112)):
         t = timeit(fn)
         print(f"{name:5s} {tag:20s} {t:6.1f} us  {mb / t * 1e-3 * 1e3:7.1f} GB/s = {mb / t / 8e3 * 1e3:.3f} of 8 TB/s", flush=True)
 PY
-for np in 6 2; do echo "products=$np (6 = bf16x3 one workgroup per CU, 2 = fp16x2 two per CU)"; NP=$np python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r06_narrow/narrow_time.txt
-import torch, os
+for mb in 1 2; do echo "DC_NARROW_MB=$mb"; DC_NARROW_MB=$mb python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r06_narrow/narrow_time.txt
+import torch
 from deformcontact_amd import _lib, ops
 from deformcontact_amd.graph import current_stream_ptr
 from deformcontact_amd.ops import _ptr_array
@@ -52,7 +52,7 @@ for name, n, fi, wpad in (("soft", 32768, 21, 96), ("rigid", 24384, 25, 112)):
     bias = torch.randn(fo, device=dev)
     def new(k):
         s, o = slabs[k % 6], outs[k % 6]
-        L.dc_tag_linear_fwd_narrow(s.data_ptr(), s.stride(0), _ptr_array(ws), 4, fi, bias.data_ptr(), 1, o.data_ptr(), o.stride(0), n, wpad, fo, int(os.environ.get("NP", "6")), st)
+        L.dc_tag_linear_fwd_narrow(s.data_ptr(), s.stride(0), _ptr_array(ws), 4, fi, bias.data_ptr(), 1, o.data_ptr(), o.stride(0), n, wpad, fo, st)
     for k in range(5): new(k)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -62,8 +62,6 @@ for name, n, fi, wpad in (("soft", 32768, 21, 96), ("rigid", 24384, 25, 112)):
 PY
 done
 timeout 200 python tools/r06/skip_probe.py base 2>&1 | grep -E "^==|ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/  two streams: \1 ms/'
-DC_NARROW_PRODUCTS=2 timeout 200 python tools/r06/skip_probe.py base 2>&1 | grep -E "ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/  two streams, DC_NARROW_PRODUCTS=2: \1 ms/'
-DC_NARROW_PRODUCTS=2 timeout 200 python tools/r06/skip_probe.py base --serial-branches 2>&1 | grep -E "ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/  one stream, DC_NARROW_PRODUCTS=2: \1 ms/'
 DC_NARROW_FWD=0 timeout 200 python tools/r06/skip_probe.py base 2>&1 | grep -E "ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/  two streams, DC_NARROW_FWD=0: \1 ms/'
 timeout 200 python tools/r06/skip_probe.py base --serial-branches 2>&1 | grep -E "ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/  one stream: \1 ms/'
 DC_NARROW_FWD=0 timeout 200 python tools/r06/skip_probe.py base --serial-branches 2>&1 | grep -E "ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/  one stream, DC_NARROW_FWD=0: \1 ms/'
