@@ -212,42 +212,6 @@ NARROW_FWD = os.environ.get("DC_NARROW_FWD", "1") != "0"
 DENSE_F16X2 = os.environ.get("DC_DENSE_F16X2", "1") != "0"
 
 
-#: Whole-CU kernels take turns.  The wide dense blocks (``k_fwd_h2d``, ``k_dw_h2w``: one 512-thread workgroup with 160 KB of LDS
-#: per CU) of the two encoder branches run on two streams; when two of them are in flight together they do not share the chip,
-#: they alternate per CU - and both run 1.5 - 1.7 x longer than alone (round-6 timeline, ``profiles/r06/j_step_timeline_default.txt``:
-#: the two forward blocks 87 + 107 us side by side against 50 + 60 us alone; round 5 saw 151 against 115 us for the two dW
-#: blocks and ordered ONE pair by hand, ``DW_POSITION``).  With the turnstile every such launch waits (stream event) for the
-#: previous one of the device, whatever stream that was issued on: big kernels run one at a time in host issue order, small
-#: ones still fill the gaps of the other stream.  ``DC_TURNSTILE=0`` off, ``2`` also the chain launches.
-TURNSTILE = int(os.environ.get("DC_TURNSTILE", "1"))
-_TURNSTILE_LAST = {}        # device index -> (event, capture id it was recorded under)
-
-
-class _turnstile:
-    """``with _turnstile(dev):`` around ONE launch of a whole-CU kernel on the current stream."""
-
-    def __init__(self, dev, level: int = 1):
-        self.dev, self.on = dev, TURNSTILE >= level
-
-    def __enter__(self):
-        if self.on:
-            from .graph import capture_id
-            self.cid = capture_id(self.dev)
-            last = _TURNSTILE_LAST.get(self.dev.index)
-            # (an event recorded under another capture - or eagerly, seen from inside a capture - cannot be waited on here,
-            # and need not be: that work is complete or ordered by the capture's own roots)
-            if last is not None and last[1] == self.cid:
-                torch.cuda.current_stream(self.dev).wait_event(last[0])
-        return self
-
-    def __exit__(self, *exc):
-        if self.on and exc[0] is None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.dev))
-            _TURNSTILE_LAST[self.dev.index] = (ev, self.cid)
-        return False
-
-
 #: K chained hops of a batch with a known layout as ONE launch with every graph's slice resident in LDS
 #: (``dc_hop_chain_f32``, bit-identical to the K single hops); ``DC_HOP_CHAIN=0``: hop by hop.
 HOP_CHAIN = os.environ.get("DC_HOP_CHAIN", "1") != "0"
@@ -285,12 +249,11 @@ def hop_chain(g, adj: SortedAdjacency, slab: torch.Tensor, f: int, k: int, weigh
     w = adj.w if weighted else None
     # the adjacency's weights are gcn_norm's (graph.GraphIndex builds nothing else): tell the kernel so
     deg = g.fwd.ptr if (HOP_CHAIN_GCN and w is not None and g.normalize and not g.self_loops) else None
-    with _turnstile(slab.device, level=2):
-        rc = _lib.lib().dc_hop_chain_f32(
-            adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
-            deg.data_ptr() if deg is not None else None, adj.other.numel(),
-            nptr, nseg, slab.data_ptr(), slab.stride(0), slab.size(0), f, k, int(src_block), int(direction),
-            rowmax.data_ptr() if rowmax is not None else None, int(rowmax_mode), current_stream_ptr(slab.device))
+    rc = _lib.lib().dc_hop_chain_f32(
+        adj.ptr.data_ptr(), adj.other.data_ptr(), w.data_ptr() if w is not None else None,
+        deg.data_ptr() if deg is not None else None, adj.other.numel(),
+        nptr, nseg, slab.data_ptr(), slab.stride(0), slab.size(0), f, k, int(src_block), int(direction),
+        rowmax.data_ptr() if rowmax is not None else None, int(rowmax_mode), current_stream_ptr(slab.device))
     _lib.check(rc, "dc_hop_chain_f32")
 
 
@@ -636,11 +599,10 @@ class _TagConvFn(torch.autograd.Function):
             if prepped is None:
                 prepped = _h2_weight_prep(L, ws, k, fo, fi, ctx.needs_input_grad[1] and fo % 16 == 0, dev, st)
             wmax, wimg, wt, wt_rowmax = prepped
-            with _turnstile(dev):
-                rc = L.dc_tag_linear_fwd_h2p(slab.data_ptr(), slab.stride(0), wimg.data_ptr(),
-                                             b.data_ptr() if b is not None else None, int(relu),
-                                             out.data_ptr(), ldo, n, width, fo,
-                                             rowmax.data_ptr(), wmax.data_ptr(), None, 0, st)
+            rc = L.dc_tag_linear_fwd_h2p(slab.data_ptr(), slab.stride(0), wimg.data_ptr(),
+                                         b.data_ptr() if b is not None else None, int(relu),
+                                         out.data_ptr(), ldo, n, width, fo,
+                                         rowmax.data_ptr(), wmax.data_ptr(), None, 0, st)
         elif narrow:
             rc = L.dc_tag_linear_fwd_narrow(slab.data_ptr(), slab.stride(0), _ptr_array(ws), k + 1, fi,
                                             b.data_ptr() if b is not None else None, int(relu), out.data_ptr(), ldo, n,
@@ -708,8 +670,7 @@ class _TagConvFn(torch.autograd.Function):
                         _ptr_array(outs), k + 1, fi, gb_out.data_ptr() if gb_out is not None else None,
                         int(direct), scratch.data_ptr(), nbytes, n, fi_eff, fo)
                 if g_rowmax is not None and n % 16 == 0:
-                    with _turnstile(dev):
-                        rc = L.dc_tag_linear_bwd_dw_h2(*args, g_rowmax.data_ptr(), xrowmax.data_ptr(), st)
+                    rc = L.dc_tag_linear_bwd_dw_h2(*args, g_rowmax.data_ptr(), xrowmax.data_ptr(), st)
                 elif DENSE_SPLIT_BF16:
                     rc = L.dc_tag_linear_bwd_dw_split(*args, DENSE_PRODUCTS, st)
                 else:
@@ -760,10 +721,9 @@ class _TagConvFn(torch.autograd.Function):
                                                     wt.data_ptr(), wt_rowmax.data_ptr(), st),
                                "dc_tag_weight_prep")
                 gx = torch.empty((n, fi), dtype=torch.float32, device=dev)
-                with _turnstile(dev):
-                    rc = L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gld, wt.data_ptr(), None, 0, gx.data_ptr(),
-                                                 fi, n, gwid, fi, hop_rowmax.data_ptr(), wt_rowmax.data_ptr(),
-                                                 None, 0, st)
+                rc = L.dc_tag_linear_fwd_h2p(gslab.data_ptr(), gld, wt.data_ptr(), None, 0, gx.data_ptr(),
+                                             fi, n, gwid, fi, hop_rowmax.data_ptr(), wt_rowmax.data_ptr(),
+                                             None, 0, st)
                 _lib.check(rc, "dc_tag_linear_fwd_h2 (dX)")
                 if DEBUG_TAP is not None:
                     DEBUG_TAP(f"bwd{fi}x{fo}.hop_rowmax", hop_rowmax)
