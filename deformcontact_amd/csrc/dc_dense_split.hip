@@ -20,6 +20,12 @@
 // conflict-free.  dW (both operands node-major) stays on the fp32 kernel.
 #include "dc_dense.h"
 
+// timing-only ablations of k_dw_split (tools/r06/dw_abl.sh builds this file with -DDC_DWS_ABL=<bits>; results are wrong by
+// construction): 1 no MFMAs, 2 no mask loads, 4 no partial stores, 8 no gradient loads, 16 no x loads
+#ifndef DC_DWS_ABL
+#define DC_DWS_ABL 0
+#endif
+
 namespace dc {
 
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
@@ -389,10 +395,13 @@ struct SplitOpRC {
     __device__ __forceinline__ void load() {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            v[j] = *reinterpret_cast<const float4 *>(p[j]);
+            if ((DC_DWS_ABL & 8) && MASK) v[j] = make_float4(1.f, 2.f, 3.f, (float)j);
+            else if ((DC_DWS_ABL & 16) && !MASK) v[j] = make_float4(1.f, 2.f, 3.f, (float)j);
+            else v[j] = *reinterpret_cast<const float4 *>(p[j]);
             p[j] += step;
             if (MASK) {
-                m[j] = *reinterpret_cast<const float4 *>(pm[j]);
+                if (DC_DWS_ABL & 2) m[j] = make_float4(1.f, -1.f, 1.f, 1.f);
+                else m[j] = *reinterpret_cast<const float4 *>(pm[j]);
                 pm[j] += mstep;
             }
         }
@@ -520,14 +529,15 @@ k_dw_split(DwParams p) {
             A.load();
             B.load();
         }
-        mma_split<MB, NP>(f, acc);
+        if (!(DC_DWS_ABL & 1)) mma_split<MB, NP>(f, acc);
+        else acc[0][0][it & 15] += (float)f.a[0][0][0] * (float)f.b[0][0][0];
         __syncthreads();
     }
     float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
     for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
         const int64_t o = o0 + r, ff = f0 + c;
         if (Planes<NP>::F16) v = (v * inva) * invb;
-        if (o < p.Fo && ff < p.Fi) out[o * p.Fi + ff] = v;
+        if (o < p.Fo && ff < p.Fi && (!(DC_DWS_ABL & 4) || v == 12345.678f)) out[o * p.Fi + ff] = v;
     });
     if (do_bias) {
         __syncthreads();
