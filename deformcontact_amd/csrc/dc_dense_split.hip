@@ -18,8 +18,6 @@
 // from registers into LDS (v_cvt_pk_bf16_f32 + exact subtractions), 112-byte LDS rows
 // (3 x 32 B planes + 16 B pad) keep both the b64 plane stores and the b128 fragment reads
 // conflict-free.  dW (both operands node-major) stays on the fp32 kernel.
-#include <type_traits>
-
 #include "dc_dense.h"
 
 // timing-only ablations of k_dw_split (tools/r06/dw_abl.sh builds this file with -DDC_DWS_ABL=<bits>; results are wrong by
@@ -364,19 +362,16 @@ template <int COLS, int NP> struct TrImage {
 };
 
 // fp32 [K][cols] (col contiguous) operand tile BK x COLS: split at LDS-store time into 3 images
-// D register sets: the tile of stage it + D is requested while stage it computes (see k_dw_split)
-constexpr int kDwRing = 4;
 template <int COLS, bool MASK, int NP>
 struct SplitOpRC {
     static constexpr int P = Planes<NP>::P;
     static constexpr int NV = COLS / 64;
     static constexpr int PER = COLS / 4, KPER = 256 / PER;
-    static constexpr int D = kDwRing;
     using Img = TrImage<COLS, NP>;
     const float *p[NV];
     const float *pm[MASK ? NV : 1];
-    float4 v[D][NV];
-    float4 m[D][MASK ? NV : 1];
+    float4 v[NV];
+    float4 m[MASK ? NV : 1];
     int off[NV];
     int64_t step, mstep;
     float sc;                                        // fp16x2 mode: power-of-two tensor scale
@@ -397,33 +392,30 @@ struct SplitOpRC {
         step = BK * ld;
         mstep = BK * mld;
     }
-    template <int S>
     __device__ __forceinline__ void load() {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            if ((DC_DWS_ABL & 8) && MASK) v[S][j] = make_float4(1.f, 2.f, 3.f, (float)j);
-            else if ((DC_DWS_ABL & 16) && !MASK) v[S][j] = make_float4(1.f, 2.f, 3.f, (float)j);
-            else v[S][j] = *reinterpret_cast<const float4 *>(p[j]);
+            if ((DC_DWS_ABL & 8) && MASK) v[j] = make_float4(1.f, 2.f, 3.f, (float)j);
+            else if ((DC_DWS_ABL & 16) && !MASK) v[j] = make_float4(1.f, 2.f, 3.f, (float)j);
+            else v[j] = *reinterpret_cast<const float4 *>(p[j]);
             p[j] += step;
             if (MASK) {
-                if (DC_DWS_ABL & 2) m[S][j] = make_float4(1.f, -1.f, 1.f, 1.f);
-                else m[S][j] = *reinterpret_cast<const float4 *>(pm[j]);
+                if (DC_DWS_ABL & 2) m[j] = make_float4(1.f, -1.f, 1.f, 1.f);
+                else m[j] = *reinterpret_cast<const float4 *>(pm[j]);
                 pm[j] += mstep;
             }
         }
     }
-    template <int S>
     __device__ __forceinline__ float4 value(int j) const {
-        if (!MASK) return v[S][j];
-        return make_float4(m[S][j].x > 0.f ? v[S][j].x : 0.f, m[S][j].y > 0.f ? v[S][j].y : 0.f,
-                           m[S][j].z > 0.f ? v[S][j].z : 0.f, m[S][j].w > 0.f ? v[S][j].w : 0.f);
+        if (!MASK) return v[j];
+        return make_float4(m[j].x > 0.f ? v[j].x : 0.f, m[j].y > 0.f ? v[j].y : 0.f,
+                           m[j].z > 0.f ? v[j].z : 0.f, m[j].w > 0.f ? v[j].w : 0.f);
     }
-    template <int S>
     __device__ __forceinline__ void store(char *lds) const {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             if (Planes<NP>::F16) {
-                float4 x = value<S>(j);
+                float4 x = value(j);
                 x = make_float4(x.x * sc, x.y * sc, x.z * sc, x.w * sc);
                 f16x4 h, l;
                 split4_h2(x, h, l);
@@ -432,7 +424,7 @@ struct SplitOpRC {
                 continue;
             }
             bf16x4 hi, mid, lo;
-            split4(value<S>(j), hi, mid, lo);
+            split4(value(j), hi, mid, lo);
             *reinterpret_cast<bf16x4 *>(lds + off[j]) = hi;
             if (P > 1) *reinterpret_cast<bf16x4 *>(lds + off[j] + Img::PLANE) = mid;
             if (P > 2) *reinterpret_cast<bf16x4 *>(lds + off[j] + 2 * Img::PLANE) = lo;
@@ -493,15 +485,29 @@ k_dw_split(DwParams p) {
         A.sc = h2_scale(am), B.sc = h2_scale(bm);
         inva = h2_unscale(am), invb = h2_unscale(bm);
     }
-    // Stage it lives in LDS buffer it & 1 and - before that - in register set it % D (D = kDwRing).  Round 6: the loads of stage
-    // it + 2 used to be issued in iteration it and consumed in iteration it + 1 - ONE stage of MFMAs (0.45 us) to cover a memory
-    // round trip of 1 - 2 us, sixteen times per workgroup; the timing-only ablations showed every load stream fully exposed
-    // (profiles/r06/n_dw_narrow_abl.txt).  Now stage it + D is requested in iteration it (D - 1 stages of cover), in a
-    // steady-state loop WITHOUT conditional loads (behind a load under a branch hipcc waits for the newest loads, vmcnt(0)),
-    // followed by D peeled iterations that only drain the ring.  Same loads, same order of MFMAs: same bits.
-    constexpr int D = kDwRing;
-    auto stage_body = [&](auto S1, auto SL, int it, bool store_next, bool load_more) {
-        // S1 = register set of stage it + 1 (stored now), SL = set that receives stage it + D
+    auto bias_acc = [&]() {
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < OA::NV; ++j) {
+                const float4 x = A.value(j);
+                bsum4.x += x.x, bsum4.y += x.y, bsum4.z += x.z, bsum4.w += x.w;
+            }
+        }
+    };
+    const int nst = (int)((n_end - n_beg) / BK);
+    if (nst > 0) {
+        A.load();
+        B.load();
+        A.store(lds);
+        B.store(lds + kOffB);
+        bias_acc();
+        if (nst > 1) {
+            A.load();
+            B.load();
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < nst; ++it) {
         const char *cur = lds + (it & 1) * kStage;
         char *nxt = lds + ((it + 1) & 1) * kStage;
         SplitFrag<MB, NP> f;
@@ -514,68 +520,18 @@ k_dw_split(DwParams p) {
             for (int nb = 0; nb < 2; ++nb)
                 f.b[nb][pl] = tr_operand<IB::ROWB>(cur + kOffB + pl * IB::PLANE, wn * 64 + nb * 32);
         }
-        if (store_next) {
-            A.template store<decltype(S1)::value>(nxt);
-            B.template store<decltype(S1)::value>(nxt + kOffB);
-            if (do_bias) {
-#pragma unroll
-                for (int j = 0; j < OA::NV; ++j) {
-                    const float4 x = A.template value<decltype(S1)::value>(j);
-                    bsum4.x += x.x, bsum4.y += x.y, bsum4.z += x.z, bsum4.w += x.w;
-                }
-            }
+        if (it + 1 < nst) {
+            A.store(nxt);
+            B.store(nxt + kOffB);
+            bias_acc();
         }
-        if (load_more) {
-            A.template load<decltype(SL)::value>();
-            B.template load<decltype(SL)::value>();
+        if (it + 2 < nst) {
+            A.load();
+            B.load();
         }
         if (!(DC_DWS_ABL & 1)) mma_split<MB, NP>(f, acc);
         else acc[0][0][it & 15] += (float)f.a[0][0][0] * (float)f.b[0][0][0];
         __syncthreads();
-    };
-    const int nst = (int)((n_end - n_beg) / BK);
-    // prologue: stages 0 .. D - 1 into sets 0 .. D - 1 (as many as exist), stage 0 into LDS
-    if (nst > 0) {
-        A.template load<0>();
-        B.template load<0>();
-    }
-    if (nst > 1) { A.template load<1>(); B.template load<1>(); }
-    if (nst > 2) { A.template load<2>(); B.template load<2>(); }
-    if (nst > 3) { A.template load<3>(); B.template load<3>(); }
-    static_assert(kDwRing == 4, "the prologue and the unrolled bodies below are written for four register sets");
-    if (nst > 0) {
-        A.template store<0>(lds);
-        B.template store<0>(lds + kOffB);
-        if (do_bias) {
-#pragma unroll
-            for (int j = 0; j < OA::NV; ++j) {
-                const float4 x = A.template value<0>(j);
-                bsum4.x += x.x, bsum4.y += x.y, bsum4.z += x.z, bsum4.w += x.w;
-            }
-        }
-        // set 0 is free again: stage D
-        if (nst > D) { A.template load<0>(); B.template load<0>(); }
-    }
-    __syncthreads();
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    int it = 0;
-    // steady state: iteration it stores stage it + 1 (set (it + 1) % 4) and requests stage it + 1 + D into the same set - both
-    // unconditionally while it + 1 + D < nst
-    for (; it + 4 + D < nst; it += 4) {
-        stage_body(I1{}, I1{}, it, true, true);
-        stage_body(I2{}, I2{}, it + 1, true, true);
-        stage_body(I3{}, I3{}, it + 2, true, true);
-        stage_body(I0{}, I0{}, it + 3, true, true);
-    }
-    // drain: the remaining stages, loads only where a stage is left to request
-    for (; it < nst; it += 4) {
-        stage_body(I1{}, I1{}, it, it + 1 < nst, it + 1 + D < nst);
-        if (it + 1 < nst) stage_body(I2{}, I2{}, it + 1, it + 2 < nst, it + 2 + D < nst);
-        if (it + 2 < nst) stage_body(I3{}, I3{}, it + 2, it + 3 < nst, it + 3 + D < nst);
-        if (it + 3 < nst) stage_body(I0{}, I0{}, it + 3, it + 4 < nst, it + 4 + D < nst);
     }
     float *out = p.partial + ((int64_t)chunk * p.nseg + s) * p.Fo * p.Fi;
     for_each_acc<MB>(acc, wm, wn, [&](int r, int c, float v) {
