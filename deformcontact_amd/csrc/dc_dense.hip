@@ -422,15 +422,59 @@ __device__ __forceinline__ void dw_reduce_body(const ReduceParams &p) {
     }
 }
 
+// one thread per output, 256 outputs per block: few chunks (the wide layers' 32) - the walk is short and the wider loads win
+__device__ __forceinline__ void dw_reduce_body1(const ReduceParams &p) {
+    const int64_t per_out = p.Fo * p.cols, total = per_out * p.ngw;
+    const int64_t seg_elems = p.Fo * p.Fi, slab = seg_elems * p.nseg;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float *src;
+    float *dst;
+    int64_t stride;
+    if (i < total) {
+        const int j = (int)(i / per_out);
+        const int64_t rem = i % per_out, o = rem / p.cols, c = rem % p.cols;
+        src = p.partial + (int64_t)(j / p.bps) * seg_elems + o * p.Fi + (int64_t)(j % p.bps) * p.cols + c;
+        dst = p.gw[j] + rem;
+        stride = slab;
+    } else if (p.gbias && i < total + p.Fo) {
+        src = p.bias_partial + (i - total);
+        dst = p.gbias + (i - total);
+        stride = p.Fo;
+    } else {
+        return;
+    }
+    float s = 0.f;
+    int c = 0;
+    for (; c + 8 <= p.nchunks; c += 8) {          // 8 independent loads in flight, fixed add order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(c + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < p.nchunks; ++c) s += src[(int64_t)c * stride];
+    *dst = p.accumulate ? *dst + s : s;
+}
+
 __global__ void __launch_bounds__(256)
-k_dw_reduce(ReduceParams p) { dw_reduce_body(p); }
+k_dw_reduce(ReduceParams p) { dw_reduce_body1(p); }
+__global__ void __launch_bounds__(256)
+k_dw_reduce4(ReduceParams p) { dw_reduce_body(p); }
+// the form by chunk count: from 64 chunks on (the first layers' 128) four threads share an output
+constexpr int kReduce4From = 64;
+static inline void launch_reduce(const ReduceParams &r, int64_t total, hipStream_t hs) {
+    if (r.nchunks >= kReduce4From)
+        DC_LAUNCH(k_dw_reduce4, dim3((unsigned)((total + kReduceOutputs - 1) / kReduceOutputs)), dim3(256), 0, hs, r);
+    else
+        DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, r);
+}
 
 // one launch for the groups of a grouped dW (blockIdx.y = group): each group sums its own chunk range
 struct ReduceGroups {
     ReduceParams g[kMaxGroups];
 };
 __global__ void __launch_bounds__(256)
-k_dw_reduce_grouped(ReduceGroups rg) { dw_reduce_body(rg.g[blockIdx.y]); }
+k_dw_reduce_grouped(ReduceGroups rg) { dw_reduce_body1(rg.g[blockIdx.y]); }
 
 static inline Mat make_mat(const float *p, int64_t ld, bool *vec) {
     if (((uintptr_t)p & 15) != 0 || (ld % 4) != 0) *vec = false;
@@ -544,7 +588,7 @@ static int fwd_impl(const float *const *xs, const int64_t *ldxs, const float *co
                 r.partial = p.kpartial, r.gw[0] = out, r.Fi = Fo, r.Fo = N, r.cols = Fo;
                 r.nseg = 1, r.nchunks = p.ksplit, r.ngw = 1, r.bps = 1, r.accumulate = 0;
                 const int64_t total = N * Fo;
-                DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total + kReduceOutputs - 1) / kReduceOutputs)), dim3(256), 0, hs, r);
+                launch_reduce(r, total, hs);
             }
             return check_launch("dc_tag_linear_fwd_h2");
         }
@@ -750,7 +794,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
         r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = nslots;
         r.cols = gw_cols, r.ngw = ngw, r.bps = ngw / nseg, r.accumulate = accumulate;
         const int64_t total_c = (int64_t)ngw * Fo * gw_cols + (gbias ? Fo : 0);
-        DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total_c + kReduceOutputs - 1) / kReduceOutputs)), dim3(256), 0, hs, r);
+        launch_reduce(r, total_c, hs);
         return check_launch("dc_tag_linear_bwd_dw_h2_corr");
     }
     if (ragged) {
@@ -797,8 +841,7 @@ static int dw_impl(const float *g, int64_t ldg, const float *out_for_mask, int64
     r.Fi = Fi, r.Fo = Fo, r.nseg = nseg, r.nchunks = nslots;
     r.cols = gw_cols, r.ngw = ngw, r.bps = ngw / nseg, r.accumulate = accumulate;
     const int64_t total = (int64_t)ngw * Fo * gw_cols + (gbias ? Fo : 0);
-    DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total + kReduceOutputs - 1) / kReduceOutputs)), dim3(256), 0,
-                       (hipStream_t)stream, r);
+    launch_reduce(r, total, (hipStream_t)stream);
     return check_launch("dc_tag_linear_bwd_dw");
 }
 
@@ -1488,7 +1531,7 @@ extern "C" int dc_tag_grouped_bwd_dw_h2(const float *g, int64_t ldg, const float
         r.ngw = nseg, r.bps = 1, r.accumulate = accumulate;
     }
     const int64_t total = (int64_t)nseg * Fo * Fi + (any_bias ? Fo : 0);
-    DC_LAUNCH(k_dw_reduce_grouped, dim3((unsigned)((total + kReduceOutputs - 1) / kReduceOutputs), (unsigned)ngroups), dim3(256), 0,
+    DC_LAUNCH(k_dw_reduce_grouped, dim3((unsigned)((total + 255) / 256), (unsigned)ngroups), dim3(256), 0,
                        hs, rg);
     return check_launch("dc_tag_grouped_bwd_dw_h2");
 }
@@ -1549,6 +1592,6 @@ extern "C" int dc_tag_linear_bwd_dw_bf16(const uint16_t *g, int64_t ldg, const u
     r.Fi = Fi, r.Fo = Fo, r.cols = Fi, r.nseg = nseg, r.nchunks = N > 0 ? p.nchunks : 0;
     r.ngw = nseg, r.bps = 1, r.accumulate = accumulate;
     const int64_t total = (int64_t)nseg * Fo * Fi + (gbias ? Fo : 0);
-    DC_LAUNCH(k_dw_reduce, dim3((unsigned)((total + kReduceOutputs - 1) / kReduceOutputs)), dim3(256), 0, hs, r);
+    launch_reduce(r, total, hs);
     return check_launch("dc_tag_linear_bwd_dw_bf16");
 }
