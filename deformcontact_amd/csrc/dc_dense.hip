@@ -1125,12 +1125,27 @@ __device__ __forceinline__ void weight_prep_body(const WPrepParams &p) {
             p.wt_rowmax[i] = 0.f;
     const int64_t rb = (p.Fo + 3) / 4;
     float m = 0.f;
+    // up to 256 x 256 per segment (the encoder's layers) a wave keeps its row / column in registers between the maximum and the
+    // image pass - one trip to L2 per wave instead of two dependent ones (round 6: the launch sits on each branch's critical path)
+    const bool small = p.Fi <= 256 && p.Fo <= 256;
     if ((int64_t)blockIdx.x < rb) {
         const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
         if (o >= p.Fo) return;
-        for (int s = 0; s < p.nseg; ++s) {
-            const float *wr = p.w[s] + o * p.Fi;
-            for (int64_t c = lane; c < p.Fi; c += 64) m = fmaxf(m, fabsf(wr[c]));
+        float v[kMaxSeg][4];
+        if (small) {
+#pragma unroll
+            for (int s = 0; s < kMaxSeg; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t c = lane + 64 * j;
+                    v[s][j] = (s < p.nseg && c < p.Fi) ? p.w[s][o * p.Fi + c] : 0.f;
+                    m = fmaxf(m, fabsf(v[s][j]));
+                }
+        } else {
+            for (int s = 0; s < p.nseg; ++s) {
+                const float *wr = p.w[s] + o * p.Fi;
+                for (int64_t c = lane; c < p.Fi; c += 64) m = fmaxf(m, fabsf(wr[c]));
+            }
         }
 #pragma unroll
         for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
@@ -1138,26 +1153,58 @@ __device__ __forceinline__ void weight_prep_body(const WPrepParams &p) {
         if (p.wimg) {
             const float sc = h2_scale(m);
             _Float16 *row = p.wimg + o * (2 * p.nseg * p.Fi);
-            for (int s = 0; s < p.nseg; ++s) {
-                const float *wr = p.w[s] + o * p.Fi;
-                for (int64_t c = lane; c < p.Fi; c += 64) wprep_put(row, s * p.Fi + c, wr[c], sc);
+            if (small) {
+#pragma unroll
+                for (int s = 0; s < kMaxSeg; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t c = lane + 64 * j;
+                        if (s < p.nseg && c < p.Fi) wprep_put(row, s * p.Fi + c, v[s][j], sc);
+                    }
+            } else {
+                for (int s = 0; s < p.nseg; ++s) {
+                    const float *wr = p.w[s] + o * p.Fi;
+                    for (int64_t c = lane; c < p.Fi; c += 64) wprep_put(row, s * p.Fi + c, wr[c], sc);
+                }
             }
         }
     } else {
         const int64_t f = ((int64_t)blockIdx.x - rb) * 4 + (threadIdx.x >> 6);
         if (f >= p.Fi) return;
-        for (int s = 0; s < p.nseg; ++s) {
-            const float *wc = p.w[s] + f;
-            for (int64_t o = lane; o < p.Fo; o += 64) m = fmaxf(m, fabsf(wc[o * p.Fi]));
+        float v[kMaxSeg][4];
+        if (small) {
+#pragma unroll
+            for (int s = 0; s < kMaxSeg; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t o = lane + 64 * j;
+                    v[s][j] = (s < p.nseg && o < p.Fo) ? p.w[s][o * p.Fi + f] : 0.f;
+                    m = fmaxf(m, fabsf(v[s][j]));
+                }
+        } else {
+            for (int s = 0; s < p.nseg; ++s) {
+                const float *wc = p.w[s] + f;
+                for (int64_t o = lane; o < p.Fo; o += 64) m = fmaxf(m, fabsf(wc[o * p.Fi]));
+            }
         }
 #pragma unroll
         for (int q = 32; q >= 1; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
         if (lane == 0) p.wt_rowmax[f] = m;
         const float sc = h2_scale(m);
         _Float16 *row = p.wtimg + f * (2 * p.nseg * p.Fo);
-        for (int s = 0; s < p.nseg; ++s) {
-            const float *wc = p.w[s] + f;
-            for (int64_t o = lane; o < p.Fo; o += 64) wprep_put(row, s * p.Fo + o, wc[o * p.Fi], sc);
+        if (small) {
+#pragma unroll
+            for (int s = 0; s < kMaxSeg; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t o = lane + 64 * j;
+                    if (s < p.nseg && o < p.Fo) wprep_put(row, s * p.Fo + o, v[s][j], sc);
+                }
+        } else {
+            for (int s = 0; s < p.nseg; ++s) {
+                const float *wc = p.w[s] + f;
+                for (int64_t o = lane; o < p.Fo; o += 64) wprep_put(row, s * p.Fo + o, wc[o * p.Fi], sc);
+            }
         }
     }
 }
