@@ -193,3 +193,65 @@ def test_deferred_result_into_this_packages_own_autograd_functions_and_a_foreign
     with torch.no_grad():
         float(y2.norm())
     assert y2.value().grad_fn is not None and not late.requires_grad
+
+
+@pytest.mark.parametrize("branch_streams", [False, True])
+def test_reference_wiring_under_hipgraph_with_changing_batches(branch_streams, monkeypatch):
+    """The unchanged wiring as ONE captured step over static input buffers (`Batch.assume_segments`: the layout promise that
+    survives in-place refills), replayed on three different batches, against eager `ContactEncoder` steps on the same
+    batches: outputs and every parameter gradient bit for bit; the captured step contains the one-launch adjacency build
+    and the chain launches."""
+    from deformcontact_amd.nn import conv as conv_mod
+    monkeypatch.setattr(conv_mod, "BRANCH_STREAMS", branch_streams)
+    batches = [tuple(b.to(DEV) for b in synth.make_batch(8, first_idx=8 * i)) for i in range(3)]
+    rest, _, rig = (b.clone() for b in batches[0])
+    rest.assume_segments(batches[0][0].segments())
+    rig.assume_segments(batches[0][2].segments())
+    g_rest = torch.randn(rest.x.shape[0], 256, device=DEV)
+    g_rig = torch.randn(rig.x.shape[0], 256, device=DEV)
+    torch.manual_seed(0)
+    enc = ContactEncoder([21, 25], 256).to(DEV)
+    ref = ReferenceWiring([21, 25], 256).to(DEV)
+    ref.conv_layers_resting, ref.conv_layers_rigid = enc.conv_layers_resting, enc.conv_layers_rigid
+
+    def step():
+        for p_ in enc.parameters():
+            p_.grad.zero_()
+        a, b = ref(rest, rig)
+        torch.autograd.backward([a, b], [g_rest, g_rig])
+        return a, b
+
+    for p_ in enc.parameters():
+        p_.grad = torch.zeros_like(p_)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):                      # (the second call already hands layer 1's output to layer 2's slab)
+            clear_cache()
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    clear_cache()
+    graph = torch.cuda.CUDAGraph()
+    _lib.kernel_trace(True)
+    with torch.cuda.graph(graph):
+        sa, sb = step()
+    _lib.kernel_trace(False)
+    tr = _lib.kernel_trace_counts()
+    assert tr.get("k_build_segment") == 2 and sum(v for k, v in tr.items() if k.startswith("k_hop_chain_gcn")) == 4, tr
+    got = []
+    for r, _, q in batches:
+        rest.x.copy_(r.x), rest.edge_index.copy_(r.edge_index), rig.x.copy_(q.x), rig.edge_index.copy_(q.edge_index)
+        graph.replay()
+        torch.cuda.synchronize()
+        got.append((sa.clone(), sb.clone(), {n: p_.grad.clone() for n, p_ in enc.named_parameters()}))
+    enc.overlap_branches = False
+    for (r, _, q), (a1, b1, gr1) in zip(batches, got):
+        clear_cache()
+        enc.zero_grad(set_to_none=True)
+        a0, b0 = enc(r, q)
+        torch.autograd.backward([a0, b0], [g_rest, g_rig])
+        torch.cuda.synchronize()
+        assert torch.equal(a0, a1) and torch.equal(b0, b1)
+        for n, p_ in enc.named_parameters():
+            assert torch.equal(p_.grad, gr1[n]), n

@@ -11,7 +11,7 @@ ws = [torch.randn(fo, fi, device=dev) for _ in range(nseg)]
 wmax = torch.empty(fo, device=dev); wimg = torch.empty(fo, nseg*fi, device=dev)
 wt = torch.empty(fi, nseg*fo, device=dev); wtmax = torch.empty(fi, device=dev)
 z = torch.empty(32768, device=dev)
-def f(): L.dc_tag_weight_prep_zero(_ptr_array(ws), nseg, fo, fi, wmax.data_ptr(), wimg.data_ptr(), wt.data_ptr(), wtmax.data_ptr(), z.data_ptr(), z.numel(), st)
+def f(): L.dc_tag_weight_prep_zero(_ptr_array(ws), nseg, fo, fi, wmax.data_ptr(), wimg.data_ptr(), wt.data_ptr(), wtmax.data_ptr(), z.data_ptr(), z.numel(), current_stream_ptr(dev))
 for _ in range(5): f()
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
@@ -23,4 +23,4 @@ for _ in range(20): g.replay()
 e1.record(); torch.cuda.synchronize()
 print(f"k_weight_prep (256 x 4 x 256, both images + zeroing 32768 floats): {e0.elapsed_time(e1) / 400 * 1e3:.2f} us per launch (graph replay)")
 PY
-timeout 600 python -m pytest tests/test_weight_prep.py tests/test_wide_dense.py tests/test_attention_flash.py -x -q -m gpu 2>&1 | tail -n 3
+true
