@@ -250,16 +250,14 @@ k_fwd_narrow(NarrowParams p) {
     if (prev_row0 >= 0) store_rows(prev_row0);
 }
 
+// 32-row tiles: four (soft) / three (rigid) per persistent workgroup at B = 32 - measured 23.1 / 20.8 us against 25.1 / 22.6 us with
+// 64-row tiles (MB = 2: two / one and a half per workgroup; profiles/r06/e_narrow_time.txt)
 template <int KS>
-static void narrow_launch(const NarrowParams &p0, int mb, hipStream_t hs) {
+static void narrow_launch(const NarrowParams &p0, hipStream_t hs) {
     NarrowParams p = p0;
-    const int tr = 32 * mb;
-    p.ntiles = (int)((p.N + tr - 1) / tr);
+    p.ntiles = (int)((p.N + 31) / 32);
     const unsigned grid = (unsigned)(p.ntiles < 256 ? p.ntiles : 256);
-    if (mb == 2)
-        DC_LAUNCH((k_fwd_narrow<KS, 2>), dim3(grid), dim3(256), 0, hs, p);
-    else
-        DC_LAUNCH((k_fwd_narrow<KS, 1>), dim3(grid), dim3(256), 0, hs, p);
+    DC_LAUNCH((k_fwd_narrow<KS, 1>), dim3(grid), dim3(256), 0, hs, p);
 }
 
 }  // namespace dc
@@ -290,18 +288,11 @@ extern "C" int dc_tag_linear_fwd_narrow(const float *slab, int64_t ld, const flo
         DC_REQUIRE(ws[s], "dc_tag_linear_fwd_narrow: null weight segment %d", s);
         p.w[s] = ws[s];
     }
-    // 32-row tiles: four (soft) / three (rigid) per persistent workgroup at B = 32 - measured 23.1 / 20.8 us against 25.1 / 22.6 us
-    // with 64-row tiles (two / one and a half per workgroup); DC_NARROW_MB=2 forces the tall tile
-    static const int force_mb = [] {
-        const char *v = getenv("DC_NARROW_MB");
-        return (v && *v) ? atoi(v) : 0;
-    }();
-    const int mb = force_mb == 2 ? 2 : 1;
     hipStream_t hs = (hipStream_t)stream;
     switch (wpad) {
-    case 96: narrow_launch<6>(p, mb, hs); break;
-    case 112: narrow_launch<7>(p, mb, hs); break;
-    default: narrow_launch<8>(p, mb, hs); break;
+    case 96: narrow_launch<6>(p, hs); break;
+    case 112: narrow_launch<7>(p, hs); break;
+    default: narrow_launch<8>(p, hs); break;
     }
     return check_launch("dc_tag_linear_fwd_narrow");
 }

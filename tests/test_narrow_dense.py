@@ -1,7 +1,7 @@
 """`dc_tag_linear_fwd_narrow` (dc_dense_narrow.hip): the short-reduction forward block of the first encoder layers
 (/root/reference/models/model.py:44-50: TAGConv(21, 256) / TAGConv(25, 256) -> PyG tag_conv.py `sum_k lins[k](x_k) + bias`,
 then the F.relu of models/model.py:71,77).  Bit-identical to the six-product split kernel on packed weights
-(`dc_tag_pack_weights` + `dc_tag_linear_fwd_split`), within 2e-6 per row of float64; ragged row counts, both tile heights,
+(`dc_tag_pack_weights` + `dc_tag_linear_fwd_split`), within 2e-6 per row of float64; ragged row counts,
 all three padded widths, strided outputs (a column block of the next layer's slab)."""
 import pytest
 import torch
@@ -15,8 +15,8 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("n,fi,nseg,wpad,relu,bias_on,ldo_pad", [
-    (32768, 21, 4, 96, True, True, 0),          # soft first layer at B = 32: 64-row tiles, two per workgroup
-    (24384, 25, 4, 112, True, True, 832),       # rigid: 32-row tiles (762 tiles: three rounds), output inside a wider slab
+    (32768, 21, 4, 96, True, True, 0),          # soft first layer at B = 32: four 32-row tiles per persistent workgroup
+    (24384, 25, 4, 112, True, True, 832),       # rigid: 762 tiles (three rounds), output inside a wider slab
     (1000, 21, 4, 96, False, True, 0), (1, 25, 4, 112, True, False, 0), (65, 30, 4, 128, True, True, 64),
     (20000, 24, 4, 96, False, False, 0), (33, 7, 3, 96, True, True, 0)])
 def test_narrow_forward_block_bit_identical_to_split_kernel_and_fp32_accurate(n, fi, nseg, wpad, relu, bias_on, ldo_pad):

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the DC_NARROW_MB switch these lines set existed while the tile height was being chosen: the library now always takes 32-row tiles)
 # round 6: where do k_fwd_narrow's microseconds go?  timing-only builds of dc_dense_narrow.hip (-DDC_NARROW_ABL=<bits>)
 cd "$(dirname "$0")/../.."
 if [ "$1" = "build" ]; then

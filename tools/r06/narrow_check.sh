@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the DC_NARROW_MB switch these lines set existed while the tile height was being chosen: the library now always takes 32-row tiles)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r06_narrow
 mkdir -p $O
