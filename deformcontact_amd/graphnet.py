@@ -309,6 +309,9 @@ class CrossAttention(nn.Module):
         xcat = torch.cat([x_resting, x_rigid], dim=0) if joint else None
         ns = x_resting.size(0)
         heads = list(self.attention_heads)
+        if (self.dense_products and eligible and not use_fused and x_resting.size(1) % 32 == 0 and x_resting.size(1) >= 128
+                and x_resting.size(0) * x_rigid.size(0) >= self.dense_products_min_scores):
+            return self._dense_products(x_resting, x_rigid, heads, return_list)
         if (joint and not use_fused and self.batched_heads and len(heads) > 1 and x_rigid.size(0) > 0
                 and all(h.weight.shape == heads[0].weight.shape and (h.bias is None) == (heads[0].bias is None) for h in heads)):
             # ... and all heads at once: ONE dense block with the heads' weights stacked along the output ([N, H d]), the
@@ -323,9 +326,6 @@ class CrossAttention(nn.Module):
             o = torch.bmm(p, x_rigid.unsqueeze(0).expand(hn, -1, -1))          # [H, ns, dv]
             pooled = list(o.unbind(0))
             return pooled if return_list else torch.cat(pooled, dim=-1)
-        if (self.dense_products and eligible and not use_fused and x_resting.size(1) % 32 == 0 and x_resting.size(1) >= 128
-                and x_resting.size(0) * x_rigid.size(0) >= self.dense_products_min_scores):
-            return self._dense_products(x_resting, x_rigid, heads, return_list)
         for head in heads:
             if joint:
                 qk = _linear(head, xcat)
