@@ -265,28 +265,6 @@ class CrossAttention(nn.Module):
                 pooled.append(torch.cat(parts, dim=0))
         return torch.cat(pooled, dim=-1)
 
-    #: mid-size score matrices (between `dense_products_min_scores` and `fused_min_scores`: the shipped batch 4 has 12.5 M scores):
-    #: the materialising formula, with its two big products per head (scores, pooling) and their four backward products on this
-    #: library's fp16x2 dense blocks instead of fp32 rocBLAS kernels (694 us of the batch-4 step's 1,960 us of kernels); the
-    #: softmax stays stock.  Keys are padded to a multiple of 32 rows (zero features: their value rows are zero; their score columns
-    #: are set to -inf before the softmax).  ``DC_ATTN_DENSE=0`` off.
-    dense_products = os.environ.get("DC_ATTN_DENSE", "1") != "0"
-    dense_products_min_scores = 1 << 22
-
-    def _dense_products(self, x_resting, x_rigid, heads, return_list):
-        ns, nr, d = x_resting.size(0), x_rigid.size(0), x_rigid.size(1)
-        nrp = (nr + 31) // 32 * 32
-        xr = x_rigid if nrp == nr else torch.cat([x_rigid, x_rigid.new_zeros(nrp - nr, d)], dim=0)
-        vt = xr.t().contiguous()                                            # [dv, nrp]: the pooling product's "weight"
-        pooled = []
-        for head in heads:
-            q, k = _linear(head, x_resting), _linear(head, xr)              # padded key rows = the head's bias: masked below
-            s = ops.dense_linear(q, k)                                      # [ns, nrp] = q k^T
-            if nrp != nr:
-                s[:, nr:] = float("-inf")
-            pooled.append(ops.dense_linear(torch.softmax(s, dim=-1), vt))    # [ns, dv] = p v
-        return pooled if return_list else torch.cat(pooled, dim=-1)
-
     def forward(self, x_resting, x_rigid, segments=None, return_list=False):
         if self.per_graph_mask:
             if segments is None or segments[0] is None or segments[1] is None:
@@ -309,9 +287,6 @@ class CrossAttention(nn.Module):
         xcat = torch.cat([x_resting, x_rigid], dim=0) if joint else None
         ns = x_resting.size(0)
         heads = list(self.attention_heads)
-        if (self.dense_products and eligible and not use_fused and x_resting.size(1) % 32 == 0 and x_resting.size(1) >= 128
-                and x_resting.size(0) * x_rigid.size(0) >= self.dense_products_min_scores):
-            return self._dense_products(x_resting, x_rigid, heads, return_list)
         if (joint and not use_fused and self.batched_heads and len(heads) > 1 and x_rigid.size(0) > 0
                 and all(h.weight.shape == heads[0].weight.shape and (h.bias is None) == (heads[0].bias is None) for h in heads)):
             # ... and all heads at once: ONE dense block with the heads' weights stacked along the output ([N, H d]), the

@@ -11,9 +11,8 @@ import bench  # noqa: E402
 from deformcontact_amd.graphnet import CrossAttention  # noqa: E402
 
 dev = torch.device("cuda:0")
-for batch in (4, 8):
-    for dense in (False, True):
-        CrossAttention.fused = "auto"
-        CrossAttention.dense_products = dense
+for batch in (4, 8, 16):
+    for mode in ("0", "1"):
+        CrossAttention.fused = mode
         r = bench.full_step_b4(dev, steps=20, batch=batch)
-        print(f"batch {batch} dense_products={dense}: {r['ms_per_step']} ms per step (hipgraph {r['hipgraph']}), loss {r['loss']}", flush=True)
+        print(f"batch {batch} fused={mode}: {r['ms_per_step']} ms per step (hipgraph {r['hipgraph']}), loss {r['loss']}", flush=True)
